@@ -1,0 +1,33 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load
+
+
+def synth_audio(utt, n, fs, S=10):
+    """SURVEY.md 8(d) synthetic-audio recipe (same as tests/golden/make_golden.py)."""
+    rng = np.random.default_rng(1234 + utt)
+    s = utt % S
+    f0 = 90 + 3 * s
+    t = np.arange(n) / fs
+    x = 0.3 * sum(np.sin(2 * np.pi * h * f0 * t) / h for h in range(1, 6)) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t))
+    x = x + 0.05 * rng.standard_normal(n)
+    return np.clip(x, -1, 1).astype(np.float32)

@@ -1,0 +1,121 @@
+"""The oracle (oracle/ref_cpu.py) pinned against outputs of the reference's own code
+(tests/golden/*.npz, made by tests/golden/make_golden.py which imports /root/reference)."""
+import numpy as np
+import pytest
+
+from oracle import ref_cpu as O
+
+SIGNALS = ["noise", "tone", "silence", "ragged", "short", "int16", "utt3s16k", "one_step"]
+GEOMS = [(8000, 512, 256), (16000, 512, 256), (16000, 256, 128), (8000, 1024, 512)]
+
+
+@pytest.mark.parametrize("name", SIGNALS)
+def test_mfcc_inrepo_matches_reference(golden, name):
+    g = golden("mfcc_inrepo")
+    x = g[f"x_{name}"]
+    for fs, L, st in GEOMS:
+        ref = g[f"mfcc_{name}_{fs}_{L}_{st}"]
+        got = O.MFCC(x, fs=fs, frameSize=L, step=st)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(O.MFCC_flat(x), g[f"flat_{name}"], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("name", SIGNALS)
+def test_enframe_matches_reference(golden, name):
+    g = golden("mfcc_inrepo")
+    x = g[f"x_{name}"].astype(np.float64)
+    for L, st in [(400, 160), (512, 256)]:
+        ref = g[f"enframe_{name}_{L}_{st}"]
+        got = O.enframe(x, L, st)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=1e-14, atol=1e-13)
+
+
+def test_filterbank_and_stmfcc(golden):
+    g = golden("mfcc_inrepo")
+    for fs, L, _ in GEOMS:
+        fb, fr = O.mfccInitFilterBanks(fs, L)
+        np.testing.assert_allclose(fb, g[f"fbank_{fs}_{L}"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(fr, g[f"freqs_{fs}_{L}"], rtol=0, atol=1e-12)
+    fb, _ = O.mfccInitFilterBanks(8000, 512)
+    np.testing.assert_allclose(O.stMFCC(g["stmfcc_X"], fb, 13), g["stmfcc_out"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", SIGNALS)
+def test_table_pipeline_equals_inrepo(golden, name):
+    """rfft + folded filterbank + DCT matrix == the reference's full-FFT arithmetic."""
+    g = golden("mfcc_inrepo")
+    x = g[f"x_{name}"]
+    for fs, L, st in GEOMS:
+        cfg, w, fb, dct = O.inrepo_tables(fs, L, st)
+        got = O.mfcc_pipeline(x, cfg, w, fb, dct)
+        np.testing.assert_allclose(got, g[f"mfcc_{name}_{fs}_{L}_{st}"], rtol=0, atol=1e-10)
+
+
+def test_delta_matches_reference(golden):
+    g = golden("delta_scale")
+    for T in (1, 2, 5, 298):
+        for D in (13, 26):
+            f = g[f"feat_{T}_{D}"]
+            np.testing.assert_allclose(O.delta(f), g[f"delta_{T}_{D}"], rtol=0, atol=1e-14)
+            np.testing.assert_allclose(O.delta(f, N=3), g[f"delta3_{T}_{D}"], rtol=0, atol=1e-14)
+            np.testing.assert_allclose(O.delta(O.delta(f)), g[f"ddelta_{T}_{D}"], rtol=0, atol=1e-14)
+    d32 = O.delta(g["feat_f32"])
+    assert d32.dtype == np.float32
+    np.testing.assert_allclose(d32, g["delta_f32"], rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        O.delta(g["feat_f32"], N=0)
+
+
+def test_scale_matches_sklearn(golden):
+    g = golden("delta_scale")
+    np.testing.assert_allclose(O.scale(g["scale_in"]), g["scale_out"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(O.scale(g["scale_one_in"]), g["scale_one_out"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("K,D", [(1, 13), (16, 26), (64, 39), (5, 7), (40, 39)])
+def test_gmm_score_samples_matches_sklearn(golden, K, D):
+    g = golden("gmm")
+    w, mu, cov, X = g[f"w_{K}_{D}"], g[f"mu_{K}_{D}"], g[f"cov_{K}_{D}"], g[f"X_{K}_{D}"]
+    np.testing.assert_allclose(O.gmm_score_samples(w, mu, cov, X), g[f"ss_{K}_{D}"], rtol=1e-12, atol=1e-11)
+    assert abs(O.gmm_score(w, mu, cov, X) - float(g[f"score_{K}_{D}"])) < 1e-11
+
+
+def test_score_matrix_matches_reference_loop(golden):
+    g = golden("gmm")
+    ubm = (g["sm_ubm_w"], g["sm_ubm_mu"], g["sm_ubm_cov"])
+    models = [(ubm[0], mu, ubm[2]) for mu in g["sm_spk_mu"]]
+    offs = np.concatenate([[0], np.cumsum(g["sm_lens"])])
+    feats = [g["sm_feats"][offs[j]:offs[j + 1]] for j in range(len(g["sm_lens"]))]
+    pred, am = O.score_matrix(models, ubm, feats)
+    np.testing.assert_allclose(pred, g["sm_pred"], rtol=0, atol=1e-11)
+    assert (am == g["sm_argmax"]).all()
+
+
+@pytest.mark.parametrize("d", [128, 256, 512, "tie"])
+def test_cosine_matches_scipy(golden, d):
+    g = golden("cosine")
+    X, C = g[f"X_{d}"], g[f"C_{d}"]
+    # scipy computes u.u in float32 for float32 u (sp:spatial/distance.py:682-685) => ~1e-7 differences
+    np.testing.assert_allclose(O.cosine_matrix(X, C), g[f"dist_{d}"], rtol=0, atol=5e-7)
+    assert (O.identify(X, C) == g[f"argmin_{d}"]).all()
+
+
+def test_eval_rule():
+    C = np.eye(4)
+    assert O.eval_rule(np.array([0.0, 1.0, 0.1, 0.0]), ["a", "b", "c", "d"], C) == "b"
+    # every distance >= 1 -> None (d_vector.py:352-357)
+    assert O.eval_rule(np.array([-1.0, -1.0, -1.0, -1.0]), ["a", "b", "c", "d"], C) is None
+
+
+def test_unpinned_presets_shapes():
+    """report/final.pdf IV-B-2: 1 s @ 16 kHz -> 98 x 13 (the only pinned fact for sidekit)."""
+    x = np.random.default_rng(0).standard_normal(16000)
+    out = O.sidekit_mfcc(x, fs=16000)
+    assert out[0].shape == (98, 13) and out[1].shape == (98,) and out[2] is None and out[3] is None
+    assert O.sidekit_mfcc(np.random.default_rng(1).standard_normal(48000))[0].shape == (298, 13)
+    cfg, w, fb, dct = O.sidekit_tables()
+    assert fb.shape == (24, 257) and int((fb != 0).sum()) == 454
+    assert O.librosa_mfcc_flat(np.random.default_rng(2).standard_normal(48000)).shape == (94 * 13,)
+    assert O.extract_feature_one(x).shape == (98, 26)
