@@ -1,0 +1,138 @@
+/*
+ * ssp.h — C-ABI of libsspgpu.so: the MI355X (gfx950) drop-in for the MFCC -> GMM-UBM /
+ * d-vector scoring hot path of kleinzcy/speech_signal_processing.
+ *
+ * The reference is pure Python and has no FFI for this path; each entry
+ * point below names the reference code it replaces.  Host code (Python, ctypes) keeps the
+ * reference's call surface and dispatches here.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns SSP_OK (0) or a negative ssp_status; ssp_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.  Nothing aborts.
+ *   - `where` = SSP_HOST (0): bulk arrays are host pointers, the library stages them through
+ *     device scratch;  SSP_DEVICE (1): bulk arrays are device pointers on the ctx's device.
+ *   - segment offsets (per-utterance sample / frame offsets) are small host-side metadata:
+ *     they are always HOST int64 arrays and are uploaded once into an ssp_segments handle.
+ *   - one ssp_ctx = one HIP device + one stream.  A ctx is not thread-safe; distinct ctxs are.
+ *   - all kernels are asynchronous on the ctx stream; SSP_HOST calls and calls that return
+ *     kernel_ms synchronise before returning.  kernel_ms (nullable) receives the device time
+ *     of the call's kernels measured with hipEvents on the ctx stream.
+ */
+#ifndef SSP_H_
+#define SSP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSP_ABI_VERSION 1
+
+typedef enum {
+    SSP_OK = 0,
+    SSP_ERR_INVALID = -1,     /* bad argument / shape */
+    SSP_ERR_UNSUPPORTED = -2, /* valid request the kernels do not cover */
+    SSP_ERR_HIP = -3,         /* HIP runtime error (message has hipGetErrorString) */
+    SSP_ERR_NOMEM = -4,
+    SSP_ERR_NODEVICE = -5
+} ssp_status;
+
+enum { SSP_HOST = 0, SSP_DEVICE = 1 };
+
+typedef struct ssp_ctx ssp_ctx;
+typedef struct ssp_segments ssp_segments;
+typedef struct ssp_mfcc_plan ssp_mfcc_plan;
+typedef struct ssp_gmm ssp_gmm;
+
+/* MFCC dialect knobs.  Three presets are built by the host side:
+ *   in-repo  utils/processing.py:19-144  (Hamming, |X|/L, 40 talkbox filters folded, log10(.+1e-8), c0..c12)
+ *   sidekit  sidekit.frontend.features.mfcc as called at GMM_UBM.py:89 / d_vector.py:91
+ *   librosa  librosa.feature.mfcc as called at MFCC_DTW.py:28-31 */
+typedef struct {
+    int32_t sample_rate;
+    int32_t win_len;      /* samples per analysis window (<= n_fft) */
+    int32_t hop;
+    int32_t n_fft;        /* power of two, 64..4096 */
+    int32_t n_filt;       /* rows of the filterbank table */
+    int32_t n_ceps;       /* rows of the DCT table */
+    int32_t frame_mode;   /* 0 floor, no pad (sidekit) | 1 ceil, zero-pad tail (utils/processing.py:27) | 2 centred, reflect (librosa) */
+    int32_t preemph_mode; /* 0 none | 1 per frame: y[0]=x[0]-a*x[0], y[n]=x[n]-a*x[n-1] */
+    float preemph;
+    int32_t spec_power;   /* 1 |X| | 2 |X|^2 */
+    float spec_scale;     /* multiplies the magnitude / power (1/L for the in-repo dialect, utils/processing.py:139) */
+    int32_t log_mode;     /* 0 ln | 1 log10 | 2 10*log10 */
+    int32_t floor_mode;   /* 0 none | 1 log(x+eps) (utils/processing.py:105) | 2 log(max(eps,x)) (librosa power_to_db) */
+    float eps;
+    float top_db;         /* <0 off; else clamp log-mel to (utterance max - top_db) (librosa power_to_db) */
+    int32_t delta_order;  /* 0 | 1 [c,dc] (GMM_UBM.py:90-91) | 2 [c,dc,ddc] */
+    int32_t delta_N;      /* regression half-width (GMM_UBM.py:53: N=2) */
+    int32_t cmvn;         /* 1: per-utterance sklearn.preprocessing.scale (GMM_UBM.py:93) */
+} ssp_mfcc_cfg;
+
+int ssp_abi_version(void);
+const char* ssp_last_error(void);
+
+/* ---- context: device + stream ------------------------------------------------------- */
+/* stream: nullable hipStream_t borrowed from the caller (e.g. torch's current stream);
+ * NULL = the library creates and owns one. */
+int ssp_ctx_create(int device, void* stream, ssp_ctx** out);
+int ssp_ctx_destroy(ssp_ctx* ctx);
+int ssp_ctx_sync(ssp_ctx* ctx);
+
+/* ---- segments: per-utterance offsets (host metadata -> device-resident) ------------- */
+/* offsets: HOST int64[n_seg+1], non-decreasing, offsets[0] >= 0. */
+int ssp_segments_create(ssp_ctx* ctx, const int64_t* offsets, int64_t n_seg, ssp_segments** out);
+int ssp_segments_destroy(ssp_segments* seg);
+int ssp_segments_count(const ssp_segments* seg, int64_t* n_seg, int64_t* total);
+int ssp_segments_read(const ssp_segments* seg, int64_t* offsets_out /* HOST int64[n_seg+1] */);
+
+/* ---- MFCC: replaces utils.processing.MFCC (utils/processing.py:110-144), sidekit mfcc call
+ *      sites (GMM_UBM.py:89, d_vector.py:91), librosa call site (MFCC_DTW.py:29), the delta
+ *      loop (GMM_UBM.py:53-69) and preprocessing.scale (GMM_UBM.py:93) as ONE fused pass ---- */
+/* window: HOST float[win_len]; fbank: HOST float[n_filt x (n_fft/2+1)] row-major (already folded
+ * for the in-repo dialect); dct: HOST float[n_ceps x n_filt] row-major. */
+int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* window, const float* fbank,
+                         const float* dct, ssp_mfcc_plan** out);
+int ssp_mfcc_plan_destroy(ssp_mfcc_plan* plan);
+int ssp_mfcc_num_frames(const ssp_mfcc_cfg* cfg, int64_t n_samples, int64_t* n_frames);
+int ssp_mfcc_out_dim(const ssp_mfcc_cfg* cfg, int32_t* d_out);
+/* frame segments derived from sample segments with the plan's framing rule */
+int ssp_mfcc_frame_segments(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, ssp_segments** frame_seg_out);
+/* samples: float[total samples]; feats_out: float[total frames x d_out] row-major.
+ * variant: 0 auto | 1 generic kernel | 2 fused fast kernel (SSP_ERR_UNSUPPORTED if the cfg is not covered) */
+int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
+                 const float* samples, float* feats_out, int where, int variant, float* kernel_ms);
+
+/* ---- stand-alone delta / CMVN on feature matrices (GMM_UBM.delta, preprocessing.scale) - */
+int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim, int32_t N,
+              float* out, int where, float* kernel_ms);
+int ssp_cmvn(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim,
+             float* out, int where, float* kernel_ms);
+
+/* ---- GMM-UBM scoring: replaces the GMM[i].score(x_j) - UBM.score(x_j) double loop
+ *      (GMM_UBM.py:181-197) and sklearn GaussianMixture.score_samples/score for diag models ---- */
+/* weights: HOST double[n_models x K]; means, covars: HOST double[n_models x K x D].
+ * has_ubm != 0: model 0 is the UBM; argmax/score differences are taken over models 1.. */
+int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const double* weights,
+                 const double* means, const double* covars, int32_t has_ubm, ssp_gmm** out);
+int ssp_gmm_destroy(ssp_gmm* gmm);
+/* feats: float[total frames x D]; loglik_out (nullable): float[n_models x total frames] (model-major,
+ * = score_samples per model); scores_out (nullable): float[n_utt x n_models] mean log-likelihood
+ * (= GaussianMixture.score); argmax_out (nullable): int32[n_utt] = argmax_i(score_i - score_ubm)
+ * over speaker models (index 0 = first speaker model); precision: 0 fp32 MFMA (parity path) |
+ * 1 bf16x3 split MFMA (fast path, same tolerance class). */
+int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_seg, float* loglik_out,
+                  float* scores_out, int32_t* argmax_out, int where, int precision, float* kernel_ms);
+
+/* ---- d-vector cosine scoring: replaces the scipy cosine double loop + argmin
+ *      (d_vector.py:315-319, 346-361) ---- */
+/* X: float[N x d]; C: float[S x d]; dist_out (nullable): float[N x S] = clip(1 - cos, 0, 2);
+ * argmin_out (nullable): int32[N] (first index on ties); min_out (nullable): float[N]. */
+int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S,
+                        float* dist_out, int32_t* argmin_out, float* min_out, int where, float* kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSP_H_ */

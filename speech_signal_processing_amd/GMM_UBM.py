@@ -1,0 +1,83 @@
+"""GPU-backed mirror of the hot-path functions of the reference's ``GMM_UBM.py``.
+
+* ``delta``            GMM_UBM.py:53-69
+* ``extract_feature``  GMM_UBM.py:72-118  (sidekit mfcc -> [c, delta c] -> per-utterance scale; one fused kernel)
+* ``score_matrix``     the scoring loops GMM_UBM.py:181-197 as a function that returns what the reference prints
+* ``GMM``              GMM_UBM.py:134 with pre-trained models (EM training is out of scope)
+"""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+
+from . import api, frontend
+
+
+def delta(feat, N=2):
+    """GMM_UBM.py:53-69 — regression delta over +-N frames with edge padding; returns an array like ``feat``."""
+    if N < 1:
+        raise ValueError('N must be an integer >= 1')
+    feat = np.asarray(feat)
+    if feat.ndim != 2:
+        raise ValueError("feat must be (NUMFRAMES, features)")
+    ctx = api.default_context()
+    seg = api.Segments.from_lengths(ctx, [feat.shape[0]])
+    out = api.delta_features(ctx, feat, seg, N)
+    return out.astype(feat.dtype if feat.dtype.kind == "f" else np.float64)
+
+
+@functools.lru_cache(maxsize=8)
+def _feature_plan(feature_type, fs, delta_order):
+    if feature_type != 'MFCC':
+        raise NameError  # GMM_UBM.py:100-101; PLP needs sidekit's plp (next)
+    return api.MfccPlan(api.default_context(), frontend.preset_sidekit(fs=fs, delta_order=delta_order, cmvn=1))
+
+
+def extract_feature(x, y, is_train=False, feature_type='MFCC', fs=16000, delta_order=1):
+    """GMM_UBM.py:72-118.  x: list of 1-D audio arrays, y: list of labels.
+    Returns (feature, y) or (train_data, feature, y); every feature is (T_i, 26) float64 = scale([c, delta c]).
+    ``delta_order=2`` appends delta-delta (39-d) — an extension used by the benchmark configs."""
+    plan = _feature_plan(feature_type, int(fs), int(delta_order))
+    sig = [np.asarray(s, dtype=np.float32).reshape(-1) for s in x]
+    seg = api.Segments.from_lengths(plan.ctx, [s.shape[0] for s in sig])
+    fseg = plan.frame_segments(seg)
+    flat = np.concatenate(sig) if sig else np.zeros(0, dtype=np.float32)
+    feats = np.asarray(plan.run(flat, seg, fseg), dtype=np.float64)
+    feature = [feats[fseg.offsets[i]:fseg.offsets[i + 1]] for i in range(len(sig))]
+    if not is_train:
+        return feature, y
+    train_data = {}
+    for f, lab in zip(feature, y):
+        train_data[lab] = np.vstack((train_data[lab], f)) if lab in train_data else f
+    return train_data, feature, y
+
+
+def score_matrix(models, ubm, feats):
+    """GMM_UBM.py:181-187 as a function: pred[j, i] = models[i].score(feats[j]) - ubm.score(feats[j]).
+
+    models / ubm: fitted sklearn GaussianMixture(covariance_type='diag') objects (or anything with weights_,
+    means_, covariances_).  feats: list of (T_j, D) arrays.  Returns (pred (U, S) float64, argmax (U,) int64)."""
+    ctx = api.default_context()
+    scorer = api.GmmScorer.from_sklearn(ctx, models, ubm)
+    fseg = api.Segments.from_lengths(ctx, [len(f) for f in feats])
+    flat = np.ascontiguousarray(np.vstack(feats), dtype=np.float32) if len(feats) else np.zeros((0, scorer.D), np.float32)
+    r = scorer.score(flat, fseg, scores=True, argmax=True)
+    sc = np.asarray(r["scores"], dtype=np.float64)
+    return sc[:, 1:] - sc[:, :1], np.asarray(r["argmax"]).astype(np.int64)
+
+
+def GMM(train, x_train, y_train, x_test, y_test, n_components=16, model=None):
+    """GMM_UBM.py:134-199 with pre-trained models: ``model`` = (list_of_speaker_GMMs, UBM) — what the reference
+    un-pickles from Model/GMM_MFCC_model.pkl / UBM_MFCC_model.pkl when model=True.  Prints and returns the
+    train/test accuracies the reference prints."""
+    if not model:
+        raise NotImplementedError("EM training of the GMMs is out of scope of the GPU hot path (SURVEY.md 8(f)); "
+                                  "fit sklearn GaussianMixture(n_components, 'diag') models and pass model=(GMMs, UBM)")
+    gmms, ubm = model
+    valid = score_matrix(gmms, ubm, x_train)[1]
+    acc_train = (valid == np.array(y_train)).sum() / len(x_train)
+    pred = score_matrix(gmms, ubm, x_test)[1]
+    acc = (pred == np.array(y_test)).sum() / len(x_test)
+    print("train acc {:.2%}, test acc {:.2%}".format(acc_train, acc))
+    return acc_train, acc

@@ -1,0 +1,327 @@
+"""Object layer over the C-ABI (include/ssp.h): Context, Segments, MfccPlan, GmmScorer, cosine_identify.
+
+Bulk arrays may be numpy arrays (host pointers, the library stages them) or torch CUDA tensors (device pointers,
+results stay on the device).  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .frontend import MfccConfig, MfccTables
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def _as_f32(x, name):
+    """-> (array-like kept alive, raw address, where)"""
+    if _is_torch(x):
+        import torch
+        if not x.is_cuda:
+            raise ValueError("%s: torch tensors must live on the GPU (pass numpy arrays for host data)" % name)
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        return x, x.data_ptr(), _lib.DEVICE
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    return a, a.ctypes.data, _lib.HOST
+
+
+class Context:
+    """One HIP device + one stream (ssp_ctx).  stream=None: the library owns a stream; an int is a borrowed
+    hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.ssp_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.stream = stream
+
+    @classmethod
+    def for_torch(cls, device: Optional[int] = None) -> "Context":
+        import torch
+        dev = torch.cuda.current_device() if device is None else int(device)
+        return cls(dev, torch.cuda.current_stream(dev).cuda_stream)
+
+    def sync(self):
+        _lib.check(self._lib.ssp_ctx_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ssp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _empty(self, shape, where, dtype="float32"):
+        if where == _lib.DEVICE:
+            import torch
+            return torch.empty(shape, dtype=getattr(torch, dtype), device="cuda:%d" % self.device)
+        return np.empty(shape, dtype=dtype)
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0, torch_stream: bool = False) -> Context:
+    key = (device, torch_stream)
+    if key not in _default_ctx:
+        _default_ctx[key] = Context.for_torch(device) if torch_stream else Context(device)
+    return _default_ctx[key]
+
+
+class Segments:
+    """Per-utterance offsets (ssp_segments): int64[n+1], uploaded once."""
+
+    def __init__(self, ctx: Context, offsets=None, _handle=None):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        if _handle is not None:
+            self._h = _handle
+        else:
+            off = np.ascontiguousarray(offsets, dtype=np.int64)
+            if off.ndim != 1 or off.size < 1:
+                raise ValueError("offsets must be a 1-D int64 array of length n+1")
+            h = C.c_void_p()
+            _lib.check(self._lib.ssp_segments_create(ctx._h, off.ctypes.data_as(C.POINTER(C.c_int64)), off.size - 1, C.byref(h)))
+            self._h = h
+        n, tot = C.c_int64(), C.c_int64()
+        _lib.check(self._lib.ssp_segments_count(self._h, C.byref(n), C.byref(tot)))
+        self.n = n.value
+        out = np.empty(self.n + 1, dtype=np.int64)
+        _lib.check(self._lib.ssp_segments_read(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        self.offsets = out
+
+    @classmethod
+    def from_lengths(cls, ctx: Context, lengths: Sequence[int]) -> "Segments":
+        off = np.zeros(len(lengths) + 1, dtype=np.int64)
+        np.cumsum(np.asarray(lengths, dtype=np.int64), out=off[1:])
+        return cls(ctx, off)
+
+    @property
+    def total(self) -> int:
+        return int(self.offsets[-1])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ssp_segments_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _cfg_struct(cfg: MfccConfig) -> _lib.ssp_mfcc_cfg:
+    s = _lib.ssp_mfcc_cfg()
+    for k, v in cfg.as_dict().items():
+        setattr(s, k, v)
+    return s
+
+
+class MfccPlan:
+    """Fused MFCC (+delta, +CMVN) pass for one dialect (ssp_mfcc_plan)."""
+
+    def __init__(self, ctx: Context, tables: MfccTables):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.cfg = tables.cfg
+        nb = self.cfg.n_fft // 2 + 1
+        w = np.ascontiguousarray(tables.window, dtype=np.float32)
+        fb = np.ascontiguousarray(tables.fbank, dtype=np.float32)
+        dct = np.ascontiguousarray(tables.dct, dtype=np.float32)
+        if w.shape != (self.cfg.win_len,) or fb.shape != (self.cfg.n_filt, nb) or dct.shape != (self.cfg.n_ceps, self.cfg.n_filt):
+            raise ValueError("table shapes do not match the cfg")
+        self._cs = _cfg_struct(self.cfg)
+        h = C.c_void_p()
+        _lib.check(self._lib.ssp_mfcc_plan_create(ctx._h, C.byref(self._cs), w.ctypes.data, fb.ctypes.data, dct.ctypes.data, C.byref(h)))
+        self._h = h
+
+    @property
+    def d_out(self) -> int:
+        return self.cfg.d_out
+
+    def num_frames(self, n_samples: int) -> int:
+        out = C.c_int64()
+        _lib.check(self._lib.ssp_mfcc_num_frames(C.byref(self._cs), int(n_samples), C.byref(out)))
+        return out.value
+
+    def frame_segments(self, sample_seg: Segments) -> Segments:
+        h = C.c_void_p()
+        _lib.check(self._lib.ssp_mfcc_frame_segments(self._h, sample_seg._h, C.byref(h)))
+        return Segments(self.ctx, _handle=h)
+
+    def run(self, samples, sample_seg: Segments, frame_seg: Optional[Segments] = None, out=None, variant: int = 0,
+            timing: bool = False):
+        """samples: float32[total samples] (numpy -> host path, torch cuda -> device path).
+        Returns feats (total_frames, d_out) [and kernel milliseconds when timing=True]."""
+        if frame_seg is None:
+            frame_seg = self.frame_segments(sample_seg)
+        keep, ptr, where = _as_f32(samples, "samples")
+        if keep.ndim != 1 and not (keep.ndim == 2 and keep.shape[0] * keep.shape[1] == sample_seg.total):
+            raise ValueError("samples must be a flat array of all utterances' samples")
+        if int(np.prod(keep.shape)) < sample_seg.total:
+            raise ValueError("samples shorter than the segment table")
+        if out is None:
+            out = self.ctx._empty((frame_seg.total, self.d_out), where)
+        okeep, optr, owhere = _as_f32(out, "out")
+        if owhere != where or okeep is not out:
+            raise ValueError("out must be a contiguous float32 array of the same kind as samples")
+        ms = C.c_float(0.0)
+        _lib.check(self._lib.ssp_mfcc_run(self._h, sample_seg._h, frame_seg._h, ptr, optr, where, int(variant),
+                                           C.byref(ms) if timing else None))
+        return (out, ms.value) if timing else out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ssp_mfcc_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def delta_features(ctx: Context, feats, frame_seg: Segments, N: int = 2, timing: bool = False):
+    keep, ptr, where = _as_f32(feats, "feats")
+    if keep.ndim != 2:
+        raise ValueError("feats must be (frames, dim)")
+    out = ctx._empty(tuple(keep.shape), where)
+    ms = C.c_float(0.0)
+    optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
+    _lib.check(ctx._lib.ssp_delta(ctx._h, ptr, frame_seg._h, int(keep.shape[1]), int(N), optr, where, C.byref(ms) if timing else None))
+    return (out, ms.value) if timing else out
+
+
+def cmvn_features(ctx: Context, feats, frame_seg: Segments, timing: bool = False):
+    keep, ptr, where = _as_f32(feats, "feats")
+    if keep.ndim != 2:
+        raise ValueError("feats must be (frames, dim)")
+    out = ctx._empty(tuple(keep.shape), where)
+    ms = C.c_float(0.0)
+    optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
+    _lib.check(ctx._lib.ssp_cmvn(ctx._h, ptr, frame_seg._h, int(keep.shape[1]), optr, where, C.byref(ms) if timing else None))
+    return (out, ms.value) if timing else out
+
+
+class GmmScorer:
+    """Packed diagonal GMMs (ssp_gmm).  weights (M,K), means (M,K,D), covars (M,K,D) float64.
+    has_ubm: model 0 is the UBM (GMM_UBM.py:169-170); scores/argmax are then taken against it."""
+
+    def __init__(self, ctx: Context, weights, means, covars, has_ubm: bool = True):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        mu = np.ascontiguousarray(means, dtype=np.float64)
+        cv = np.ascontiguousarray(covars, dtype=np.float64)
+        if w.ndim != 2 or mu.ndim != 3 or mu.shape != cv.shape or mu.shape[:2] != w.shape:
+            raise ValueError("expected weights (M,K), means (M,K,D), covars (M,K,D)")
+        self.n_models, self.K, self.D = mu.shape
+        self.has_ubm = bool(has_ubm)
+        h = C.c_void_p()
+        _lib.check(self._lib.ssp_gmm_pack(ctx._h, self.n_models, self.K, self.D, w.ctypes.data, mu.ctypes.data, cv.ctypes.data,
+                                           1 if has_ubm else 0, C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_sklearn(cls, ctx: Context, models: Sequence, ubm=None) -> "GmmScorer":
+        """models / ubm: fitted sklearn GaussianMixture(covariance_type='diag') objects (duck-typed:
+        weights_, means_, covariances_), all with the same K and D — the lists GMM_UBM.py:141-146 pickles."""
+        allm = ([ubm] if ubm is not None else []) + list(models)
+        for g in allm:
+            if getattr(g, "covariance_type", "diag") != "diag":
+                raise ValueError("only covariance_type='diag' models are supported")
+        return cls(ctx, np.stack([g.weights_ for g in allm]), np.stack([g.means_ for g in allm]),
+                   np.stack([g.covariances_ for g in allm]), has_ubm=ubm is not None)
+
+    def score(self, feats, frame_seg: Segments, loglik: bool = False, scores: bool = True, argmax: bool = True,
+              precision: int = 0, timing: bool = False) -> dict:
+        """Returns a dict with the requested arrays:
+        loglik (M, F) per-frame log-likelihood per model (= score_samples), scores (U, M) mean log-likelihood
+        (= GaussianMixture.score), argmax (U,) int32 over speaker models of score - score_ubm."""
+        keep, ptr, where = _as_f32(feats, "feats")
+        if keep.ndim != 2 or keep.shape[1] != self.D:
+            raise ValueError("feats must be (frames, %d)" % self.D)
+        if keep.shape[0] < frame_seg.total:
+            raise ValueError("feats has fewer rows than the frame segments cover")
+        F, U = frame_seg.total, frame_seg.n
+        res = {}
+        ll = self.ctx._empty((self.n_models, F), where) if loglik else None
+        sc = self.ctx._empty((U, self.n_models), where) if scores else None
+        am = self.ctx._empty((U,), where, "int32") if argmax else None
+
+        def p(x):
+            if x is None:
+                return None
+            return x.data_ptr() if where == _lib.DEVICE else x.ctypes.data
+        ms = C.c_float(0.0)
+        _lib.check(self._lib.ssp_gmm_score(self._h, ptr, frame_seg._h, p(ll), p(sc), p(am), where, int(precision),
+                                            C.byref(ms) if timing else None))
+        if loglik:
+            res["loglik"] = ll
+        if scores:
+            res["scores"] = sc
+        if argmax:
+            res["argmax"] = am
+        if timing:
+            res["kernel_ms"] = ms.value
+        return res
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ssp_gmm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True, minval: bool = True,
+                    timing: bool = False) -> dict:
+    """dist[i,j] = clip(1 - cos(X[i], C[j]), 0, 2); argmin over j (first index on ties) — d_vector.py:315-319."""
+    xk, xp, where = _as_f32(X, "X")
+    ck, cp, cwhere = _as_f32(Cn, "C")
+    if cwhere != where:
+        raise ValueError("X and C must both be numpy arrays or both be torch CUDA tensors")
+    if xk.ndim != 2 or ck.ndim != 2 or xk.shape[1] != ck.shape[1]:
+        raise ValueError("X (N,d) and C (S,d) must share d")
+    N, d = int(xk.shape[0]), int(xk.shape[1])
+    S = int(ck.shape[0])
+    dm = ctx._empty((N, S), where) if dist else None
+    am = ctx._empty((N,), where, "int32") if argmin else None
+    mv = ctx._empty((N,), where) if minval else None
+
+    def p(x):
+        if x is None:
+            return None
+        return x.data_ptr() if where == _lib.DEVICE else x.ctypes.data
+    ms = C.c_float(0.0)
+    _lib.check(ctx._lib.ssp_cosine_identify(ctx._h, xp, N, d, cp, S, p(dm), p(am), p(mv), where, C.byref(ms) if timing else None))
+    res = {}
+    if dist:
+        res["dist"] = dm
+    if argmin:
+        res["argmin"] = am
+    if minval:
+        res["min"] = mv
+    if timing:
+        res["kernel_ms"] = ms.value
+    return res

@@ -1,0 +1,71 @@
+"""Build libsspgpu.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m speech_signal_processing_amd.build [--force]
+
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsspgpu.so")
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
+SOURCES = ["ctx.hip", "mfcc.hip", "mfcc_fast.hip", "mfcc_plan.hip", "feat_ops.hip", "gmm.hip", "cosine.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-fno-gpu-rdc", "-munsafe-fp-atomics"]
+
+
+def _deps():
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    out.append(os.path.join(os.path.dirname(HERE), "include", "ssp.h"))
+    return out
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+    srcp = os.path.join(CSRC, src)
+    newest = max(os.path.getmtime(p) for p in _deps() if p.endswith((".hpp", ".h")) or p == srcp)
+    if os.path.exists(obj) and os.path.getmtime(obj) > newest:
+        return obj
+    cmd = [HIPCC, *FLAGS, "-c", srcp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

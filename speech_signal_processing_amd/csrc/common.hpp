@@ -1,0 +1,156 @@
+// Shared host-side plumbing for libsspgpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ssp.h"
+
+namespace ssp {
+
+void set_error(const char* fmt, ...);
+
+#define SSP_FAIL(code, ...)            \
+    do {                               \
+        ::ssp::set_error(__VA_ARGS__); \
+        return (code);                 \
+    } while (0)
+
+#define SSP_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ::ssp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                             __LINE__);                                                      \
+            return e_ == hipErrorOutOfMemory ? SSP_ERR_NOMEM : SSP_ERR_HIP;                  \
+        }                                                                                    \
+    } while (0)
+
+#define SSP_TRY(expr)          \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != SSP_OK) return rc_; \
+    } while (0)
+
+template <class T>
+static inline T ceil_div(T a, T b) {
+    return (a + b - 1) / b;
+}
+
+// RAII device buffer (used for per-call staging in SSP_HOST mode and for plan tables).
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        SSP_HIP(hipMalloc(&p, n));
+        bytes = n;
+        return SSP_OK;
+    }
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+// hipEvent pair around a region on the ctx stream.
+struct Timer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on = false;
+    int start(bool enable, hipStream_t s) {
+        on = enable;
+        if (!on) return SSP_OK;
+        SSP_HIP(hipEventCreate(&a));
+        SSP_HIP(hipEventCreate(&b));
+        SSP_HIP(hipEventRecord(a, s));
+        return SSP_OK;
+    }
+    int stop(hipStream_t s, float* ms) {
+        if (!on) return SSP_OK;
+        SSP_HIP(hipEventRecord(b, s));
+        SSP_HIP(hipEventSynchronize(b));
+        SSP_HIP(hipEventElapsedTime(ms, a, b));
+        return SSP_OK;
+    }
+    ~Timer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+}  // namespace ssp
+
+struct ssp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int num_cu = 256;
+};
+
+struct ssp_segments {
+    ssp_ctx* ctx = nullptr;
+    uint64_t serial = 0;        // unique per handle (work-table caches key on it, not on the address)
+    int64_t n = 0;
+    std::vector<int64_t> host;  // n+1
+    ssp::DevBuf dev;            // int64[n+1]
+    int64_t total() const { return host.empty() ? 0 : host.back() - host.front(); }
+    int64_t max_len() const {
+        int64_t m = 0;
+        for (int64_t i = 0; i < n; ++i) m = host[i + 1] - host[i] > m ? host[i + 1] - host[i] : m;
+        return m;
+    }
+};
+
+namespace ssp {
+// make `dev` the current device for this thread
+static inline int use_ctx(const ssp_ctx* ctx) {
+    if (!ctx) SSP_FAIL(SSP_ERR_INVALID, "null ssp_ctx");
+    SSP_HIP(hipSetDevice(ctx->device));
+    return SSP_OK;
+}
+int segments_make(ssp_ctx* ctx, const int64_t* offsets, int64_t n, ssp_segments** out);
+
+// Staging helper for SSP_HOST calls: device copy of a host input / device scratch for an output.
+struct Staged {
+    DevBuf buf;
+    const void* in(const ssp_ctx* ctx, const void* host, size_t bytes, int where, int* rc) {
+        *rc = SSP_OK;
+        if (where == SSP_DEVICE || host == nullptr) return host;
+        *rc = buf.alloc(bytes);
+        if (*rc != SSP_OK) return nullptr;
+        hipError_t e = hipMemcpyAsync(buf.p, host, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            set_error("hipMemcpyAsync H2D failed: %s", hipGetErrorString(e));
+            *rc = SSP_ERR_HIP;
+            return nullptr;
+        }
+        return buf.p;
+    }
+    void* out(void* host, size_t bytes, int where, int* rc) {
+        *rc = SSP_OK;
+        if (where == SSP_DEVICE || host == nullptr) return host;
+        *rc = buf.alloc(bytes);
+        return buf.p;
+    }
+    int back(const ssp_ctx* ctx, void* host, size_t bytes, int where) {
+        if (where == SSP_DEVICE || host == nullptr) return SSP_OK;
+        SSP_HIP(hipMemcpyAsync(host, buf.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return SSP_OK;
+    }
+};
+}  // namespace ssp

@@ -1,0 +1,256 @@
+// d-vector cosine scoring on gfx950 MFMA.
+//
+// Replaces the N x S Python loop  distance[i,j] = scipy.spatial.distance.cosine(X_val[i], avg[j])  followed by
+// argmin(axis=1) (d_vector.py:315-319) and the linear scan of nn_model.eval (d_vector.py:346-361):
+//   dist[i,j] = clip(1 - x_i.c_j / (|x_i| |c_j|), 0, 2)          (sp:spatial/distance.py:602-687)
+// as one (centroids x d) . (d x embeddings) fp32 MFMA GEMM with the normalisation, clip and a running arg-min
+// (numpy first-index tie rule) fused into the epilogue.  Centroids are the MFMA rows, embeddings the columns, so
+// each lane owns ONE embedding and scans centroids in its accumulator registers.
+#include <cmath>
+
+#include "common.hpp"
+
+namespace ssp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BM = 128;  // centroid rows per block step
+constexpr int BN = 128;  // embedding columns per workgroup
+constexpr int BK = 32;   // k-chunk
+
+struct CosArgs {
+    const float* X;    // [N x d]
+    const float* C;    // [S x d]
+    const float* inc;  // [S] 1/|c_j|
+    float* dist;       // nullable [N x S]
+    int32_t* argmin;   // nullable [N]
+    float* minval;     // nullable [N]
+    int64_t N;
+    int32_t d, S;
+};
+
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ A, int64_t rows, int d,
+                                                           float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* __restrict__ p = A + row * d;
+    float s = 0.f;
+    for (int k = lane; k < d; k += 64) s = fmaf(p[k], p[k], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[row] = 1.0f / sqrtf(s);
+}
+
+// stage a [128 x BK] slab of a row-major matrix into the MFMA operand image [q=BK/8][h=2][row=128][e=4]:
+// element (row, k = 8q + 2e + h).  Returns the sum of squares of what this thread loaded (for the row norm).
+__device__ __forceinline__ float stage_slab(const float* __restrict__ A, int64_t row0, int64_t n_rows, int d, int k0,
+                                            float* __restrict__ img, int tid, bool vec) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;       // 1024 float4 per slab
+        const int r = idx >> 3, c4 = idx & 7;  // 8 float4 per row
+        const int64_t gr = row0 + r;
+        const int k = k0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < n_rows) {
+            const float* __restrict__ p = A + gr * d + k;
+            if (vec && k + 3 < d) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (k < d) v.x = p[0];
+                if (k + 1 < d) v.y = p[1];
+                if (k + 2 < d) v.z = p[2];
+                if (k + 3 < d) v.w = p[3];
+            }
+        }
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        const int q = c4 >> 1, e0 = (c4 & 1) * 2;  // kk = (c4&1)*4 + {0,1,2,3}: h = kk&1, e = kk>>1
+        float* b0 = img + ((size_t)(q * 2 + 0) * 128 + r) * 4 + e0;
+        float* b1 = img + ((size_t)(q * 2 + 1) * 128 + r) * 4 + e0;
+        *reinterpret_cast<float2*>(b0) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2*>(b1) = make_float2(v.y, v.w);
+    }
+    return ss;
+}
+
+__global__ __launch_bounds__(256) void cosine_kernel(CosArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLAB = (BK / 8) * 2 * 128 * 4;  // floats per operand slab
+    float* imgA = reinterpret_cast<float*>(smem);  // centroids
+    float* imgB = imgA + SLAB;                     // embeddings
+    float* inx = imgB + SLAB;                      // [BN] 1/|x|
+    float* redv = inx + BN;                        // [2][BN] cross-wave arg-min exchange
+    int* redi = reinterpret_cast<int*>(redv + 2 * BN);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 waves, each 64 rows x 64 cols
+    const int64_t col0 = (int64_t)blockIdx.x * BN;
+    const int d = a.d;
+    const bool vec = (d & 3) == 0;
+    const int n_kc = (d + BK - 1) / BK;
+    const int n_rb = (a.S + BM - 1) / BM;
+
+    float best[2];
+    int besti[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        best[ct] = INFINITY;
+        besti[ct] = 0x7fffffff;
+    }
+    float xss = 0.f;
+
+    for (int rb = 0; rb < n_rb; ++rb) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+        for (int kc = 0; kc < n_kc; ++kc) {
+            __syncthreads();  // previous slab fully consumed
+            stage_slab(a.C, (int64_t)rb * BM, a.S, d, kc * BK, imgA, tid, vec);
+            const float s = stage_slab(a.X, col0, a.N, d, kc * BK, imgB, tid, vec);
+            if (rb == 0) xss += s;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) {
+                f32x4 av[2], bv[2];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+                    av[rt] = *reinterpret_cast<const f32x4*>(imgA + ((size_t)(q * 2 + h) * 128 + wr * 64 + rt * 32 + fl) * 4);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    bv[ct] = *reinterpret_cast<const f32x4*>(imgB + ((size_t)(q * 2 + h) * 128 + wc * 64 + ct * 32 + fl) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rt][e], bv[ct][e], acc[rt][ct], 0, 0, 0);
+            }
+        }
+        if (rb == 0) {  // embedding norms: 8 consecutive threads staged one row (tid>>3 + 32 i)
+            // thread t staged rows r_i = (t + 256 i) >> 3 = (t >> 3) + 32 i for i = 0..3 -> four different rows:
+            // keep it simple and exact: recompute per-row norms from global by one wave-parallel pass
+            __syncthreads();
+            for (int c = tid; c < BN; c += 256) {
+                const int64_t gc = col0 + c;
+                float s = 0.f;
+                if (gc < a.N) {
+                    const float* __restrict__ p = a.X + gc * d;
+                    for (int k = 0; k < d; ++k) s = fmaf(p[k], p[k], s);
+                }
+                inx[c] = 1.0f / sqrtf(s);
+            }
+            __syncthreads();
+        }
+        // epilogue: distances for this 128-row block, running arg-min per column
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int c = wc * 64 + ct * 32 + fl;
+            const float ix = inx[c];
+            const int64_t gc = col0 + c;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = rb * BM + wr * 64 + rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (row < a.S) {
+                        float dv = 1.0f - acc[rt][ct][i] * a.inc[row] * ix;
+                        dv = fminf(fmaxf(dv, 0.0f), 2.0f);
+                        if (a.dist && gc < a.N) a.dist[gc * a.S + row] = dv;
+                        if (dv < best[ct] || (dv == best[ct] && row < besti[ct])) {
+                            best[ct] = dv;
+                            besti[ct] = row;
+                        }
+                    }
+                }
+        }
+    }
+    (void)xss;
+    // combine the two lane halves, then the two row-waves, per column
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const float ob = __shfl_xor(best[ct], 32);
+        const int oi = __shfl_xor(besti[ct], 32);
+        if (ob < best[ct] || (ob == best[ct] && oi < besti[ct])) {
+            best[ct] = ob;
+            besti[ct] = oi;
+        }
+    }
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int c = wc * 64 + ct * 32 + fl;
+            redv[wr * BN + c] = best[ct];
+            redi[wr * BN + c] = besti[ct];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+        const int64_t gc = col0 + c;
+        if (gc >= a.N) continue;
+        float b0 = redv[c], b1 = redv[BN + c];
+        int i0 = redi[c], i1 = redi[BN + c];
+        if (b1 < b0 || (b1 == b0 && i1 < i0)) {
+            b0 = b1;
+            i0 = i1;
+        }
+        if (a.argmin) a.argmin[gc] = i0 == 0x7fffffff ? 0 : i0;
+        if (a.minval) a.minval[gc] = b0;
+    }
+}
+
+}  // namespace ssp
+
+using namespace ssp;
+
+extern "C" {
+
+int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,
+                        int32_t* argmin_out, float* min_out, int where, float* kernel_ms) {
+    SSP_TRY(use_ctx(ctx));
+    if (N < 0 || d < 1 || S < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: bad shape N=%lld d=%d S=%d", (long long)N, d, S);
+    if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: where");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (N == 0) return SSP_OK;
+    if (!X || !C) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: null input");
+    hipStream_t s = ctx->stream;
+    Staged sx, sc, sd, sa, sm;
+    int rc;
+    const float* dX = (const float*)sx.in(ctx, X, (size_t)N * d * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    const float* dC = (const float*)sc.in(ctx, C, (size_t)S * d * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    float* dD = (float*)sd.out(dist_out, (size_t)N * S * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    int32_t* dA = (int32_t*)sa.out(argmin_out, (size_t)N * sizeof(int32_t), where, &rc);
+    SSP_TRY(rc);
+    float* dM = (float*)sm.out(min_out, (size_t)N * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    DevBuf inc;
+    SSP_TRY(inc.alloc((size_t)S * sizeof(float)));
+    const int64_t grid = ceil_div<int64_t>(N, BN);
+    if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
+    CosArgs a{dX, dC, inc.as<float>(), dD, dA, dM, N, d, S};
+    constexpr size_t lds = (size_t)(2 * (BK / 8) * 2 * 128 * 4 + BN + 2 * BN) * sizeof(float) + 2 * BN * sizeof(int);
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, s));
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, s, dC, (int64_t)S, d, inc.as<float>());
+    SSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(cosine_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    SSP_HIP(hipGetLastError());
+    SSP_TRY(tm.stop(s, kernel_ms));
+    SSP_TRY(sd.back(ctx, dist_out, (size_t)N * S * sizeof(float), where));
+    SSP_TRY(sa.back(ctx, argmin_out, (size_t)N * sizeof(int32_t), where));
+    SSP_TRY(sm.back(ctx, min_out, (size_t)N * sizeof(float), where));
+    SSP_HIP(hipStreamSynchronize(s));  // `inc` is freed at return
+    return SSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// Context, error reporting and segment handles of libsspgpu.so.
+#include "common.hpp"
+
+#include <atomic>
+
+namespace ssp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int segments_make(ssp_ctx* ctx, const int64_t* offsets, int64_t n, ssp_segments** out) {
+    if (!out) SSP_FAIL(SSP_ERR_INVALID, "segments: null out");
+    *out = nullptr;
+    SSP_TRY(use_ctx(ctx));
+    if (n < 0 || (!offsets)) SSP_FAIL(SSP_ERR_INVALID, "segments: null offsets or negative count");
+    if (offsets[0] < 0) SSP_FAIL(SSP_ERR_INVALID, "segments: offsets[0] < 0");
+    for (int64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) SSP_FAIL(SSP_ERR_INVALID, "segments: offsets decrease at %lld", (long long)i);
+    ssp_segments* s = new (std::nothrow) ssp_segments;
+    if (!s) SSP_FAIL(SSP_ERR_NOMEM, "segments: host alloc");
+    static std::atomic<uint64_t> next_serial{1};
+    s->ctx = ctx;
+    s->serial = next_serial.fetch_add(1);
+    s->n = n;
+    s->host.assign(offsets, offsets + n + 1);
+    int rc = s->dev.alloc(sizeof(int64_t) * (size_t)(n + 1));
+    if (rc == SSP_OK) {
+        hipError_t e = hipMemcpyAsync(s->dev.p, s->host.data(), sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
+                                      ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("segments upload failed: %s", hipGetErrorString(e));
+            rc = SSP_ERR_HIP;
+        }
+    }
+    if (rc != SSP_OK) {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return SSP_OK;
+}
+
+}  // namespace ssp
+
+extern "C" {
+
+int ssp_abi_version(void) { return SSP_ABI_VERSION; }
+
+const char* ssp_last_error(void) { return ssp::g_err; }
+
+int ssp_ctx_create(int device, void* stream, ssp_ctx** out) {
+    if (!out) SSP_FAIL(SSP_ERR_INVALID, "ssp_ctx_create: null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) SSP_FAIL(SSP_ERR_NODEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) SSP_FAIL(SSP_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    SSP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SSP_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        SSP_FAIL(SSP_ERR_UNSUPPORTED, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    ssp_ctx* c = new (std::nothrow) ssp_ctx;
+    if (!c) SSP_FAIL(SSP_ERR_NOMEM, "ctx: host alloc");
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+        c->owns_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            SSP_FAIL(SSP_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return SSP_OK;
+}
+
+int ssp_ctx_destroy(ssp_ctx* ctx) {
+    if (!ctx) return SSP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SSP_OK;
+}
+
+int ssp_ctx_sync(ssp_ctx* ctx) {
+    SSP_TRY(ssp::use_ctx(ctx));
+    SSP_HIP(hipStreamSynchronize(ctx->stream));
+    return SSP_OK;
+}
+
+int ssp_segments_create(ssp_ctx* ctx, const int64_t* offsets, int64_t n_seg, ssp_segments** out) {
+    return ssp::segments_make(ctx, offsets, n_seg, out);
+}
+
+int ssp_segments_destroy(ssp_segments* seg) {
+    if (!seg) return SSP_OK;
+    if (seg->ctx) (void)hipSetDevice(seg->ctx->device);
+    delete seg;
+    return SSP_OK;
+}
+
+int ssp_segments_count(const ssp_segments* seg, int64_t* n_seg, int64_t* total) {
+    if (!seg) SSP_FAIL(SSP_ERR_INVALID, "null segments");
+    if (n_seg) *n_seg = seg->n;
+    if (total) *total = seg->total();
+    return SSP_OK;
+}
+
+int ssp_segments_read(const ssp_segments* seg, int64_t* offsets_out) {
+    if (!seg || !offsets_out) SSP_FAIL(SSP_ERR_INVALID, "null segments / output");
+    memcpy(offsets_out, seg->host.data(), sizeof(int64_t) * seg->host.size());
+    return SSP_OK;
+}
+
+}  // extern "C"

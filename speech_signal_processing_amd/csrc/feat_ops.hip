@@ -1,0 +1,140 @@
+// Stand-alone delta (GMM_UBM.py:53-69 == d_vector.py:143-160) and per-utterance CMVN
+// (sklearn.preprocessing.scale as called at GMM_UBM.py:93) on (frames x dim) feature matrices.
+// Both are HBM-bound streaming kernels; the fused MFCC pass does the same work in LDS.
+#include "common.hpp"
+
+namespace ssp {
+
+// one thread per output element; utterance found by binary search over frame offsets
+__device__ __forceinline__ int find_segment(const int64_t* __restrict__ off, int n_seg, int64_t row) {
+    int lo = 0, hi = n_seg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= row) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                    const int64_t* __restrict__ off, int n_seg, int dim, int N,
+                                                    float inv_den, int64_t row0, int64_t n_elem) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elem; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = row0 + i / dim;
+        const int d = (int)(i % dim);
+        const int u = find_segment(off, n_seg, row);
+        const int64_t a = off[u], b = off[u + 1] - 1;  // edge padding inside the utterance (GMM_UBM.py:64)
+        float acc = 0.f;
+        for (int m = 1; m <= N; ++m) {
+            const int64_t rp = row + m > b ? b : row + m, rm = row - m < a ? a : row - m;
+            acc += (float)m * (in[rp * dim + d] - in[rm * dim + d]);
+        }
+        out[row * dim + d] = acc * inv_den;
+    }
+}
+
+// one workgroup per utterance: mean, then variance about the mean (two passes), then normalise
+__global__ __launch_bounds__(256) void cmvn_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                   const int64_t* __restrict__ off, int dim) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [4][dim] partials, then [dim] mean, [dim] inv std
+    const int u = blockIdx.x;
+    const int64_t a = off[u];
+    const int T = (int)(off[u + 1] - a);
+    if (T == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* mean = red + 4 * dim;
+    float* istd = mean + dim;
+    const float* __restrict__ x = in + a * dim;
+    for (int d = wave; d < dim; d += 4) {
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s += x[(size_t)t * dim + d];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float m = s / (float)T;
+        float v = 0.f;
+        for (int t = lane; t < T; t += 64) {
+            const float e = x[(size_t)t * dim + d] - m;
+            v = fmaf(e, e, v);
+        }
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        float sd = sqrtf(v / (float)T);
+        if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;  // sk: _handle_zeros_in_scale
+        if (lane == 0) {
+            mean[d] = m;
+            istd[d] = 1.0f / sd;
+        }
+    }
+    __syncthreads();
+    float* __restrict__ y = out + a * dim;
+    for (int i = tid; i < T * dim; i += 256) {
+        const int d = i % dim;
+        y[i] = (x[i] - mean[d]) * istd[d];
+    }
+}
+
+}  // namespace ssp
+
+using namespace ssp;
+
+extern "C" {
+
+int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim, int32_t N, float* out,
+              int where, float* kernel_ms) {
+    SSP_TRY(use_ctx(ctx));
+    if (!frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_delta: null segments");
+    if (N < 1) SSP_FAIL(SSP_ERR_INVALID, "N must be an integer >= 1");  // GMM_UBM.py:59-60
+    if (N > 64 || dim < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_delta: bad N or dim");
+    if (kernel_ms) *kernel_ms = 0.f;
+    const int64_t row0 = frame_seg->host.front(), rows = frame_seg->total();
+    if (rows == 0) return SSP_OK;
+    if (!feats || !out) SSP_FAIL(SSP_ERR_INVALID, "ssp_delta: null data pointer");
+    const size_t bytes = (size_t)frame_seg->host.back() * dim * sizeof(float);
+    Staged sin, sout;
+    int rc;
+    const float* d_in = (const float*)sin.in(ctx, feats, bytes, where, &rc);
+    SSP_TRY(rc);
+    float* d_out = (float*)sout.out(out, bytes, where, &rc);
+    SSP_TRY(rc);
+    int den = 0;
+    for (int i = 1; i <= N; ++i) den += 2 * i * i;
+    const int64_t n_elem = rows * dim;
+    const int grid = (int)std::min<int64_t>(ceil_div<int64_t>(n_elem, 256), (int64_t)ctx->num_cu * 8);
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
+    hipLaunchKernelGGL(delta_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_in, d_out, frame_seg->dev.as<int64_t>(),
+                       (int)frame_seg->n, dim, N, 1.0f / (float)den, row0, n_elem);
+    SSP_HIP(hipGetLastError());
+    SSP_TRY(tm.stop(ctx->stream, kernel_ms));
+    SSP_TRY(sout.back(ctx, out, bytes, where));
+    if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(ctx->stream));
+    return SSP_OK;
+}
+
+int ssp_cmvn(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim, float* out, int where,
+             float* kernel_ms) {
+    SSP_TRY(use_ctx(ctx));
+    if (!frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_cmvn: null segments");
+    if (dim < 1 || dim > 4096) SSP_FAIL(SSP_ERR_INVALID, "ssp_cmvn: dim out of range");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (frame_seg->total() == 0 || frame_seg->n == 0) return SSP_OK;
+    if (!feats || !out) SSP_FAIL(SSP_ERR_INVALID, "ssp_cmvn: null data pointer");
+    if (frame_seg->max_len() * dim > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_cmvn: utterance too long");
+    const size_t bytes = (size_t)frame_seg->host.back() * dim * sizeof(float);
+    Staged sin, sout;
+    int rc;
+    const float* d_in = (const float*)sin.in(ctx, feats, bytes, where, &rc);
+    SSP_TRY(rc);
+    float* d_out = (float*)sout.out(out, bytes, where, &rc);
+    SSP_TRY(rc);
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
+    hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)frame_seg->n), dim3(256), (size_t)6 * dim * sizeof(float), ctx->stream,
+                       d_in, d_out, frame_seg->dev.as<int64_t>(), dim);
+    SSP_HIP(hipGetLastError());
+    SSP_TRY(tm.stop(ctx->stream, kernel_ms));
+    SSP_TRY(sout.back(ctx, out, bytes, where));
+    if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(ctx->stream));
+    return SSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// Diagonal-covariance GMM log-likelihood scoring on gfx950 MFMA.
+//
+// Replaces the S x U Python loop  pred[j,i] = GMM[i].score(x_j) - UBM.score(x_j)  (GMM_UBM.py:181-197) and sklearn's
+// GaussianMixture.score_samples / score for covariance_type='diag' (sk:mixture/_gaussian_mixture.py:453-512,
+// sk:mixture/_base.py:337-373): every frame is scored against every mixture of every model in one launch.
+//
+// Formulation: lp[t,k] = sum_j aug[t][j] * W[k][j] with aug = [x, x^2, 1] and
+//   W[k] = [mu*P, -P/2, ln w_k + 1/2 sum ln P - 1/2 (D ln 2pi + sum mu^2 P)],  P = 1/sigma^2,
+// i.e. one (mixtures x 2D+1) . (2D+1 x frames) contraction on v_mfma_f32_32x32x2_f32 (exact fp32), followed by a
+// log-sum-exp over the mixtures of each model.  Mixtures are the MFMA ROWS and frames the COLUMNS, so the 16 accumulator
+// registers of a lane all belong to ONE frame: the LSE is in-lane plus one exchange with lane^32.
+#include <cmath>
+
+#include "common.hpp"
+
+namespace ssp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// async global -> LDS copy of one packed row tile (NQ pieces of 1 KiB; each wave moves whole pieces, the image is
+// linear so the LDS destination is wave-uniform base + lane * 16)
+template <int NQ>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ tile, float* dst, int wave, int lane) {
+#pragma unroll
+    for (int p = 0; p < (NQ + 3) / 4; ++p) {
+        const int piece = wave + 4 * p;
+        if (piece < NQ)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(tile + piece * 256 + lane * 4), (lds_ptr_t)(dst + piece * 256), 16, 0, 0);
+    }
+}
+
+struct GmmArgs {
+    const float* feats;   // [F x D]
+    const float* wimg;    // [n_tiles][NQ][2][32][4]  packed row tiles (32 mixtures each)
+    float* llT;           // [n_models x F] model-major per-frame log-likelihood
+    int64_t F;            // total frames (rows of feats)
+    int32_t D, n_models, tiles_per_model, n_tiles;
+};
+
+// NQ = k-depth / 8 of the packed image (k-depth >= 2D+1); CT = 32-frame column tiles per wave
+template <int NQ, int CT>
+__global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_FLOATS = NQ * 2 * 32 * 4;
+    constexpr int FRAMES_WG = 4 * CT * 32;
+    float* wbuf = reinterpret_cast<float*>(smem);                   // [2][TILE_FLOATS]
+    float* xs = reinterpret_cast<float*>(smem) + 2 * TILE_FLOATS;   // [FRAMES_WG * D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & 31, h = lane >> 5;
+    const int D = a.D;
+    const int64_t f0 = (int64_t)blockIdx.x * FRAMES_WG;
+    const int n_valid = (int)min((int64_t)FRAMES_WG, a.F - f0);
+
+    // stage this workgroup's frames (contiguous rows) into LDS, coalesced
+    {
+        const float* __restrict__ src = a.feats + f0 * D;
+        const int tot = n_valid * D;
+        for (int i = tid; i < FRAMES_WG * D; i += 256) xs[i] = i < tot ? src[i] : 0.f;
+    }
+    stage_tile<NQ>(a.wimg, wbuf, wave, lane);  // row tile 0
+    __syncthreads();
+
+    // B operand (this wave's frames) in registers: b[ct][q][e] = aug[frame][8q + 2e + h]
+    float b[CT][NQ][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const float* xr = xs + (size_t)((wave * CT + ct) * 32 + fl) * D;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 8 * q + 2 * e + h;
+                const int jj = j < D ? j : (j < 2 * D ? j - D : 0);
+                const float v = xr[jj];
+                b[ct][q][e] = j < D ? v : (j < 2 * D ? v * v : (j == 2 * D ? 1.0f : 0.0f));
+            }
+    }
+
+    float run_m[CT], run_s[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        run_m[ct] = -INFINITY;
+        run_s[ct] = 0.f;
+    }
+
+    int rt = 0, model = 0;
+    for (int r = 0; r < a.n_tiles; ++r) {
+        const float* wcur = wbuf + (r & 1) * TILE_FLOATS;
+        // tile r+1 streams into the other buffer while this one feeds the MFMAs (the barrier at the end of the
+        // iteration drains the LDS-DMA: __syncthreads() waits vmcnt(0))
+        if (r + 1 < a.n_tiles)
+            stage_tile<NQ>(a.wimg + (size_t)(r + 1) * TILE_FLOATS, wbuf + ((r + 1) & 1) * TILE_FLOATS, wave, lane);
+        f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(wcur + ((q * 2 + h) * 32 + fl) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b[ct][q][e], acc[ct], 0, 0, 0);
+        }
+        // online log-sum-exp over this tile's 16 mixtures per lane
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float tm = acc[ct][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) tm = fmaxf(tm, acc[ct][i]);
+            const float nm = fmaxf(run_m[ct], tm);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += __expf(acc[ct][i] - nm);
+            run_s[ct] = run_s[ct] * __expf(run_m[ct] - nm) + s;
+            run_m[ct] = nm;
+        }
+        if (++rt == a.tiles_per_model) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float m2 = __shfl_xor(run_m[ct], 32), s2 = __shfl_xor(run_s[ct], 32);
+                const float mm = fmaxf(run_m[ct], m2);
+                const float ss = run_s[ct] * __expf(run_m[ct] - mm) + s2 * __expf(m2 - mm);
+                const int fidx = (wave * CT + ct) * 32 + fl;
+                if (h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = mm + logf(ss);
+                run_m[ct] = -INFINITY;
+                run_s[ct] = 0.f;
+            }
+            rt = 0;
+            ++model;
+        }
+        __syncthreads();
+    }
+}
+
+// per-utterance mean over frames (GaussianMixture.score), score differences against the UBM and arg-max
+// (GMM_UBM.py:185-187).  One workgroup per utterance, fixed summation order => bitwise reproducible.
+__global__ __launch_bounds__(256) void gmm_utt_reduce_kernel(const float* __restrict__ llT, int64_t F,
+                                                             const int64_t* __restrict__ frame_off, int n_models,
+                                                             int has_ubm, float* __restrict__ scores,
+                                                             int32_t* __restrict__ argmax_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);
+    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t a0 = frame_off[u];
+    const int T = (int)(frame_off[u + 1] - a0);
+    for (int m = wave; m < n_models; m += 4) {
+        const float* __restrict__ p = llT + (size_t)m * F + a0;
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s += p[t];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float v = s / (float)T;  // T == 0 -> NaN (numpy mean of empty)
+        if (lane == 0) {
+            sc[m] = v;
+            if (scores) scores[(size_t)u * n_models + m] = v;
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && argmax_out) {
+        const float base = has_ubm ? sc[0] : 0.f;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int m = has_ubm + lane; m < n_models; m += 64) {
+            const float v = sc[m] - base;
+            if (v > best || bi == 0x7fffffff) {
+                best = v;
+                bi = m - has_ubm;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        if (lane == 0) argmax_out[u] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
+template <int NQ, int CT>
+static int launch_loglik(const GmmArgs& a, hipStream_t s) {
+    constexpr int FRAMES_WG = 4 * CT * 32;
+    const size_t lds = (size_t)(2 * NQ * 2 * 32 * 4 + FRAMES_WG * a.D) * sizeof(float);
+    const int64_t grid = ceil_div<int64_t>(a.F, FRAMES_WG);
+    if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many frames for one launch");
+    if (lds > 64 * 1024)
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_loglik_kernel<NQ, CT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gmm_loglik_kernel<NQ, CT>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
+}
+
+static const int kNQ[] = {4, 7, 10, 16, 24, 32};
+
+static int pick_nq(int D) {
+    const int need = (2 * D + 1 + 7) / 8;
+    for (int v : kNQ)
+        if (v >= need) return v;
+    return -1;
+}
+
+}  // namespace ssp
+
+struct ssp_gmm {
+    ssp_ctx* ctx = nullptr;
+    int32_t n_models = 0, K = 0, D = 0, has_ubm = 0;
+    int32_t nq = 0, tiles_per_model = 0;
+    ssp::DevBuf wimg;
+    ssp::DevBuf scratch;  // llT when the caller does not ask for it (grow-only)
+};
+
+using namespace ssp;
+
+extern "C" {
+
+int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const double* weights, const double* means,
+                 const double* covars, int32_t has_ubm, ssp_gmm** out) {
+    if (!out) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_pack: null out");
+    *out = nullptr;
+    SSP_TRY(use_ctx(ctx));
+    if (n_models < 1 || K < 1 || D < 1 || !weights || !means || !covars)
+        SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_pack: bad shape or null parameter array");
+    if (has_ubm && n_models < 2) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_pack: has_ubm needs at least one speaker model");
+    const int nq = pick_nq(D);
+    if (nq < 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_pack: D=%d exceeds the supported feature dimension (127)", D);
+    const int tpm = (K + 31) / 32;
+    const size_t tile_floats = (size_t)nq * 2 * 32 * 4;
+    const size_t n_tiles = (size_t)n_models * tpm;
+    std::vector<float> img(n_tiles * tile_floats, 0.f);
+    const double ln2pi = std::log(2.0 * M_PI);
+    std::vector<double> w((size_t)nq * 8);
+    for (int m = 0; m < n_models; ++m)
+        for (int k = 0; k < tpm * 32; ++k) {
+            std::fill(w.begin(), w.end(), 0.0);
+            if (k < K) {
+                const double* mu = means + ((size_t)m * K + k) * D;
+                const double* cv = covars + ((size_t)m * K + k) * D;
+                const double wk = weights[(size_t)m * K + k];
+                double c = std::log(wk) - 0.5 * D * ln2pi;
+                for (int d = 0; d < D; ++d) {
+                    if (!(cv[d] > 0.0)) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_pack: non-positive covariance (model %d, mix %d)", m, k);
+                    const double P = 1.0 / cv[d];
+                    w[d] = mu[d] * P;
+                    w[D + d] = -0.5 * P;
+                    c += 0.5 * std::log(P) - 0.5 * mu[d] * mu[d] * P;
+                }
+                w[2 * D] = c;
+            } else {
+                w[2 * D] = -1.0e30;  // padded mixture: contributes exp(-1e30 - max) = 0 to the LSE
+            }
+            float* tile = img.data() + ((size_t)m * tpm + k / 32) * tile_floats;
+            const int mix = k & 31;
+            for (int j = 0; j < nq * 8; ++j) {
+                const int q = j >> 3, e = (j & 7) >> 1, hh = j & 1;
+                tile[((size_t)(q * 2 + hh) * 32 + mix) * 4 + e] = (float)w[j];
+            }
+        }
+    ssp_gmm* g = new (std::nothrow) ssp_gmm;
+    if (!g) SSP_FAIL(SSP_ERR_NOMEM, "gmm: host alloc");
+    g->ctx = ctx;
+    g->n_models = n_models;
+    g->K = K;
+    g->D = D;
+    g->has_ubm = has_ubm ? 1 : 0;
+    g->nq = nq;
+    g->tiles_per_model = tpm;
+    int rc = g->wimg.alloc(img.size() * sizeof(float));
+    if (rc == SSP_OK) {
+        hipError_t e = hipMemcpyAsync(g->wimg.p, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gmm: upload failed: %s", hipGetErrorString(e));
+            rc = SSP_ERR_HIP;
+        }
+    }
+    if (rc != SSP_OK) {
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return SSP_OK;
+}
+
+int ssp_gmm_destroy(ssp_gmm* gmm) {
+    if (!gmm) return SSP_OK;
+    if (gmm->ctx) {
+        (void)hipSetDevice(gmm->ctx->device);
+        (void)hipStreamSynchronize(gmm->ctx->stream);
+    }
+    delete gmm;
+    return SSP_OK;
+}
+
+int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_seg, float* loglik_out,
+                  float* scores_out, int32_t* argmax_out, int where, int precision, float* kernel_ms) {
+    if (!gmm || !frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: null handle");
+    ssp_ctx* ctx = gmm->ctx;
+    SSP_TRY(use_ctx(ctx));
+    if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: where");
+    if (precision != 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_score: precision %d not built (0 = fp32 MFMA)", precision);
+    if (kernel_ms) *kernel_ms = 0.f;
+    const int64_t F = frame_seg->host.back();
+    const int64_t n_utt = frame_seg->n;
+    if (n_utt == 0) return SSP_OK;
+    if (F > 0 && !feats) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: null feats");
+    hipStream_t s = ctx->stream;
+    const int M = gmm->n_models;
+    Staged sin, sll, ssc, sam;
+    int rc;
+    const float* d_feats = (const float*)sin.in(ctx, feats, (size_t)F * gmm->D * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    const size_t ll_bytes = (size_t)M * (size_t)std::max<int64_t>(F, 1) * sizeof(float);
+    float* d_ll = nullptr;
+    if (loglik_out) {
+        d_ll = (float*)sll.out(loglik_out, ll_bytes, where, &rc);
+        SSP_TRY(rc);
+    } else {
+        if (gmm->scratch.bytes < ll_bytes) SSP_TRY(gmm->scratch.alloc(ll_bytes));
+        d_ll = gmm->scratch.as<float>();
+    }
+    float* d_sc = (float*)ssc.out(scores_out, (size_t)n_utt * M * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    int32_t* d_am = (int32_t*)sam.out(argmax_out, (size_t)n_utt * sizeof(int32_t), where, &rc);
+    SSP_TRY(rc);
+
+    GmmArgs a{};
+    a.feats = d_feats;
+    a.wimg = gmm->wimg.as<float>();
+    a.llT = d_ll;
+    a.F = F;
+    a.D = gmm->D;
+    a.n_models = M;
+    a.tiles_per_model = gmm->tiles_per_model;
+    a.n_tiles = M * gmm->tiles_per_model;
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, s));
+    if (F > 0) {
+        switch (gmm->nq) {
+            case 4: SSP_TRY((launch_loglik<4, 2>(a, s))); break;
+            case 7: SSP_TRY((launch_loglik<7, 2>(a, s))); break;
+            case 10: SSP_TRY((launch_loglik<10, 2>(a, s))); break;
+            case 16: SSP_TRY((launch_loglik<16, 2>(a, s))); break;
+            case 24: SSP_TRY((launch_loglik<24, 1>(a, s))); break;
+            case 32: SSP_TRY((launch_loglik<32, 1>(a, s))); break;
+            default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no kernel for nq=%d", gmm->nq);
+        }
+    }
+    if (scores_out || argmax_out) {
+        if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many utterances");
+        hipLaunchKernelGGL(gmm_utt_reduce_kernel, dim3((unsigned)n_utt), dim3(256), (size_t)M * sizeof(float), s, d_ll, F,
+                           frame_seg->dev.as<int64_t>(), M, gmm->has_ubm, d_sc, d_am);
+        SSP_HIP(hipGetLastError());
+    }
+    SSP_TRY(tm.stop(s, kernel_ms));
+    SSP_TRY(sll.back(ctx, loglik_out, ll_bytes, where));
+    SSP_TRY(ssc.back(ctx, scores_out, (size_t)n_utt * M * sizeof(float), where));
+    SSP_TRY(sam.back(ctx, argmax_out, (size_t)n_utt * sizeof(int32_t), where));
+    if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(s));
+    return SSP_OK;
+}
+
+}  // extern "C"

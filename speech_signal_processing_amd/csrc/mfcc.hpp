@@ -1,0 +1,60 @@
+// Kernel argument block + plan object of the fused MFCC pass.
+#pragma once
+#include "common.hpp"
+
+namespace ssp {
+
+struct MfccChunk {
+    int32_t utt;  // utterance index
+    int32_t t0;   // first frame of the chunk inside the utterance
+    int32_t n;    // frames in the chunk
+    int32_t pad;
+};
+
+struct MfccArgs {
+    // data
+    const float* samples;
+    const int64_t* sample_off;  // [n_utt+1] device
+    const int64_t* frame_off;   // [n_utt+1] device
+    float* out;                 // [total_frames x d_out]
+    const MfccChunk* chunks;
+    // tables (device)
+    const float* window;    // [n_fft] zero padded
+    const float2* twiddle;  // [n_fft]  W_nfft^k = exp(-2 pi i k / n_fft)
+    const int32_t* filt_lo;
+    const int32_t* filt_len;
+    const int32_t* filt_ofs;
+    const float* filt_w;
+    const float* dct;  // [n_ceps x n_filt]
+    // cfg
+    int32_t win_len, hop, n_fft, n_filt, n_ceps, d_out;
+    int32_t frame_mode, preemph_mode, spec_power, log_mode, floor_mode, delta_order, delta_N, cmvn;
+    float preemph, spec_scale, eps, top_db, delta_inv_denom;
+    // LDS carve (bytes from the dynamic LDS base; all multiples of 16)
+    int32_t lds_logmel_off, lds_ceps_off, lds_dlt_off, lds_ddl_off, lds_lmrows_off, lds_stats_off;
+};
+
+int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, hipStream_t stream);
+// fused n_fft == 512 throughput kernel (mfcc_fast.hip); returns SSP_ERR_UNSUPPORTED when the cfg is not covered
+bool mfcc_fast_supported(const ssp_mfcc_cfg& cfg);
+int launch_mfcc_fast(const MfccArgs& args, const ssp_mfcc_cfg& cfg, int n_chunks, int chunk_frames, int num_cu,
+                     hipStream_t stream);
+
+}  // namespace ssp
+
+struct ssp_mfcc_plan {
+    ssp_ctx* ctx = nullptr;
+    ssp_mfcc_cfg cfg{};
+    int32_t d_out = 0;
+    ssp::DevBuf window, twiddle, filt_lo, filt_len, filt_ofs, filt_w, dct, fbank_dense;
+    int32_t max_filt_len = 0;
+    // cached work table for the last (sample_seg, frame_seg, variant) seen
+    uint64_t cache_sseg = 0;  // ssp_segments::serial
+    uint64_t cache_fseg = 0;
+    int cache_variant = -1;
+    int cache_chunk_frames = 0;
+    size_t cache_lds = 0;
+    int32_t cache_n_chunks = 0;
+    ssp::DevBuf chunks;
+    ssp::MfccArgs args{};
+};

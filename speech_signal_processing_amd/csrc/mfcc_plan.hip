@@ -1,0 +1,296 @@
+// Host side of the MFCC pass: plan (device tables), framing rules, chunk work table, launch.
+#include <cmath>
+
+#include "mfcc.hpp"
+
+namespace ssp {
+
+static int validate_cfg(const ssp_mfcc_cfg* c) {
+    if (!c) SSP_FAIL(SSP_ERR_INVALID, "mfcc: null cfg");
+    if (c->n_fft < 64 || c->n_fft > 2048 || (c->n_fft & (c->n_fft - 1)))
+        SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: n_fft=%d must be a power of two in [64, 2048]", c->n_fft);
+    if (c->win_len < 1 || c->win_len > c->n_fft) SSP_FAIL(SSP_ERR_INVALID, "mfcc: win_len=%d not in [1, n_fft]", c->win_len);
+    if (c->hop < 1) SSP_FAIL(SSP_ERR_INVALID, "mfcc: hop < 1");
+    if (c->n_filt < 1 || c->n_filt > 512) SSP_FAIL(SSP_ERR_INVALID, "mfcc: n_filt=%d not in [1,512]", c->n_filt);
+    if (c->n_ceps < 1 || c->n_ceps > 128) SSP_FAIL(SSP_ERR_INVALID, "mfcc: n_ceps=%d not in [1,128]", c->n_ceps);
+    if (c->frame_mode < 0 || c->frame_mode > 2) SSP_FAIL(SSP_ERR_INVALID, "mfcc: frame_mode");
+    if (c->frame_mode == 2 && c->win_len != c->n_fft)
+        SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: centred framing needs win_len == n_fft");
+    if (c->preemph_mode < 0 || c->preemph_mode > 1) SSP_FAIL(SSP_ERR_INVALID, "mfcc: preemph_mode");
+    if (c->spec_power != 1 && c->spec_power != 2) SSP_FAIL(SSP_ERR_INVALID, "mfcc: spec_power must be 1 or 2");
+    if (c->log_mode < 0 || c->log_mode > 2) SSP_FAIL(SSP_ERR_INVALID, "mfcc: log_mode");
+    if (c->floor_mode < 0 || c->floor_mode > 2) SSP_FAIL(SSP_ERR_INVALID, "mfcc: floor_mode");
+    if (c->delta_order < 0 || c->delta_order > 2) SSP_FAIL(SSP_ERR_INVALID, "mfcc: delta_order must be 0, 1 or 2");
+    if (c->delta_order > 0 && (c->delta_N < 1 || c->delta_N > 8))
+        SSP_FAIL(SSP_ERR_INVALID, "mfcc: delta_N must be in [1, 8] (GMM_UBM.py:59 raises for N < 1)");
+    return SSP_OK;
+}
+
+static int64_t frames_for(const ssp_mfcc_cfg& c, int64_t n) {
+    switch (c.frame_mode) {
+        case 0: return n < c.win_len ? 0 : (n - c.win_len) / c.hop + 1;  // sidekit framing: floor, no padding
+        case 1: return (n + c.hop - 1) / c.hop;                          // utils/processing.py:27 ceil(wlen/step)
+        default: return n <= 0 ? 0 : 1 + n / c.hop;                      // librosa stft(center=True)
+    }
+}
+
+template <class T>
+static int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
+    SSP_TRY(b.alloc(sizeof(T) * v.size()));
+    if (!v.empty()) SSP_HIP(hipMemcpyAsync(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, s));
+    return SSP_OK;
+}
+
+static size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
+
+// LDS carve of the generic kernel for chunks of `ch` frames; returns total bytes
+static size_t generic_lds_layout(const ssp_mfcc_cfg& c, int ch, MfccArgs* a) {
+    const int H = c.delta_order * c.delta_N;
+    size_t off = (size_t)4 * c.n_fft * sizeof(float2);  // 4 waves x [2][n_fft/2] float2
+    a->lds_logmel_off = (int32_t)off;
+    off = align16(off + (size_t)4 * c.n_filt * sizeof(float));
+    a->lds_ceps_off = (int32_t)off;
+    off = align16(off + (size_t)(ch + 2 * H) * c.n_ceps * sizeof(float));
+    a->lds_dlt_off = (int32_t)off;
+    if (c.delta_order >= 1) off = align16(off + (size_t)(ch + 2 * (c.delta_order - 1) * c.delta_N) * c.n_ceps * sizeof(float));
+    a->lds_ddl_off = (int32_t)off;
+    if (c.delta_order >= 2) off = align16(off + (size_t)ch * c.n_ceps * sizeof(float));
+    a->lds_lmrows_off = (int32_t)off;
+    if (c.top_db >= 0.f) off = align16(off + (size_t)ch * c.n_filt * sizeof(float));
+    a->lds_stats_off = (int32_t)off;
+    off = align16(off + (size_t)(2 * c.n_ceps * (1 + c.delta_order) + 8) * sizeof(float));
+    return off;
+}
+
+static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segments* fseg, int variant) {
+    const ssp_mfcc_cfg& c = p->cfg;
+    const bool whole = c.cmvn || c.top_db >= 0.f;  // needs utterance-level statistics inside one workgroup
+    const int64_t max_T = fseg->max_len();
+    const size_t lds_cap = 160 * 1024;
+    int ch;
+    size_t lds = 0;
+    if (variant == 2) {
+        ch = 0;  // decided by the fast kernel's own geometry (see mfcc_fast.hip); chunk = whole utterance capped
+        ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 1024);
+        if (whole && max_T > ch) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): cmvn needs utterances of <= %d frames", ch);
+    } else {
+        MfccArgs tmp{};
+        ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
+        while (ch > 16 && generic_lds_layout(c, ch, &tmp) > 64 * 1024 && !whole) ch = (ch * 3) / 4;
+        if (whole) {
+            ch = (int)std::max<int64_t>(max_T, 1);
+            if (generic_lds_layout(c, ch, &tmp) > lds_cap)
+                SSP_FAIL(SSP_ERR_UNSUPPORTED,
+                         "mfcc: cmvn/top_db need a whole utterance per workgroup; %lld frames exceed the 160 KiB LDS",
+                         (long long)max_T);
+        }
+        lds = generic_lds_layout(c, ch, &p->args);
+        if (lds > lds_cap) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: LDS footprint %zu B exceeds 160 KiB", lds);
+    }
+    std::vector<MfccChunk> chunks;
+    chunks.reserve((size_t)fseg->n);
+    for (int64_t u = 0; u < fseg->n; ++u) {
+        const int64_t T = fseg->host[u + 1] - fseg->host[u];
+        if (T > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: utterance %lld has too many frames", (long long)u);
+        for (int64_t t0 = 0; t0 < T; t0 += ch)
+            chunks.push_back(MfccChunk{(int32_t)u, (int32_t)t0, (int32_t)std::min<int64_t>(ch, T - t0), 0});
+    }
+    if (chunks.size() > (size_t)INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: too many chunks");
+    SSP_TRY(upload(p->chunks, chunks, p->ctx->stream));
+    SSP_HIP(hipStreamSynchronize(p->ctx->stream));  // `chunks` (host) dies at return
+    p->cache_n_chunks = (int32_t)chunks.size();
+    p->cache_chunk_frames = ch;
+    p->cache_lds = lds;
+    p->cache_sseg = sseg->serial;
+    p->cache_fseg = fseg->serial;
+    p->cache_variant = variant;
+    return SSP_OK;
+}
+
+}  // namespace ssp
+
+using namespace ssp;
+
+extern "C" {
+
+int ssp_mfcc_num_frames(const ssp_mfcc_cfg* cfg, int64_t n_samples, int64_t* n_frames) {
+    if (!cfg || !n_frames || n_samples < 0) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_num_frames: bad argument");
+    if (cfg->hop < 1 || cfg->frame_mode < 0 || cfg->frame_mode > 2) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_num_frames: bad cfg");
+    *n_frames = frames_for(*cfg, n_samples);
+    return SSP_OK;
+}
+
+int ssp_mfcc_out_dim(const ssp_mfcc_cfg* cfg, int32_t* d_out) {
+    if (!cfg || !d_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_out_dim: null");
+    *d_out = cfg->n_ceps * (1 + cfg->delta_order);
+    return SSP_OK;
+}
+
+int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* window, const float* fbank,
+                         const float* dct, ssp_mfcc_plan** out) {
+    if (!out) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_plan_create: null out");
+    *out = nullptr;
+    SSP_TRY(use_ctx(ctx));
+    SSP_TRY(validate_cfg(cfg));
+    if (!window || !fbank || !dct) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_plan_create: null table");
+    ssp_mfcc_plan* p = new (std::nothrow) ssp_mfcc_plan;
+    if (!p) SSP_FAIL(SSP_ERR_NOMEM, "mfcc plan: host alloc");
+    p->ctx = ctx;
+    p->cfg = *cfg;
+    p->d_out = cfg->n_ceps * (1 + cfg->delta_order);
+    const int n_fft = cfg->n_fft, nb = n_fft / 2 + 1;
+
+    std::vector<float> win(n_fft, 0.f);
+    for (int i = 0; i < cfg->win_len; ++i) win[i] = window[i];
+    std::vector<float2> tw(n_fft);
+    for (int k = 0; k < n_fft; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)n_fft;
+        tw[k] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    // banded form of the filterbank: per filter [lo, lo+len) = first..last non-zero bin
+    std::vector<int32_t> lo(cfg->n_filt), len(cfg->n_filt), ofs(cfg->n_filt);
+    std::vector<float> w;
+    int32_t maxlen = 0;
+    for (int j = 0; j < cfg->n_filt; ++j) {
+        const float* row = fbank + (size_t)j * nb;
+        int first = -1, last = -1;
+        for (int k = 0; k < nb; ++k)
+            if (row[k] != 0.f) {
+                if (first < 0) first = k;
+                last = k;
+            }
+        lo[j] = first < 0 ? 0 : first;
+        len[j] = first < 0 ? 0 : last - first + 1;
+        ofs[j] = (int32_t)w.size();
+        for (int k = 0; k < len[j]; ++k) w.push_back(row[lo[j] + k]);
+        maxlen = std::max(maxlen, len[j]);
+    }
+    p->max_filt_len = maxlen;
+    std::vector<float> dctv(dct, dct + (size_t)cfg->n_ceps * cfg->n_filt);
+    std::vector<float> dense(fbank, fbank + (size_t)cfg->n_filt * nb);
+    hipStream_t s = ctx->stream;
+    int rc = upload(p->window, win, s);
+    if (rc == SSP_OK) rc = upload(p->twiddle, tw, s);
+    if (rc == SSP_OK) rc = upload(p->filt_lo, lo, s);
+    if (rc == SSP_OK) rc = upload(p->filt_len, len, s);
+    if (rc == SSP_OK) rc = upload(p->filt_ofs, ofs, s);
+    if (rc == SSP_OK) rc = upload(p->filt_w, w, s);
+    if (rc == SSP_OK) rc = upload(p->dct, dctv, s);
+    if (rc == SSP_OK) rc = upload(p->fbank_dense, dense, s);
+    if (rc == SSP_OK && hipStreamSynchronize(s) != hipSuccess) {
+        set_error("mfcc plan: table upload failed");
+        rc = SSP_ERR_HIP;
+    }
+    if (rc != SSP_OK) {
+        delete p;
+        return rc;
+    }
+    MfccArgs& a = p->args;
+    a.window = p->window.as<float>();
+    a.twiddle = p->twiddle.as<float2>();
+    a.filt_lo = p->filt_lo.as<int32_t>();
+    a.filt_len = p->filt_len.as<int32_t>();
+    a.filt_ofs = p->filt_ofs.as<int32_t>();
+    a.filt_w = p->filt_w.as<float>();
+    a.dct = p->dct.as<float>();
+    a.win_len = cfg->win_len;
+    a.hop = cfg->hop;
+    a.n_fft = cfg->n_fft;
+    a.n_filt = cfg->n_filt;
+    a.n_ceps = cfg->n_ceps;
+    a.d_out = p->d_out;
+    a.frame_mode = cfg->frame_mode;
+    a.preemph_mode = cfg->preemph_mode;
+    a.spec_power = cfg->spec_power;
+    a.log_mode = cfg->log_mode;
+    a.floor_mode = cfg->floor_mode;
+    a.delta_order = cfg->delta_order;
+    a.delta_N = cfg->delta_order > 0 ? cfg->delta_N : 0;
+    a.cmvn = cfg->cmvn;
+    a.preemph = cfg->preemph;
+    a.spec_scale = cfg->spec_scale;
+    a.eps = cfg->eps;
+    a.top_db = cfg->top_db;
+    int den = 0;
+    for (int i = 1; i <= a.delta_N; ++i) den += 2 * i * i;  // GMM_UBM.py:61
+    a.delta_inv_denom = den > 0 ? 1.0f / (float)den : 0.f;
+    *out = p;
+    return SSP_OK;
+}
+
+int ssp_mfcc_plan_destroy(ssp_mfcc_plan* plan) {
+    if (!plan) return SSP_OK;
+    if (plan->ctx) {
+        (void)hipSetDevice(plan->ctx->device);
+        (void)hipStreamSynchronize(plan->ctx->stream);
+    }
+    delete plan;
+    return SSP_OK;
+}
+
+int ssp_mfcc_frame_segments(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, ssp_segments** frame_seg_out) {
+    if (!plan || !sample_seg || !frame_seg_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_frame_segments: null");
+    std::vector<int64_t> fo((size_t)sample_seg->n + 1);
+    fo[0] = 0;
+    for (int64_t u = 0; u < sample_seg->n; ++u) {
+        const int64_t ns = sample_seg->host[u + 1] - sample_seg->host[u];
+        if (plan->cfg.frame_mode == 2 && ns > 0 && ns <= plan->cfg.n_fft / 2)
+            SSP_FAIL(SSP_ERR_INVALID, "mfcc: utterance %lld has %lld samples; reflect padding needs > n_fft/2 = %d",
+                     (long long)u, (long long)ns, plan->cfg.n_fft / 2);
+        fo[u + 1] = fo[u] + frames_for(plan->cfg, ns);
+    }
+    return segments_make(plan->ctx, fo.data(), sample_seg->n, frame_seg_out);
+}
+
+int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
+                 const float* samples, float* feats_out, int where, int variant, float* kernel_ms) {
+    if (!plan || !sample_seg || !frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: null handle");
+    SSP_TRY(use_ctx(plan->ctx));
+    if (sample_seg->n != frame_seg->n) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: sample/frame segment counts differ");
+    if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: where");
+    if (variant < 0 || variant > 2) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: variant");
+    const int64_t total_frames = frame_seg->total();
+    const int64_t n_samp_total = sample_seg->host.back();
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (total_frames == 0) return SSP_OK;
+    if (!samples || !feats_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: null data pointer");
+    for (int64_t u = 0; u < frame_seg->n; ++u) {  // frame segments must follow the plan's framing rule
+        const int64_t T = frame_seg->host[u + 1] - frame_seg->host[u];
+        if (T != frames_for(plan->cfg, sample_seg->host[u + 1] - sample_seg->host[u]))
+            SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: frame segment %lld does not match the framing rule", (long long)u);
+    }
+    int v = variant;
+    if (v == 0) v = mfcc_fast_supported(plan->cfg) ? 2 : 1;
+    if (v == 2 && !mfcc_fast_supported(plan->cfg))
+        SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the fused fast kernel does not cover this cfg");
+    if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_variant != v)
+        SSP_TRY(build_work(plan, sample_seg, frame_seg, v));
+
+    hipStream_t s = plan->ctx->stream;
+    Staged sin, sout;
+    int rc;
+    const size_t out_bytes = (size_t)(frame_seg->host.back()) * plan->d_out * sizeof(float);
+    const float* d_samples = (const float*)sin.in(plan->ctx, samples, (size_t)n_samp_total * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    float* d_out = (float*)sout.out(feats_out, out_bytes, where, &rc);
+    SSP_TRY(rc);
+
+    MfccArgs a = plan->args;
+    a.samples = d_samples;
+    a.sample_off = sample_seg->dev.as<int64_t>();
+    a.frame_off = frame_seg->dev.as<int64_t>();
+    a.out = d_out;
+    a.chunks = plan->chunks.as<MfccChunk>();
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, s));
+    if (v == 2)
+        SSP_TRY(launch_mfcc_fast(a, plan->cfg, plan->cache_n_chunks, plan->cache_chunk_frames, plan->ctx->num_cu, s));
+    else
+        SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, s));
+    SSP_TRY(tm.stop(s, kernel_ms));
+    SSP_TRY(sout.back(plan->ctx, feats_out, out_bytes, where));
+    if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(s));
+    return SSP_OK;
+}
+
+}  // extern "C"

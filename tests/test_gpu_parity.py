@@ -1,0 +1,372 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI via the reference-shaped
+Python surface, against (a) golden vectors generated from the reference itself and (b) the CPU oracle on seeded inputs.
+
+Tolerances (BASELINE.json north_star: "MFCC and log-likelihoods within 1e-4 rel fp32, argmax speaker id bit-exact"):
+  features : max|gpu-ref| <= 1e-4 * max(1, max|ref|) per utterance  AND  allclose(rtol=1e-4, atol=1e-4*rms(ref))
+  scores   : |gpu-ref| <= 1e-4 * |ref|
+  argmax / argmin : exact
+"""
+import numpy as np
+import pytest
+
+from conftest import synth_audio
+
+pytestmark = pytest.mark.gpu
+
+FEAT_TOL = 1e-4
+
+
+def assert_feat_close(got, ref, tol=FEAT_TOL, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    if ref.size == 0:
+        return
+    fin = np.isfinite(ref)
+    assert (np.isfinite(got) == fin).all(), what + ": non-finite pattern differs"
+    g, r = got[fin], ref[fin]
+    if r.size == 0:
+        return
+    err = np.abs(g - r).max()
+    assert err <= tol * max(1.0, np.abs(r).max()), "%s: max abs err %.3e (ref max %.3e)" % (what, err, np.abs(r).max())
+    rms = np.sqrt(np.mean(r * r))
+    assert np.allclose(g, r, rtol=tol, atol=tol * max(rms, 1e-30)), "%s: allclose(rtol=1e-4, atol=1e-4*rms) failed, max err %.3e rms %.3e" % (what, err, rms)
+
+
+@pytest.fixture(scope="module")
+def ssp():
+    import speech_signal_processing_amd as pkg
+    from speech_signal_processing_amd import api
+    return pkg, api
+
+
+# ----------------------------------------------------------------------------------------- MFCC-A vs the reference
+SIGNALS = ["noise", "tone", "silence", "ragged", "short", "int16", "utt3s16k", "one_step"]
+GEOMS = [(8000, 512, 256), (16000, 512, 256), (16000, 256, 128), (8000, 1024, 512)]
+
+
+@pytest.mark.parametrize("name", SIGNALS)
+def test_inrepo_mfcc_vs_reference_golden(golden, ssp, name):
+    from speech_signal_processing_amd.utils import processing as P
+    from speech_signal_processing_amd import MFCC_DTW
+    g = golden("mfcc_inrepo")
+    x = g[f"x_{name}"]
+    for fs, L, st in GEOMS:
+        got = P.MFCC(x, fs=fs, frameSize=L, step=st)
+        assert got.dtype == np.float64
+        assert_feat_close(got, g[f"mfcc_{name}_{fs}_{L}_{st}"], what=f"{name} {fs}/{L}/{st}")
+    assert_feat_close(MFCC_DTW._MFCC(x), g[f"flat_{name}"], what="flat " + name)
+
+
+def test_inrepo_batch_equals_single(golden, ssp):
+    from speech_signal_processing_amd.utils import processing as P
+    g = golden("mfcc_inrepo")
+    xs = [g[f"x_{n}"] for n in SIGNALS]
+    batch = P.MFCC_batch(xs)
+    for n, b in zip(SIGNALS, batch):
+        single = P.MFCC(g[f"x_{n}"])
+        assert np.array_equal(b, single), n  # bit-identical: utterances are independent
+        assert_feat_close(b, g[f"mfcc_{n}_8000_512_256"], what=n)
+
+
+def test_enframe_and_tables(golden, ssp):
+    from speech_signal_processing_amd.utils import processing as P
+    g = golden("mfcc_inrepo")
+    for n in SIGNALS:
+        x = g[f"x_{n}"].astype(np.float64)
+        np.testing.assert_allclose(P.enframe(x, 400, 160), g[f"enframe_{n}_400_160"], rtol=1e-14, atol=1e-13)
+    np.testing.assert_allclose(P.stMFCC(g["stmfcc_X"], g["fbank_8000_512"], 13), g["stmfcc_out"], atol=1e-11)
+
+
+# ----------------------------------------------------------------------------------------- sidekit / librosa presets vs oracle
+def _run_plan(api, tables, signals, variant=0, device=False):
+    ctx = api.default_context(torch_stream=device)
+    plan = api.MfccPlan(ctx, tables)
+    seg = api.Segments.from_lengths(ctx, [len(s) for s in signals])
+    fseg = plan.frame_segments(seg)
+    flat = np.concatenate(signals).astype(np.float32) if signals else np.zeros(0, np.float32)
+    if device:
+        import torch
+        flat = torch.from_numpy(flat).cuda()
+    out = plan.run(flat, seg, fseg, variant=variant)
+    if device:
+        out = out.cpu().numpy()
+    return [np.asarray(out[fseg.offsets[i]:fseg.offsets[i + 1]]) for i in range(len(signals))], fseg
+
+
+@pytest.mark.parametrize("delta_order,cmvn", [(0, 0), (1, 0), (2, 0), (1, 1), (2, 1)])
+def test_sidekit_preset_vs_oracle(ssp, delta_order, cmvn):
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    sigs = [synth_audio(u, 48000 if u % 3 else 16000 + 37 * u, 16000) for u in range(24)]
+    tables = pkg.preset_sidekit(delta_order=delta_order, cmvn=cmvn)
+    got, fseg = _run_plan(api, tables, sigs, variant=1)
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=delta_order, cmvn=cmvn)
+    assert fseg.offsets[-1] == sum(O.num_frames(len(s), cfg) for s in sigs)
+    for u, s in enumerate(sigs):
+        ref = O.mfcc_pipeline(s, cfg, w, fb, dct)
+        assert_feat_close(got[u], ref, what=f"utt {u} order {delta_order} cmvn {cmvn}")
+
+
+def test_sidekit_shape_fact(ssp):
+    """report/final.pdf IV-B-2: 1 s @ 16 kHz -> 98 x 13."""
+    pkg, api = ssp
+    got, _ = _run_plan(api, pkg.preset_sidekit(), [synth_audio(1, 16000, 16000)], variant=1)
+    assert got[0].shape == (98, 13)
+
+
+def test_mfcc_edge_cases(ssp):
+    """empty utterance, N < window, exactly one frame, ragged batch, silence (ln 0 = -inf like the reference)."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    sigs = [np.zeros(0, np.float32), synth_audio(2, 399, 16000), synth_audio(3, 400, 16000), synth_audio(4, 559, 16000),
+            synth_audio(5, 560, 16000), np.zeros(1000, np.float32), synth_audio(6, 16000, 16000)]
+    for order in (0, 2):
+        tables = pkg.preset_sidekit(delta_order=order)
+        got, fseg = _run_plan(api, tables, sigs, variant=1)
+        cfg, w, fb, dct = O.sidekit_tables(delta_order=order)
+        assert [g.shape[0] for g in got] == [0, 0, 1, 1, 2, 4, 98]
+        for u, s in enumerate(sigs):
+            ref = O.mfcc_pipeline(s, cfg, w, fb, dct)
+            if u == 5:  # silence: every value is -inf / nan in both
+                assert not np.isfinite(got[u]).any() and not np.isfinite(ref).any()
+            else:
+                assert_feat_close(got[u], ref, what=f"edge utt {u}")
+
+
+def test_librosa_preset_vs_oracle(ssp):
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd import MFCC_DTW
+    sigs = [synth_audio(u, 24000 + 1000 * u, 8000) for u in range(4)] + [synth_audio(9, 1025, 8000)]
+    got, _ = _run_plan(api, pkg.preset_librosa(8000, 13), sigs, variant=1)
+    cfg, w, fb, dct = O.librosa_tables(8000, 13)
+    for u, s in enumerate(sigs):
+        ref = O.mfcc_pipeline(s, cfg, w, fb, dct)
+        assert got[u].shape == (1 + len(s) // 512, 13)
+        # 10*log10 power_to_db values span 80 dB: tolerance relative to the largest coefficient
+        assert_feat_close(got[u], ref, what=f"librosa utt {u}")
+    assert_feat_close(MFCC_DTW.MFCC_lib(sigs[0]), O.librosa_mfcc_flat(sigs[0]), what="MFCC_lib")
+
+
+def test_device_pointer_path_matches_host_path(ssp):
+    pkg, api = ssp
+    sigs = [synth_audio(u, 16000 + 160 * u, 16000) for u in range(8)]
+    tables = pkg.preset_sidekit(delta_order=2)
+    host, _ = _run_plan(api, tables, sigs, variant=1, device=False)
+    dev, _ = _run_plan(api, tables, sigs, variant=1, device=True)
+    for a, b in zip(host, dev):
+        assert np.array_equal(a, b)
+
+
+def test_scale_invariance_property(ssp):
+    """c0 is dropped in the sidekit dialect, so scaling the waveform only shifts log-mel by a constant that the
+    remaining DCT rows annihilate: ceps(a*x) == ceps(x).  A size-independent check of FFT+mel+log+DCT."""
+    pkg, api = ssp
+    x = synth_audio(3, 48000, 16000)
+    got, _ = _run_plan(api, pkg.preset_sidekit(), [x, 8.0 * x, 0.125 * x], variant=1)
+    assert_feat_close(got[1], got[0], tol=2e-5, what="x8")
+    assert_feat_close(got[2], got[0], tol=2e-5, what="/8")
+
+
+def test_extract_feature_matches_reference_recipe(ssp):
+    """GMM_UBM.extract_feature: mfcc -> hstack(c, delta) -> preprocessing.scale, (T, 26)."""
+    from speech_signal_processing_amd import GMM_UBM
+    from oracle import ref_cpu as O
+    x = [synth_audio(u, 32000 + 999 * u, 16000) for u in range(5)]
+    y = [0, 1, 0, 2, 1]
+    train, feats, yy = GMM_UBM.extract_feature(x, y, is_train=True)
+    assert yy == y and set(train.keys()) == {0, 1, 2}
+    for u in range(5):
+        ref = O.extract_feature_one(x[u])
+        assert feats[u].shape == ref.shape and feats[u].shape[1] == 26
+        assert_feat_close(feats[u], ref, what=f"extract_feature {u}")
+    assert train[0].shape[0] == feats[0].shape[0] + feats[2].shape[0]
+    with pytest.raises(NameError):
+        GMM_UBM.extract_feature(x, y, feature_type='XYZ')
+
+
+# ----------------------------------------------------------------------------------------- delta / scale
+def test_delta_vs_reference_golden(golden, ssp):
+    from speech_signal_processing_amd import GMM_UBM, d_vector
+    g = golden("delta_scale")
+    for T in (1, 2, 5, 298):
+        for D in (13, 26):
+            f = g[f"feat_{T}_{D}"]
+            got = GMM_UBM.delta(f)
+            assert got.dtype == f.dtype
+            np.testing.assert_allclose(got, g[f"delta_{T}_{D}"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(GMM_UBM.delta(f, N=3), g[f"delta3_{T}_{D}"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(d_vector.Data_gen.delta(f), g[f"delta_{T}_{D}"], rtol=0, atol=2e-6)
+    assert GMM_UBM.delta(g["feat_f32"]).dtype == np.float32
+    with pytest.raises(ValueError):
+        GMM_UBM.delta(g["feat_f32"], N=0)
+
+
+def test_cmvn_vs_sklearn_golden(golden, ssp):
+    pkg, api = ssp
+    g = golden("delta_scale")
+    ctx = api.default_context()
+    for key in ("scale", "scale_one"):
+        x = g[f"{key}_in"]
+        seg = api.Segments.from_lengths(ctx, [x.shape[0]])
+        got = api.cmvn_features(ctx, x, seg)
+        np.testing.assert_allclose(got, g[f"{key}_out"], rtol=0, atol=3e-5)
+
+
+# ----------------------------------------------------------------------------------------- GMM scoring
+@pytest.mark.parametrize("K,D", [(1, 13), (16, 26), (64, 39), (5, 7), (40, 39)])
+def test_gmm_score_samples_vs_sklearn_golden(golden, ssp, K, D):
+    pkg, api = ssp
+    g = golden("gmm")
+    ctx = api.default_context()
+    sc = api.GmmScorer(ctx, g[f"w_{K}_{D}"][None], g[f"mu_{K}_{D}"][None], g[f"cov_{K}_{D}"][None], has_ubm=False)
+    X = g[f"X_{K}_{D}"]
+    seg = api.Segments.from_lengths(ctx, [X.shape[0]])
+    r = sc.score(X, seg, loglik=True, scores=True, argmax=False)
+    ref = g[f"ss_{K}_{D}"]
+    assert np.abs(r["loglik"][0] - ref).max() <= 1e-4 * np.abs(ref).max()
+    np.testing.assert_allclose(r["loglik"][0], ref, rtol=1e-4, atol=1e-4)
+    assert abs(r["scores"][0, 0] - float(g[f"score_{K}_{D}"])) <= 1e-4 * abs(float(g[f"score_{K}_{D}"]))
+
+
+def test_gmm_score_matrix_vs_reference_loop(golden, ssp):
+    """U=100, S=10: the double loop of GMM_UBM.py:181-197 (golden) vs one GPU call; argmax exact."""
+    from speech_signal_processing_amd import GMM_UBM
+
+    class M:  # duck-typed fitted GaussianMixture
+        covariance_type = "diag"
+
+        def __init__(self, w, mu, cov):
+            self.weights_, self.means_, self.covariances_ = w, mu, cov
+    g = golden("gmm")
+    ubm = M(g["sm_ubm_w"], g["sm_ubm_mu"], g["sm_ubm_cov"])
+    spk = [M(ubm.weights_, mu, ubm.covariances_) for mu in g["sm_spk_mu"]]
+    offs = np.concatenate([[0], np.cumsum(g["sm_lens"])])
+    feats = [g["sm_feats"][offs[j]:offs[j + 1]] for j in range(len(g["sm_lens"]))]
+    pred, am = GMM_UBM.score_matrix(spk, ubm, feats)
+    ref = g["sm_pred"]
+    top2 = np.sort(ref, axis=1)[:, -2:]
+    margin = (top2[:, 1] - top2[:, 0]).min()
+    assert (am == g["sm_argmax"]).all(), "argmax differs (min top-2 margin %.3g)" % margin
+    # differences of two ~-40 scores: compare the un-differenced scale
+    assert np.abs(pred - ref).max() <= 1e-4 * np.abs(g["sm_ubm_score"]).max()
+    y = list(g["sm_argmax"])
+    acc_tr, acc_te = GMM_UBM.GMM(None, feats[:50], y[:50], feats[50:], y[50:], model=(spk, ubm))
+    assert acc_tr == 1.0 and acc_te == 1.0
+    with pytest.raises(NotImplementedError):
+        GMM_UBM.GMM(None, feats, y, feats, y, model=False)
+
+
+def test_gmm_cfg3_shape_vs_oracle(ssp):
+    """cfg3 geometry at oracle-friendly size: D=39, K=64 UBM + 50 speaker GMMs (mean offsets), ragged utterances."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(7)
+    K, D, S, U = 64, 39, 50, 40
+    w = rng.dirichlet(5 * np.ones(K))
+    mu = rng.standard_normal((K, D))
+    cov = rng.uniform(0.5, 2.0, (K, D))
+    mus = [mu] + [mu + 0.3 * rng.standard_normal((K, D)) for _ in range(S)]
+    lens = rng.integers(1, 400, U)
+    feats = []
+    for j in range(U):
+        comp = rng.choice(K, size=lens[j], p=w)
+        feats.append((mus[1 + j % S][comp] + np.sqrt(cov[comp]) * rng.standard_normal((lens[j], D))).astype(np.float32))
+    ctx = api.default_context()
+    sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), np.stack(mus), np.stack([cov] * (S + 1)), has_ubm=True)
+    seg = api.Segments.from_lengths(ctx, lens)
+    r = sc.score(np.vstack(feats), seg, loglik=True)
+    ref_pred, ref_am = O.score_matrix([(w, m, cov) for m in mus[1:]], (w, mu, cov), feats)
+    got_pred = r["scores"][:, 1:].astype(np.float64) - r["scores"][:, :1]
+    ref_scores = np.array([[O.gmm_score(w, m, cov, f) for m in mus] for f in feats])
+    assert np.abs(r["scores"] - ref_scores).max() <= 1e-4 * np.abs(ref_scores).max()
+    np.testing.assert_allclose(r["scores"], ref_scores, rtol=1e-4)
+    assert (np.asarray(r["argmax"]) == ref_am).all()
+    assert np.abs(got_pred - ref_pred).max() < 2e-3
+    ll_ref = O.gmm_score_samples(w, mus[3], cov, np.vstack(feats))
+    np.testing.assert_allclose(r["loglik"][3], ll_ref, rtol=1e-4, atol=1e-4)
+
+
+def test_gmm_batch_permutation_property(ssp):
+    """Utterances are independent: permuting them permutes the outputs bit-exactly; the frame mean is reproducible."""
+    pkg, api = ssp
+    rng = np.random.default_rng(3)
+    K, D, M = 16, 26, 5
+    w = rng.dirichlet(np.ones(K), size=M)
+    mu = rng.standard_normal((M, K, D))
+    cov = rng.uniform(0.5, 2, (M, K, D))
+    ctx = api.default_context()
+    sc = api.GmmScorer(ctx, w, mu, cov, has_ubm=True)
+    lens = rng.integers(5, 300, 64)
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    perm = rng.permutation(64)
+    r1 = sc.score(np.vstack(feats), api.Segments.from_lengths(ctx, lens))
+    r2 = sc.score(np.vstack([feats[i] for i in perm]), api.Segments.from_lengths(ctx, lens[perm]))
+    assert np.array_equal(np.asarray(r1["scores"])[perm], np.asarray(r2["scores"]))
+    assert np.array_equal(np.asarray(r1["argmax"])[perm], np.asarray(r2["argmax"]))
+
+
+# ----------------------------------------------------------------------------------------- cosine
+@pytest.mark.parametrize("d", [128, 256, 512, "tie"])
+def test_cosine_vs_scipy_golden(golden, ssp, d):
+    from speech_signal_processing_amd import d_vector
+    g = golden("cosine")
+    X, Cn = g[f"X_{d}"], g[f"C_{d}"]
+    dist = d_vector.cosine_scores(X, Cn)
+    np.testing.assert_allclose(dist, g[f"dist_{d}"], rtol=0, atol=2e-6)
+    assert (d_vector.identify(X, Cn) == g[f"argmin_{d}"]).all()
+
+
+def test_cosine_odd_shapes_vs_oracle(ssp):
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(17)
+    for (N, S, d) in [(1, 1, 3), (130, 129, 70), (257, 1251, 256), (5, 300, 33)]:
+        Cn = rng.standard_normal((S, d))
+        X = (Cn[rng.integers(0, S, N)] + 0.7 * rng.standard_normal((N, d))).astype(np.float32)
+        r = api.cosine_identify(api.default_context(), X, Cn.astype(np.float32), dist=True)
+        ref = O.cosine_matrix(X, Cn.astype(np.float32))
+        np.testing.assert_allclose(r["dist"], ref, rtol=0, atol=3e-6)
+        assert (np.asarray(r["argmin"]) == ref.argmin(1)).all()
+        np.testing.assert_allclose(r["min"], ref.min(1), rtol=0, atol=3e-6)
+
+
+def test_nn_model_test_enroll_eval(ssp):
+    from speech_signal_processing_amd import d_vector
+    rng = np.random.default_rng(11)
+    S, d = 20, 256
+    Cn = rng.standard_normal((S, d))
+    lab_tr = np.repeat(np.arange(S), 10)
+    Xtr = (Cn[lab_tr] + 0.7 * rng.standard_normal((S * 10, d))).astype(np.float32)
+    lab_va = rng.integers(0, S, 100)
+    Xva = (Cn[lab_va] + 0.7 * rng.standard_normal((100, d))).astype(np.float32)
+    m = d_vector.nn_model()
+    assert m.test(Xtr, np.eye(S)[lab_tr], Xva, np.eye(S)[lab_va]) == 1.0
+    assert m.eval(Xva[0]) is None  # nothing enrolled
+    for s in range(3):
+        m.enroll(Xtr[lab_tr == s], "spk%d" % s)
+    assert m.eval(Xva[lab_va == 1][0]) == "spk1"
+    assert m.eval(-m.d_vector["spk0"] - m.d_vector["spk1"] - m.d_vector["spk2"]) is None  # every distance >= 1
+
+
+def test_dvector_front_end_shapes(ssp):
+    from speech_signal_processing_amd import d_vector
+    gen = d_vector.Data_gen(16000)
+    feats, labels = gen.extract_feature([synth_audio(0, 16000 * 2 + 500, 16000), synth_audio(1, 15999, 16000)], ["a", "b"])
+    assert len(feats) == 2 and labels == ["a", "a"] and all(f.shape == (98, 13) for f in feats)
+
+
+# ----------------------------------------------------------------------------------------- error behaviour
+def test_error_codes(ssp):
+    pkg, api = ssp
+    ctx = api.default_context()
+    with pytest.raises(ValueError):
+        api.Segments(ctx, np.array([0, 5, 3], dtype=np.int64))
+    t = pkg.preset_sidekit()
+    t.cfg.n_fft = 500  # not a power of two (e.g. utils.processing.MFCC(frameSize=500)) -> SSP_ERR_UNSUPPORTED
+    t.fbank = np.zeros((24, 251), np.float32)
+    with pytest.raises(NotImplementedError):
+        api.MfccPlan(ctx, t)
+    with pytest.raises(ValueError):
+        api.GmmScorer(ctx, np.ones((1, 2)) / 2, np.zeros((1, 2, 3)), np.zeros((1, 2, 3)), has_ubm=False)  # covariance 0

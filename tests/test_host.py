@@ -1,0 +1,112 @@
+"""CPU-side tests: host tables vs the oracle and the reference golden vectors, C-ABI surface, sharding logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import ref_cpu as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_inrepo_tables_match_reference(golden):
+    import speech_signal_processing_amd as pkg
+    g = golden("mfcc_inrepo")
+    for fs, L in [(8000, 512), (16000, 512), (16000, 256), (8000, 1024)]:
+        fb, fr = pkg.frontend.mfccInitFilterBanks(fs, L)
+        np.testing.assert_allclose(fb, g[f"fbank_{fs}_{L}"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(fr, g[f"freqs_{fs}_{L}"], rtol=0, atol=1e-12)
+        t = pkg.preset_inrepo(fs, L, L // 2)
+        cfg, w, fold, dct = O.inrepo_tables(fs, L, L // 2)
+        np.testing.assert_allclose(t.window, w, atol=1e-7)
+        np.testing.assert_allclose(t.fbank, fold, rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(t.dct, dct, atol=1e-7)
+        assert t.cfg.as_dict() == {k: pytest.approx(v) for k, v in cfg.items()}
+
+
+def test_sidekit_and_librosa_tables_match_oracle():
+    import speech_signal_processing_amd as pkg
+    for kw in (dict(), dict(window="hamming", delta_order=2, cmvn=1), dict(fs=8000, maxfreq=4000)):
+        t = pkg.preset_sidekit(**kw)
+        cfg, w, fb, dct = O.sidekit_tables(**kw)
+        assert t.cfg.as_dict() == {k: pytest.approx(v) for k, v in cfg.items()}
+        np.testing.assert_allclose(t.window, w, atol=1e-7)
+        np.testing.assert_allclose(t.fbank, fb, rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(t.dct, dct, atol=1e-7)
+    t = pkg.preset_sidekit()
+    assert t.fbank.shape == (24, 257) and int((t.fbank != 0).sum()) == 454
+    t = pkg.preset_librosa(8000, 13)
+    cfg, w, fb, dct = O.librosa_tables(8000, 13)
+    assert t.cfg.as_dict() == {k: pytest.approx(v) for k, v in cfg.items()}
+    np.testing.assert_allclose(t.window, w, atol=1e-7)
+    np.testing.assert_allclose(t.fbank, fb, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(t.dct, dct, atol=1e-7)
+
+
+def test_dct_matrix_is_scipy_ortho():
+    from scipy.fftpack import dct
+    import speech_signal_processing_amd as pkg
+    x = np.random.default_rng(0).standard_normal((5, 40))
+    np.testing.assert_allclose(x @ pkg.frontend.dct2_ortho(40, 0, 13).T, dct(x, type=2, norm="ortho", axis=-1)[:, :13], atol=1e-12)
+    np.testing.assert_allclose(x @ pkg.frontend.dct2_ortho(40, 1, 13).T, dct(x, type=2, norm="ortho", axis=-1)[:, 1:14], atol=1e-12)
+
+
+def test_num_frames_rules():
+    import speech_signal_processing_amd as pkg
+    sk, ir, lb = pkg.preset_sidekit().cfg, pkg.preset_inrepo().cfg, pkg.preset_librosa().cfg
+    assert [sk.num_frames(n) for n in (0, 399, 400, 559, 560, 16000, 48000)] == [0, 0, 1, 1, 2, 98, 298]
+    assert [ir.num_frames(n) for n in (0, 1, 256, 257, 24000)] == [0, 1, 1, 2, 94]
+    assert [lb.num_frames(n) for n in (0, 1025, 48000)] == [0, 3, 94]
+    for cfg in (sk, ir, lb):
+        for n in (0, 1, 400, 5077, 48000):
+            assert cfg.num_frames(n) == O.num_frames(n, cfg.as_dict())
+
+
+def test_enframe_mirror_matches_reference(golden):
+    from speech_signal_processing_amd.utils import processing as P
+    g = golden("mfcc_inrepo")
+    for n in ("noise", "ragged", "short", "one_step", "silence"):
+        x = g[f"x_{n}"].astype(np.float64)
+        for L, st in [(400, 160), (512, 256)]:
+            np.testing.assert_allclose(P.enframe(x, L, st), g[f"enframe_{n}_{L}_{st}"], rtol=1e-14, atol=1e-13)
+    np.testing.assert_allclose(P.stMFCC(g["stmfcc_X"], g["fbank_8000_512"], 13), g["stmfcc_out"], atol=1e-11)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The .so loads without a GPU and exports exactly the entry points include/ssp.h declares."""
+    from speech_signal_processing_amd import _lib
+    header = open(os.path.join(ROOT, "include", "ssp.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(ssp_[a-z_0-9]+)\s*\(", header, flags=re.M))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ssp_abi_version() == 1
+    assert ctypes.sizeof(_lib.ssp_mfcc_cfg) == 18 * 4
+
+
+def test_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without a gfx950 device every compute entry point raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from speech_signal_processing_amd import api, _lib
+    with pytest.raises(_lib.SspError):
+        api.Context(0)
+    from speech_signal_processing_amd.utils import processing as P
+    with pytest.raises(_lib.SspError):
+        P.MFCC(np.zeros(1000, dtype=np.float32))
+
+
+def test_frame_count_and_dim_helpers_need_no_gpu():
+    from speech_signal_processing_amd import _lib, api, preset_sidekit
+    lib = _lib.load()
+    cs = api._cfg_struct(preset_sidekit(delta_order=2).cfg)
+    n = ctypes.c_int64()
+    assert lib.ssp_mfcc_num_frames(ctypes.byref(cs), 48000, ctypes.byref(n)) == 0 and n.value == 298
+    d = ctypes.c_int32()
+    assert lib.ssp_mfcc_out_dim(ctypes.byref(cs), ctypes.byref(d)) == 0 and d.value == 39
+    assert lib.ssp_mfcc_num_frames(None, 10, ctypes.byref(n)) == _lib.SSP_ERR_INVALID
+    assert b"bad argument" in lib.ssp_last_error()
