@@ -1,0 +1,292 @@
+#!/usr/bin/env python
+"""Benchmark of the MFCC -> GMM-UBM / d-vector scoring hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Headline (`value`): MFCC frames/s on BASELINE.json configs[1] — 100k x 3 s synthetic 16 kHz utterances per GPU,
+sidekit-dialect MFCC + delta + delta-delta = 39-d, inputs resident in HBM, one fused kernel launch per step.
+A "step" = one pass of the fused MFCC kernel over the rank's whole batch.  Weak scaling: every rank owns its own
+100k utterances (utterances shard with no data-path collective); the only collective on the path is the gather of
+per-utterance speaker decisions after GMM scoring (stage "gmm").
+Extra stages reported in the same JSON line (not part of `value`): GMM-UBM scoring on configs[2] and cosine
+scoring on configs[4].
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md, Matrix cores)
+
+
+def synth_audio_device(torch, n_utt, n_samp, fs, seed, device, out=None, chunk=2000, n_spk=50):
+    """SURVEY.md 8(d) throughput recipe on the device: 5 harmonics of f0 = 90 + 3*spk Hz, 3 Hz AM, N(0, 0.05) noise."""
+    if out is None:
+        out = torch.empty((n_utt, n_samp), dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    t = torch.arange(n_samp, device=device, dtype=torch.float32) / fs
+    am = 0.6 + 0.4 * torch.sin(2 * np.pi * 3 * t)
+    for lo in range(0, n_utt, chunk):
+        hi = min(lo + chunk, n_utt)
+        spk = (torch.arange(lo, hi, device=device) % n_spk).to(torch.float32)
+        f0 = (90.0 + 3.0 * spk)[:, None]
+        x = torch.zeros((hi - lo, n_samp), dtype=torch.float32, device=device)
+        for h in range(1, 6):
+            x += torch.sin((2 * np.pi * h) * f0 * t[None, :]) / h
+        x *= 0.3 * am[None, :]
+        x += 0.05 * torch.randn((hi - lo, n_samp), generator=g, device=device, dtype=torch.float32)
+        out[lo:hi] = x.clamp_(-1, 1)
+    return out
+
+
+def cpu_baseline_mfcc(n_utt, n_samp, fs, budget_s=15.0):
+    """The oracle (numpy float64 restatement of the reference path) timed on this host, one thread."""
+    from oracle import ref_cpu as O
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=2)
+    rng = np.random.default_rng(0)
+    x = np.clip(0.3 * np.sin(2 * np.pi * 120 * np.arange(n_samp) / fs) + 0.05 * rng.standard_normal(n_samp), -1, 1).astype(np.float32)
+
+    def run():
+        frames, utts, t0 = 0, 0, time.perf_counter()
+        while utts < n_utt and time.perf_counter() - t0 < budget_s:
+            frames += O.mfcc_pipeline(x, cfg, w, fb, dct).shape[0]
+            utts += 1
+        return frames, utts, time.perf_counter() - t0
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            frames, utts, dt = run()
+    else:
+        frames, utts, dt = run()
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d utterances x %d samples, oracle.ref_cpu.mfcc_pipeline (numpy float64 restatement of the "
+                      "sidekit-dialect MFCC + delta + delta-delta path), 1 thread, %.1f s" % (utts, n_samp, dt),
+            "host_cores": os.cpu_count()}
+
+
+def cpu_baseline_gmm(D, K, n_models, budget_s=8.0):
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(1)
+    w = rng.dirichlet(5 * np.ones(K))
+    mu = rng.standard_normal((K, D))
+    cov = rng.uniform(0.5, 2, (K, D))
+    X = rng.standard_normal((298, D))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        O.gmm_score(w, mu, cov, X)  # one (speaker, utterance) score call, as the loop at GMM_UBM.py:183-185
+        n += 298
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frame-scores/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "per-(model, utterance) score() calls on 298x%d frames, K=%d, numpy float64 (BLAS threads = host default), %.1f s" % (D, K, dt)}
+
+
+def cpu_baseline_cosine(d, S, budget_s=5.0):
+    from scipy.spatial.distance import cosine
+    rng = np.random.default_rng(2)
+    Cn = rng.standard_normal((S, d))
+    x = rng.standard_normal(d).astype(np.float32)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for j in range(64):
+            cosine(x, Cn[j])  # per-pair call as in d_vector.py:315-318
+        n += 64
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "pair-scores/s", "cores": 1, "kind": "reference",
+            "sample": "scipy.spatial.distance.cosine per pair (the reference's own call, d_vector.py:317), d=%d, %.1f s" % (d, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
+    ap.add_argument("--seconds", type=float, default=3.0)
+    ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused fast kernel")
+    ap.add_argument("--stages", default="mfcc,gmm,cosine")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import speech_signal_processing_amd as pkg
+    from speech_signal_processing_amd import api
+    from speech_signal_processing_amd.dist import all_gather_rows, max_over_ranks
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    stages = set(args.stages.split(","))
+    fs = 16000
+    n_samp = int(round(args.seconds * fs))
+    n_utt = args.utts
+    ctx = api.Context.for_torch(local_rank)
+
+    # ------------------------------------------------------------------ data: resident in HBM before timing
+    audio = synth_audio_device(torch, n_utt, n_samp, fs, seed=1234 + rank, device=device)
+    tables = pkg.preset_sidekit(fs=fs, delta_order=2, cmvn=0)
+    plan = api.MfccPlan(ctx, tables)
+    seg = api.Segments.from_lengths(ctx, np.full(n_utt, n_samp, dtype=np.int64))
+    fseg = plan.frame_segments(seg)
+    n_frames = fseg.total
+    feats = torch.empty((n_frames, plan.d_out), dtype=torch.float32, device=device)
+    flat = audio.view(-1)
+
+    # ------------------------------------------------------------------ MFCC: the timed region
+    for _ in range(args.warmup):
+        plan.run(flat, seg, fseg, out=feats, variant=args.variant)
+    kernel_ms = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, ms = plan.run(flat, seg, fseg, out=feats, variant=args.variant, timing=True)
+        kernel_ms.append(ms)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    total_frames = n_frames * world * args.steps
+    value = total_frames / elapsed
+    ms_kernel = float(np.mean(kernel_ms))
+    bytes_per_frame = tables.cfg.hop * 4 + plan.d_out * 4            # 160*4 read + 39*4 written
+    algo_bytes = n_utt * n_samp * 4 + n_frames * plan.d_out * 4      # exact per launch: every sample read once, every feature written once
+    achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "mfcc_hbm_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    result = {
+        "metric": "MFCC frames/s (fused framing+preemph+window+rFFT+mel+log+DCT+delta+delta-delta, 39-d)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: %d x %.0f s synthetic 16 kHz utterances per GPU, 39-dim MFCC (+delta+delta-delta), "
+                               "win 400 / hop 160 / nfft 512, 24 mel filters" % (n_utt, args.seconds),
+                   "utterances_per_gpu": n_utt, "frames_per_gpu": n_frames, "d_out": plan.d_out,
+                   "kernel_variant": args.variant, "parallelism": "utterance-sharded x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "mfcc fused pass", "kernel_ms": ms_kernel, "algorithmic_bytes_per_launch": algo_bytes,
+                     "bytes_per_frame": bytes_per_frame},
+    }
+
+    # ------------------------------------------------------------------ GMM-UBM scoring stage (configs[2])
+    if "gmm" in stages:
+        K, S, D = 64, 50, plan.d_out
+        rng = np.random.default_rng(7)
+        sub = feats[:: max(1, n_frames // 200000)]
+        mean = sub.mean(0).double().cpu().numpy()
+        std = sub.std(0).double().cpu().numpy()
+        wts = rng.dirichlet(5 * np.ones(K))
+        mu = mean + std * rng.standard_normal((K, D))
+        cov = (std ** 2) * rng.uniform(0.5, 2.0, (K, D))
+        mus = np.stack([mu] + [mu + 0.3 * std * rng.standard_normal((K, D)) for _ in range(S)])
+        scorer = api.GmmScorer(ctx, np.stack([wts] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
+        g_steps = max(2, min(args.steps, 5))
+        r = scorer.score(feats, fseg)  # warm-up (allocates the per-frame scratch)
+        gms = []
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(g_steps):
+            r = scorer.score(feats, fseg, timing=True)
+            gms.append(r["kernel_ms"])
+            decisions = torch.stack([r["argmax"].to(torch.float32), r["scores"][:, 0]], dim=1)
+            gathered = all_gather_rows(decisions)  # RCCL all-gather of the compact per-utterance result
+        torch.cuda.synchronize()
+        barrier()
+        g_elapsed = max_over_ranks(time.perf_counter() - t0, device)
+        fscores = n_frames * (S + 1) * world * g_steps
+        flop = 4.0 * D * K * n_frames * (S + 1)
+        g_ms = float(np.mean(gms))
+        result["gmm"] = {
+            "metric": "GMM frame-scores/s (diag, K=%d, D=%d, %d models)" % (K, D, S + 1),
+            "value": fscores / g_elapsed, "unit": "frame-scores/s", "ms_per_step": g_elapsed / g_steps * 1e3,
+            "steps": g_steps, "dtype": "f32", "gathered_rows": int(gathered.shape[0]),
+            "config": {"workload": "configs[2]: the MFCC stream above vs 64-mix diag UBM + 50 speaker GMMs"},
+            "roofline": {"bound": "mfma", "achieved": flop / (g_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": flop / (g_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                         "kernel": "gmm_loglik + utt_reduce", "kernel_ms": g_ms, "algorithmic_flop_per_launch": flop},
+        }
+        del scorer, r
+
+    # ------------------------------------------------------------------ cosine stage (configs[4])
+    if "cosine" in stages:
+        N, S, d = 1000000, 1251, 256
+        gen = torch.Generator(device=device)
+        gen.manual_seed(11 + rank)
+        Cn = torch.randn((S, d), generator=gen, device=device)
+        lab = torch.randint(0, S, (N,), generator=gen, device=device)
+        X = Cn[lab] + 0.7 * torch.randn((N, d), generator=gen, device=device)
+        rc = api.cosine_identify(ctx, X, Cn)
+        c_steps = max(2, min(args.steps, 5))
+        cms = []
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(c_steps):
+            rc = api.cosine_identify(ctx, X, Cn, timing=True)
+            cms.append(rc["kernel_ms"])
+        torch.cuda.synchronize()
+        barrier()
+        c_elapsed = max_over_ranks(time.perf_counter() - t0, device)
+        acc = float((rc["argmin"].long() == lab).float().mean().item())
+        c_ms = float(np.mean(cms))
+        flop = 2.0 * d * N * S
+        result["cosine"] = {
+            "metric": "cosine pair-scores/s (N=1e6, S=1251, d=256)", "value": N * S * world * c_steps / c_elapsed,
+            "unit": "pair-scores/s", "ms_per_step": c_elapsed / c_steps * 1e3, "steps": c_steps, "dtype": "f32",
+            "argmin_accuracy": acc,
+            "roofline": {"bound": "mfma", "achieved": flop / (c_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flop / (c_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "cosine_kernel",
+                         "kernel_ms": c_ms, "algorithmic_flop_per_launch": flop},
+        }
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_mfcc(2000, n_samp, fs)
+        if "gmm" in result:
+            result["gmm"]["cpu_baseline"] = cpu_baseline_gmm(plan.d_out, 64, 51)
+        if "cosine" in result:
+            result["cosine"]["cpu_baseline"] = cpu_baseline_cosine(256, 1251)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

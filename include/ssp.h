@@ -74,9 +74,9 @@ int ssp_abi_version(void);
 const char* ssp_last_error(void);
 
 /* ---- context: device + stream ------------------------------------------------------- */
-/* stream: nullable hipStream_t borrowed from the caller (e.g. torch's current stream);
- * NULL = the library creates and owns one. */
-int ssp_ctx_create(int device, void* stream, ssp_ctx** out);
+/* borrow_stream != 0: `stream` is the caller's hipStream_t (e.g. torch's current stream; NULL = the HIP default
+ * stream) and all work is enqueued on it;  borrow_stream == 0: the library creates and owns a stream. */
+int ssp_ctx_create(int device, void* stream, int borrow_stream, ssp_ctx** out);
 int ssp_ctx_destroy(ssp_ctx* ctx);
 int ssp_ctx_sync(ssp_ctx* ctx);
 

@@ -36,7 +36,7 @@ _MSP = C.POINTER(C.c_float)
 SIGNATURES = {
     "ssp_abi_version": (C.c_int, []),
     "ssp_last_error": (C.c_char_p, []),
-    "ssp_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "ssp_ctx_create": (C.c_int, [C.c_int, _P, C.c_int, C.POINTER(_P)]),
     "ssp_ctx_destroy": (C.c_int, [_P]),
     "ssp_ctx_sync": (C.c_int, [_P]),
     "ssp_segments_create": (C.c_int, [_P, _I64P, C.c_int64, C.POINTER(_P)]),
@@ -69,6 +69,10 @@ def load():
         raise ImportError(
             "libsspgpu.so is missing (%s). Build it with `python -m speech_signal_processing_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64 and whichever
+    # copy initialises first owns the device, the other then reports "no ROCm-capable device".  Importing torch first
+    # makes the dynamic loader resolve libsspgpu.so's NEEDED libamdhip64.so.7 (same SONAME) to torch's copy.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

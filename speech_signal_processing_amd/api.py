@@ -34,12 +34,12 @@ def _as_f32(x, name):
 
 class Context:
     """One HIP device + one stream (ssp_ctx).  stream=None: the library owns a stream; an int is a borrowed
-    hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+    hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; 0 = the HIP default stream)."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         self._lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(self._lib.ssp_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        _lib.check(self._lib.ssp_ctx_create(int(device), C.c_void_p(stream or 0), 0 if stream is None else 1, C.byref(h)))
         self._h = h
         self.device = int(device)
         self.stream = stream

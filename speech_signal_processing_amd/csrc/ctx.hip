@@ -55,7 +55,7 @@ int ssp_abi_version(void) { return SSP_ABI_VERSION; }
 
 const char* ssp_last_error(void) { return ssp::g_err; }
 
-int ssp_ctx_create(int device, void* stream, ssp_ctx** out) {
+int ssp_ctx_create(int device, void* stream, int borrow_stream, ssp_ctx** out) {
     if (!out) SSP_FAIL(SSP_ERR_INVALID, "ssp_ctx_create: null out");
     *out = nullptr;
     int n = 0;
@@ -71,7 +71,7 @@ int ssp_ctx_create(int device, void* stream, ssp_ctx** out) {
     if (!c) SSP_FAIL(SSP_ERR_NOMEM, "ctx: host alloc");
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
-    if (stream) {
+    if (borrow_stream) {
         c->stream = static_cast<hipStream_t>(stream);
         c->owns_stream = false;
     } else {
