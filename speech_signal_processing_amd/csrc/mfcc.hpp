@@ -34,11 +34,27 @@ struct MfccArgs {
     int32_t lds_logmel_off, lds_ceps_off, lds_dlt_off, lds_ddl_off, lds_lmrows_off, lds_stats_off;
 };
 
+constexpr int MFCC_FAST_MAX_PASS = 4;  // <= 64 filters in the fused n_fft == 512 kernel
+
+// extra tables / LDS carve of the fused n_fft == 512 kernel (mfcc_fast.hip)
+struct FastArgs {
+    const float2* tw16;     // [16][16]  W_256^(k1*n2)
+    const float2* wpost;    // [9][16]   W_512^k, k = 8p + i (i < 8); row 8: k = 128
+    const float* melw;      // [total_steps][16]
+    const int32_t* mel_lo;  // [n_pass*16]
+    const int32_t* mel_id;  // [n_pass*16] filter id, -1 = empty slot
+    const float* dctT;      // [n_filt][q_pass*16]
+    int32_t mel_steps[MFCC_FAST_MAX_PASS];
+    int32_t n_pass, q_pass, total_steps;
+    int32_t slen;           // staged samples per quad = 3*hop + 32*NZ
+    int32_t stage_floats;   // per-wave stage buffer (>= slen, >= 4*PSTR)
+    int32_t ceps_rows;      // capacity of the cepstra buffer (rows)
+    int32_t off_win, off_tw16, off_wpost, off_melw, off_mello, off_melid, off_dct, off_ceps, off_stats, off_wave, wave_bytes;
+    float pscale;           // 0.25 * spec_scale (power) or 0.5 * spec_scale (magnitude)
+    float one_minus_a;
+};
+
 int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, hipStream_t stream);
-// fused n_fft == 512 throughput kernel (mfcc_fast.hip); returns SSP_ERR_UNSUPPORTED when the cfg is not covered
-bool mfcc_fast_supported(const ssp_mfcc_cfg& cfg);
-int launch_mfcc_fast(const MfccArgs& args, const ssp_mfcc_cfg& cfg, int n_chunks, int chunk_frames, int num_cu,
-                     hipStream_t stream);
 
 }  // namespace ssp
 
@@ -57,4 +73,15 @@ struct ssp_mfcc_plan {
     int32_t cache_n_chunks = 0;
     ssp::DevBuf chunks;
     ssp::MfccArgs args{};
+    // fused n_fft == 512 kernel
+    bool fast_ready = false;
+    ssp::FastArgs fast{};
+    ssp::DevBuf f_tw16, f_wpost, f_melw, f_mello, f_melid, f_dct;
 };
+
+namespace ssp {
+bool mfcc_fast_supported(const ssp_mfcc_cfg& cfg);
+int build_fast_tables(ssp_mfcc_plan* plan);
+size_t mfcc_fast_lds(const ssp_mfcc_cfg& cfg, FastArgs& f, int chunk_frames);
+int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, int chunk_frames, hipStream_t stream);
+}  // namespace ssp

@@ -1,12 +1,487 @@
-// Fused n_fft == 512 throughput kernel (placeholder until the register-resident FFT kernel lands).
+// mfcc_fused512_kernel — the throughput kernel of the fused MFCC pass for n_fft == 512 (sidekit and in-repo dialects).
+//
+// Work decomposition (CDNA4, 64-wide waves):
+//   workgroup (256 threads = 4 waves)  = one chunk of frames of ONE utterance (normally the whole utterance)
+//   wave                               = 4 frames at a time ("quad"), 16 lanes per frame
+//   lane                               = 16 complex points of the 256-point complex FFT that carries the 512-point real FFT
+//
+// Per quad, per wave (no workgroup barrier inside the loop; every LDS region below is wave-private):
+//   1. the wave's 3*hop + 32*NZ samples stream HBM -> registers (prefetched one quad ahead, 16-B loads) -> pre-emphasis
+//      -> LDS stage (each sample is written once and read by the 2.5 frames that overlap it)
+//   2. lane n2 of a frame gathers z[n1] = (y[32 n1 + 2 n2], y[32 n1 + 2 n2 + 1]) * window     (n1 = 0..NZ-1, rest zero)
+//   3. radix-16 FFT over n1 in registers, twiddle W_256^(n2 k1)
+//   4. 16x16 transpose through LDS (144-B padded rows: conflict-free ds_write_b64 / ds_read_b128)
+//   5. radix-16 FFT over n2 in registers -> Z[k1 + 16 k2]
+//   6. Z goes back to LDS in natural order; lane p then owns the bin pairs k = 8p..8p+7 <-> 256-k, forms
+//      X[k], X[256-k] of the REAL spectrum (split step) and the power / magnitude, written to a per-frame P row
+//   7. banded filterbank: lane = filter (slots sorted by band length), log
+//   8. DCT rows: lane = cepstral index; cepstra go to the workgroup's LDS buffer
+// After the loop one barrier, then delta / delta-delta (recomputed on the fly from the cepstra in LDS), optional
+// per-utterance CMVN and ONE coalesced write of the (frames x d_out) block.  HBM sees every sample once and every
+// output feature once.
+#include <algorithm>
+#include <cmath>
+
 #include "mfcc.hpp"
 
 namespace ssp {
 
-bool mfcc_fast_supported(const ssp_mfcc_cfg&) { return false; }
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-int launch_mfcc_fast(const MfccArgs&, const ssp_mfcc_cfg&, int, int, int, hipStream_t) {
-    SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc fast kernel not built");
+constexpr int ZROW = 144;             // bytes per 16-complex row of the transpose / Z image (128 + 16 pad)
+constexpr int ZFRAME = 16 * ZROW;     // 2304 B per frame (multiple of 256 B: keeps the 4 frames bank-aligned)
+constexpr int PSTR = 260;             // floats per frame of the P (power spectrum) row: 257 bins + pad
+constexpr int LMSTR = 64;             // floats per frame of the log-mel row
+constexpr int MAX_PASS = MFCC_FAST_MAX_PASS;
+
+__device__ __forceinline__ v2f mul_neg_i(v2f z) { return v2f{z.y, -z.x}; }
+__device__ __forceinline__ v2f cmul(v2f z, v2f w) { return v2f{z.x * w.x - z.y * w.y, z.x * w.y + z.y * w.x}; }
+__device__ __forceinline__ v2f cmulc(v2f z, float c, float s) { return v2f{z.x * c - z.y * s, z.x * s + z.y * c}; }
+
+__device__ __forceinline__ void dft4(v2f& a, v2f& b, v2f& c, v2f& d) {
+    const v2f t0 = a + c, t1 = a - c, t2 = b + d, t3 = mul_neg_i(b - d);
+    a = t0 + t2;
+    b = t1 + t3;
+    c = t0 - t2;
+    d = t1 - t3;
+}
+
+// forward 16-point DFT, natural order in, natural order out (4 x 4 Cooley-Tukey, constant twiddles)
+__device__ __forceinline__ void fft16(v2f (&z)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4(z[n2], z[n2 + 4], z[n2 + 8], z[n2 + 12]);  // -> a[k1][n2] at z[n2 + 4 k1]
+    // twiddle W16^(n2 k1)
+    z[5] = cmulc(z[5], C1, -S1);                  // n2=1,k1=1: W^1
+    z[6] = cmulc(z[6], R, -R);                    // n2=2,k1=1: W^2
+    z[7] = cmulc(z[7], S1, -C1);                  // n2=3,k1=1: W^3
+    z[9] = cmulc(z[9], R, -R);                    // n2=1,k1=2: W^2
+    z[10] = mul_neg_i(z[10]);                     // n2=2,k1=2: W^4 = -i
+    z[11] = cmulc(z[11], -R, -R);                 // n2=3,k1=2: W^6
+    z[13] = cmulc(z[13], S1, -C1);                // n2=1,k1=3: W^3
+    z[14] = cmulc(z[14], -R, -R);                 // n2=2,k1=3: W^6
+    z[15] = cmulc(z[15], -C1, S1);                // n2=3,k1=3: W^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4(z[4 * k1], z[4 * k1 + 1], z[4 * k1 + 2], z[4 * k1 + 3]);  // -> X[k1 + 4 k2] at z[4 k1 + k2]
+    v2f o[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) o[k1 + 4 * k2] = z[4 * k1 + k2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = o[i];
+}
+
+struct __attribute__((packed, aligned(4))) f4u {
+    float x, y, z, w;
+};
+
+__device__ __forceinline__ float fast_log(const MfccArgs& a, float v) {
+    if (a.floor_mode == 1) v += a.eps;
+    else if (a.floor_mode == 2) v = fmaxf(v, a.eps);
+    if (a.log_mode == 0) return logf(v);
+    if (a.log_mode == 1) return log10f(v);
+    return 10.0f * log10f(v);
+}
+
+constexpr int NCH = 5;  // 256-float chunks per quad stage: slen <= 3*256 + 512 = 1280
+
+template <int NZ>
+__global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int nc = a.n_ceps;
+
+    float* s_win = reinterpret_cast<float*>(smem + f.off_win);
+    v2f* s_tw16 = reinterpret_cast<v2f*>(smem + f.off_tw16);
+    v2f* s_wpost = reinterpret_cast<v2f*>(smem + f.off_wpost);
+    float* s_melw = reinterpret_cast<float*>(smem + f.off_melw);
+    int* s_mello = reinterpret_cast<int*>(smem + f.off_mello);
+    int* s_melid = reinterpret_cast<int*>(smem + f.off_melid);
+    float* s_dct = reinterpret_cast<float*>(smem + f.off_dct);
+    float* s_ceps = reinterpret_cast<float*>(smem + f.off_ceps);
+    float* s_stats = reinterpret_cast<float*>(smem + f.off_stats);
+    char* wbase = smem + f.off_wave + wave * f.wave_bytes;
+    float* stage = reinterpret_cast<float*>(wbase);
+    char* zbuf = wbase + f.stage_floats * 4;
+    float* lmrow = reinterpret_cast<float*>(zbuf + 4 * ZFRAME);
+
+    // ---- shared tables -> LDS
+    for (int i = tid; i < 512; i += 256) s_win[i] = a.window[i];
+    for (int i = tid; i < 256; i += 256) s_tw16[i] = *reinterpret_cast<const v2f*>(&f.tw16[i]);
+    for (int i = tid; i < 144; i += 256) s_wpost[i] = *reinterpret_cast<const v2f*>(&f.wpost[i]);
+    for (int i = tid; i < f.total_steps * 16; i += 256) s_melw[i] = f.melw[i];
+    for (int i = tid; i < f.n_pass * 16; i += 256) {
+        s_mello[i] = f.mel_lo[i];
+        s_melid[i] = f.mel_id[i];
+    }
+    for (int i = tid; i < a.n_filt * f.q_pass * 16; i += 256) s_dct[i] = f.dctT[i];
+    __syncthreads();
+
+    const MfccChunk ch = a.chunks[blockIdx.x];
+    const int64_t s0 = a.sample_off[ch.utt];
+    const int64_t N = a.sample_off[ch.utt + 1] - s0;
+    const int64_t f0 = a.frame_off[ch.utt];
+    const int T = (int)(a.frame_off[ch.utt + 1] - f0);
+    const float* __restrict__ x = a.samples + s0;
+    const int t0 = ch.t0, n = ch.n;
+    const int H = a.delta_order * a.delta_N;
+    const int ta = max(t0 - H, 0), tb = min(t0 + n + H, T);
+    const int hop = a.hop;
+    const float pre = a.preemph_mode ? a.preemph : 0.f;
+    const int nquads = (tb - ta + 3) >> 2;
+
+    // ---- software prefetch of a quad's samples: HBM -> registers
+    float4 pf[NCH];
+    float pfprev[NCH];
+    float pfx0 = 0.f;
+    auto prefetch = [&](int q) {
+        const int64_t sq = (int64_t)(ta + 4 * q) * hop;  // first sample of the quad inside the utterance
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int e0 = c * 256 + lane * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e0 < f.slen) {
+                const int64_t i0 = sq + e0;
+                if (i0 + 3 < N) {
+                    const f4u u = *reinterpret_cast<const f4u*>(x + i0);
+                    v = make_float4(u.x, u.y, u.z, u.w);
+                } else {
+                    if (i0 < N) v.x = x[i0];
+                    if (i0 + 1 < N) v.y = x[i0 + 1];
+                    if (i0 + 2 < N) v.z = x[i0 + 2];
+                }
+            }
+            pf[c] = v;
+            float p = __shfl_up(v.w, 1);
+            if (lane == 0) {
+                const int64_t ip = sq + c * 256 - 1;
+                p = (ip >= 0 && ip < N && c * 256 < f.slen) ? x[ip] : 0.f;
+            }
+            pfprev[c] = p;
+        }
+        const int64_t ix = (int64_t)(ta + 4 * q + g) * hop;
+        pfx0 = (j == 0 && ix < N) ? x[ix] : 0.f;
+    };
+
+    if (wave < nquads) prefetch(wave);
+    for (int q = wave; q < nquads; q += 4) {
+        const int t = ta + 4 * q + g;  // this lane group's frame
+        // ---- 1. pre-emphasis + stage to LDS (the previous quad's P rows in this buffer are dead by now)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int e0 = c * 256 + lane * 4;
+            if (e0 < f.stage_floats) {
+                const float4 v = pf[c];
+                v4f y;
+                y.x = v.x - pre * pfprev[c];
+                y.y = v.y - pre * v.x;
+                y.z = v.z - pre * v.y;
+                y.w = v.w - pre * v.z;
+                *reinterpret_cast<v4f*>(stage + e0) = y;
+            }
+        }
+        const float x0 = pfx0;
+        // ---- 2. gather + window
+        v2f z[16];
+        {
+            const float* sp = stage + g * hop + 2 * j;
+            const float* wp = s_win + 2 * j;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                if (n1 < NZ) {
+                    const v2f s = *reinterpret_cast<const v2f*>(sp + 32 * n1);
+                    const v2f w = *reinterpret_cast<const v2f*>(wp + 32 * n1);
+                    z[n1] = s * w;
+                } else {
+                    z[n1] = v2f{0.f, 0.f};
+                }
+            }
+            if (a.preemph_mode && j == 0) z[0].x = f.one_minus_a * x0 * s_win[0];  // y[0] = x[0] - a x[0]
+        }
+        if (q + 4 < nquads) prefetch(q + 4);  // next quad's loads fly under the FFT
+        // ---- 3. FFT16 over n1, twiddle W_256^(n2 k1)
+        fft16(z);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], s_tw16[k1 * 16 + j]);
+        // ---- 4. transpose through LDS
+        char* zf = zbuf + g * ZFRAME;
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) *reinterpret_cast<v2f*>(zf + k1 * ZROW + j * 8) = z[k1];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v4f r = *reinterpret_cast<const v4f*>(zf + j * ZROW + c * 16);
+            z[2 * c] = v2f{r.x, r.y};
+            z[2 * c + 1] = v2f{r.z, r.w};
+        }
+        // ---- 5. FFT16 over n2: lane j = k1, register = k2
+        fft16(z);
+        // ---- 6. Z natural order -> LDS, split step on bin pairs, power / magnitude -> P row
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<v2f*>(zf + k2 * ZROW + j * 8) = z[k2];
+        {
+            float* P = stage + g * PSTR;
+            v2f lo[8], hi[9];
+            const char* plo = zf + (j >> 1) * ZROW + (j & 1) * 64;  // bins 8j .. 8j+7
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const v4f r = *reinterpret_cast<const v4f*>(plo + c * 16);
+                lo[2 * c] = v2f{r.x, r.y};
+                lo[2 * c + 1] = v2f{r.z, r.w};
+            }
+            const int mb = 248 - 8 * j;  // aligned block [mb, mb+8); element mb+8 = 256-8j (wraps to 0 for j = 0)
+            const char* phi = zf + (mb >> 4) * ZROW + (mb & 15) * 8;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const v4f r = *reinterpret_cast<const v4f*>(phi + c * 16);
+                hi[2 * c] = v2f{r.x, r.y};
+                hi[2 * c + 1] = v2f{r.z, r.w};
+            }
+            const int me = (256 - 8 * j) & 255;
+            hi[8] = *reinterpret_cast<const v2f*>(zf + (me >> 4) * ZROW + (me & 15) * 8);
+            const v2f z128 = *reinterpret_cast<const v2f*>(zf + 8 * ZROW);  // bin 128 (self pair, lane 15 keeps it)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const v2f zk = i < 8 ? lo[i] : z128;
+                const v2f zm = i < 8 ? hi[8 - i] : z128;  // Z[256 - k]
+                const v2f w = s_wpost[i * 16 + j];
+                const v2f e = v2f{zk.x + zm.x, zk.y - zm.y};      // 2E = Z[k] + conj Z[256-k]
+                const v2f d = v2f{zk.x - zm.x, zk.y + zm.y};      // 2D = Z[k] - conj Z[256-k]
+                const v2f o = cmul(v2f{d.y, -d.x}, w);            // 2 (-i D) W^k
+                const v2f xa = e + o, xb = e - o;
+                float pa = xa.x * xa.x + xa.y * xa.y;
+                float pb = xb.x * xb.x + xb.y * xb.y;
+                if (a.spec_power == 1) {
+                    pa = sqrtf(pa);
+                    pb = sqrtf(pb);
+                }
+                pa *= f.pscale;
+                pb *= f.pscale;
+                if (i < 8) {
+                    P[8 * j + i] = pa;
+                    P[256 - 8 * j - i] = pb;
+                } else if (j == 15) {
+                    P[128] = pa;
+                }
+            }
+        }
+        // ---- 7. banded filterbank + log: lane = filter slot
+        {
+            const float* P = stage + g * PSTR;
+            float* lm = lmrow + g * LMSTR;
+            int wofs = 0;
+            for (int pass = 0; pass < f.n_pass; ++pass) {
+                const int steps = f.mel_steps[pass];
+                const int lo = s_mello[pass * 16 + j];
+                const int id = s_melid[pass * 16 + j];
+                const float* pp = P + lo;
+                const float* ww = s_melw + wofs * 16 + j;
+                float acc = 0.f;
+                for (int s = 0; s < steps; ++s) acc = fmaf(pp[s], ww[s * 16], acc);
+                if (id >= 0) lm[id] = fast_log(a, acc);
+                wofs += steps;
+            }
+        }
+        // ---- 8. DCT rows: lane = cepstral index
+        {
+            const float* lm = lmrow + g * LMSTR;
+            const int qs = f.q_pass * 16;
+            for (int qp = 0; qp < f.q_pass; ++qp) {
+                const int qq = qp * 16 + j;
+                float acc = 0.f;
+                for (int jf = 0; jf < a.n_filt; ++jf) acc = fmaf(lm[jf], s_dct[jf * qs + qq], acc);
+                if (qq < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + qq] = acc;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- delta / delta-delta on the fly from the cepstra (edge padding at utterance ends, GMM_UBM.py:64)
+    const int Nd = a.delta_N;
+    const float inv = a.delta_inv_denom;
+    const int D = a.d_out;
+    auto cep = [&](int u, int qq) -> float { return s_ceps[(size_t)(u - ta) * nc + qq]; };
+    auto dl = [&](int u, int qq) -> float {
+        float acc = 0.f;
+        for (int m = 1; m <= Nd; ++m) acc += (float)m * (cep(min(u + m, T - 1), qq) - cep(max(u - m, 0), qq));
+        return acc * inv;
+    };
+    auto value = [&](int r, int d) -> float {
+        const int blk = d / nc, qq = d - blk * nc;
+        const int u = t0 + r;
+        if (blk == 0) return cep(u, qq);
+        if (blk == 1) return dl(u, qq);
+        float acc = 0.f;
+        for (int m = 1; m <= Nd; ++m) acc += (float)m * (dl(min(u + m, T - 1), qq) - dl(max(u - m, 0), qq));
+        return acc * inv;
+    };
+    if (a.cmvn) {
+        for (int d = wave; d < D; d += 4) {
+            float s = 0.f;
+            for (int r = lane; r < n; r += 64) s += value(r, d);
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s / (float)n;
+            float v = 0.f;
+            for (int r = lane; r < n; r += 64) {
+                const float e = value(r, d) - mean;
+                v = fmaf(e, e, v);
+            }
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            float sd = sqrtf(v / (float)n);
+            if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;
+            if (lane == 0) {
+                s_stats[d] = mean;
+                s_stats[D + d] = 1.0f / sd;
+            }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ out = a.out + (size_t)(f0 + t0) * D;
+    for (int i = tid; i < n * D; i += 256) {
+        const int r = i / D, d = i - r * D;
+        float v = value(r, d);
+        if (a.cmvn) v = (v - s_stats[d]) * s_stats[D + d];
+        out[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool mfcc_fast_supported(const ssp_mfcc_cfg& c) {
+    return c.n_fft == 512 && c.hop >= 2 && c.hop <= 256 && (c.hop & 1) == 0 && c.n_filt <= 64 && c.n_ceps <= 64 &&
+           c.frame_mode != 2 && c.top_db < 0.f && (c.delta_order == 0 || c.delta_N <= 4);
+}
+
+int build_fast_tables(ssp_mfcc_plan* p) {
+    const ssp_mfcc_cfg& c = p->cfg;
+    const int nb = 257;
+    std::vector<float2> tw16(256), wpost(144);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const double ang = -2.0 * M_PI * (double)(k1 * n2) / 256.0;
+            tw16[k1 * 16 + n2] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+    for (int i = 0; i < 9; ++i)
+        for (int pl = 0; pl < 16; ++pl) {
+            const int k = i < 8 ? 8 * pl + i : 128;
+            const double ang = -2.0 * M_PI * (double)k / 512.0;
+            wpost[i * 16 + pl] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+    // banded filters sorted by band length (descending) into slots of 16 lanes
+    std::vector<int32_t> lo(c.n_filt), len(c.n_filt), order(c.n_filt);
+    std::vector<float> dense((size_t)c.n_filt * nb);
+    SSP_HIP(hipMemcpy(dense.data(), p->fbank_dense.p, dense.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int jf = 0; jf < c.n_filt; ++jf) {
+        int first = -1, last = -1;
+        for (int k = 0; k < nb; ++k)
+            if (dense[(size_t)jf * nb + k] != 0.f) {
+                if (first < 0) first = k;
+                last = k;
+            }
+        lo[jf] = first < 0 ? 0 : first;
+        len[jf] = first < 0 ? 0 : last - first + 1;
+        order[jf] = jf;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len[x] > len[y]; });
+    const int n_pass = (c.n_filt + 15) / 16;
+    FastArgs& f = p->fast;
+    std::vector<int32_t> mel_lo(n_pass * 16, 0), mel_id(n_pass * 16, -1);
+    std::vector<float> melw;
+    int total = 0;
+    for (int ps = 0; ps < n_pass; ++ps) {
+        int steps = 0;
+        for (int l = 0; l < 16; ++l) {
+            const int s = ps * 16 + l;
+            if (s < c.n_filt) steps = std::max(steps, len[order[s]]);
+        }
+        f.mel_steps[ps] = steps;
+        melw.resize((size_t)(total + steps) * 16, 0.f);
+        for (int l = 0; l < 16; ++l) {
+            const int s = ps * 16 + l;
+            if (s >= c.n_filt) continue;
+            const int jf = order[s];
+            mel_id[s] = jf;
+            // keep lo + steps inside the P row (257 bins + pad): shift the band start down when needed
+            int start = lo[jf];
+            if (start + steps > PSTR) start = PSTR - steps;
+            mel_lo[s] = start;
+            for (int k = 0; k < len[jf]; ++k) melw[(size_t)(total + (lo[jf] - start) + k) * 16 + l] = dense[(size_t)jf * nb + lo[jf] + k];
+        }
+        total += steps;
+    }
+    for (int ps = n_pass; ps < MAX_PASS; ++ps) f.mel_steps[ps] = 0;
+    const int q_pass = (c.n_ceps + 15) / 16;
+    std::vector<float> dctT((size_t)c.n_filt * q_pass * 16, 0.f), dcth((size_t)c.n_ceps * c.n_filt);
+    SSP_HIP(hipMemcpy(dcth.data(), p->dct.p, dcth.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int q = 0; q < c.n_ceps; ++q)
+        for (int jf = 0; jf < c.n_filt; ++jf) dctT[(size_t)jf * q_pass * 16 + q] = dcth[(size_t)q * c.n_filt + jf];
+
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        SSP_TRY(b.alloc(bytes));
+        if (bytes) SSP_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        return SSP_OK;
+    };
+    SSP_TRY(up(p->f_tw16, tw16.data(), tw16.size() * sizeof(float2)));
+    SSP_TRY(up(p->f_wpost, wpost.data(), wpost.size() * sizeof(float2)));
+    SSP_TRY(up(p->f_melw, melw.data(), melw.size() * sizeof(float)));
+    SSP_TRY(up(p->f_mello, mel_lo.data(), mel_lo.size() * sizeof(int32_t)));
+    SSP_TRY(up(p->f_melid, mel_id.data(), mel_id.size() * sizeof(int32_t)));
+    SSP_TRY(up(p->f_dct, dctT.data(), dctT.size() * sizeof(float)));
+    f.tw16 = p->f_tw16.as<float2>();
+    f.wpost = p->f_wpost.as<float2>();
+    f.melw = p->f_melw.as<float>();
+    f.mel_lo = p->f_mello.as<int32_t>();
+    f.mel_id = p->f_melid.as<int32_t>();
+    f.dctT = p->f_dct.as<float>();
+    f.n_pass = n_pass;
+    f.q_pass = q_pass;
+    f.total_steps = total;
+    const int NZ = c.win_len <= 416 ? 13 : 16;
+    f.slen = 3 * c.hop + 32 * NZ;
+    f.stage_floats = (std::max(f.slen, 4 * PSTR) + 3) & ~3;
+    f.pscale = (c.spec_power == 2 ? 0.25f : 0.5f) * c.spec_scale;
+    f.one_minus_a = 1.0f - c.preemph;
+    p->fast_ready = true;
+    return SSP_OK;
+}
+
+static size_t al16(size_t x) { return (x + 15) & ~size_t(15); }
+
+// LDS carve for chunks of `ch` frames; returns total bytes
+size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
+    const int H = c.delta_order * c.delta_N;
+    size_t off = 0;
+    f.off_win = (int32_t)off;    off = al16(off + 512 * 4);
+    f.off_tw16 = (int32_t)off;   off = al16(off + 256 * 8);
+    f.off_wpost = (int32_t)off;  off = al16(off + 144 * 8);
+    f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 16 * 4);
+    f.off_mello = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
+    f.off_melid = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
+    f.off_dct = (int32_t)off;    off = al16(off + (size_t)c.n_filt * f.q_pass * 16 * 4);
+    f.ceps_rows = ch + 2 * H;
+    f.off_ceps = (int32_t)off;   off = al16(off + (size_t)f.ceps_rows * c.n_ceps * 4);
+    f.off_stats = (int32_t)off;  off = al16(off + (size_t)2 * c.n_ceps * (1 + c.delta_order) * 4);
+    off = (off + 255) & ~size_t(255);
+    f.off_wave = (int32_t)off;
+    f.wave_bytes = (int32_t)((al16((size_t)f.stage_floats * 4) + 4 * ZFRAME + 4 * LMSTR * 4 + 255) & ~size_t(255));
+    return off + 4 * (size_t)f.wave_bytes;
+}
+
+int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int chunk_frames, hipStream_t stream) {
+    if (n_chunks <= 0) return SSP_OK;
+    FastArgs f = p->fast;
+    const size_t lds = mfcc_fast_lds(p->cfg, f, chunk_frames);
+    if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
+    const bool nz13 = p->cfg.win_len <= 416;
+    const void* fn = nz13 ? reinterpret_cast<const void*>(mfcc_fused512_kernel<13>) : reinterpret_cast<const void*>(mfcc_fused512_kernel<16>);
+    if (lds > 64 * 1024) SSP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (nz13)
+        hipLaunchKernelGGL(mfcc_fused512_kernel<13>, dim3(n_chunks), dim3(256), lds, stream, args, f);
+    else
+        hipLaunchKernelGGL(mfcc_fused512_kernel<16>, dim3(n_chunks), dim3(256), lds, stream, args, f);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
 }
 
 }  // namespace ssp

@@ -70,9 +70,18 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     int ch;
     size_t lds = 0;
     if (variant == 2) {
-        ch = 0;  // decided by the fast kernel's own geometry (see mfcc_fast.hip); chunk = whole utterance capped
-        ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 1024);
-        if (whole && max_T > ch) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): cmvn needs utterances of <= %d frames", ch);
+        // whole utterance per workgroup while 2 workgroups still fit a CU's 160 KiB LDS; longer ones are chunked
+        FastArgs tmp = p->fast;
+        ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 4096);
+        while (ch > 64 && mfcc_fast_lds(c, tmp, ch) > 80 * 1024 && !whole) ch = (ch * 3) / 4;
+        if (whole) {
+            ch = (int)std::max<int64_t>(max_T, 1);
+            if (mfcc_fast_lds(c, tmp, ch) > lds_cap)
+                SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): cmvn needs a whole utterance per workgroup; %lld frames exceed the LDS",
+                         (long long)max_T);
+        }
+        lds = mfcc_fast_lds(c, tmp, ch);
+        if (lds > lds_cap) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
     } else {
         MfccArgs tmp{};
         ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
@@ -181,6 +190,7 @@ int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* win
         set_error("mfcc plan: table upload failed");
         rc = SSP_ERR_HIP;
     }
+    if (rc == SSP_OK && mfcc_fast_supported(*cfg)) rc = build_fast_tables(p);
     if (rc != SSP_OK) {
         delete p;
         return rc;
@@ -284,7 +294,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, s));
     if (v == 2)
-        SSP_TRY(launch_mfcc_fast(a, plan->cfg, plan->cache_n_chunks, plan->cache_chunk_frames, plan->ctx->num_cu, s));
+        SSP_TRY(launch_mfcc_fast(a, plan, plan->cache_n_chunks, plan->cache_chunk_frames, s));
     else
         SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, s));
     SSP_TRY(tm.stop(s, kernel_ms));

@@ -94,13 +94,15 @@ def _run_plan(api, tables, signals, variant=0, device=False):
     return [np.asarray(out[fseg.offsets[i]:fseg.offsets[i + 1]]) for i in range(len(signals))], fseg
 
 
+# variant 1 = generic table-driven kernel, variant 2 = fused n_fft == 512 throughput kernel
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("delta_order,cmvn", [(0, 0), (1, 0), (2, 0), (1, 1), (2, 1)])
-def test_sidekit_preset_vs_oracle(ssp, delta_order, cmvn):
+def test_sidekit_preset_vs_oracle(ssp, delta_order, cmvn, variant):
     pkg, api = ssp
     from oracle import ref_cpu as O
     sigs = [synth_audio(u, 48000 if u % 3 else 16000 + 37 * u, 16000) for u in range(24)]
     tables = pkg.preset_sidekit(delta_order=delta_order, cmvn=cmvn)
-    got, fseg = _run_plan(api, tables, sigs, variant=1)
+    got, fseg = _run_plan(api, tables, sigs, variant=variant)
     cfg, w, fb, dct = O.sidekit_tables(delta_order=delta_order, cmvn=cmvn)
     assert fseg.offsets[-1] == sum(O.num_frames(len(s), cfg) for s in sigs)
     for u, s in enumerate(sigs):
@@ -115,7 +117,8 @@ def test_sidekit_shape_fact(ssp):
     assert got[0].shape == (98, 13)
 
 
-def test_mfcc_edge_cases(ssp):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_mfcc_edge_cases(ssp, variant):
     """empty utterance, N < window, exactly one frame, ragged batch, silence (ln 0 = -inf like the reference)."""
     pkg, api = ssp
     from oracle import ref_cpu as O
@@ -123,7 +126,7 @@ def test_mfcc_edge_cases(ssp):
             synth_audio(5, 560, 16000), np.zeros(1000, np.float32), synth_audio(6, 16000, 16000)]
     for order in (0, 2):
         tables = pkg.preset_sidekit(delta_order=order)
-        got, fseg = _run_plan(api, tables, sigs, variant=1)
+        got, fseg = _run_plan(api, tables, sigs, variant=variant)
         cfg, w, fb, dct = O.sidekit_tables(delta_order=order)
         assert [g.shape[0] for g in got] == [0, 0, 1, 1, 2, 4, 98]
         for u, s in enumerate(sigs):
@@ -149,14 +152,49 @@ def test_librosa_preset_vs_oracle(ssp):
     assert_feat_close(MFCC_DTW.MFCC_lib(sigs[0]), O.librosa_mfcc_flat(sigs[0]), what="MFCC_lib")
 
 
-def test_device_pointer_path_matches_host_path(ssp):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_device_pointer_path_matches_host_path(ssp, variant):
     pkg, api = ssp
     sigs = [synth_audio(u, 16000 + 160 * u, 16000) for u in range(8)]
     tables = pkg.preset_sidekit(delta_order=2)
-    host, _ = _run_plan(api, tables, sigs, variant=1, device=False)
-    dev, _ = _run_plan(api, tables, sigs, variant=1, device=True)
+    host, _ = _run_plan(api, tables, sigs, variant=variant, device=False)
+    dev, _ = _run_plan(api, tables, sigs, variant=variant, device=True)
     for a, b in zip(host, dev):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("geom", [(8000, 512, 256), (16000, 512, 256), (16000, 512, 100), (16000, 480, 160)])
+def test_inrepo_dialect_both_kernels_vs_oracle(ssp, variant, geom):
+    """the in-repo dialect (magnitude spectrum, folded 40-filter bank, log10(.+1e-8), zero-padded tail) through both kernels;
+    frameSize 480 exercises win_len < n_fft is NOT this dialect (n_fft = frameSize) -> covered by table overrides below."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    fs, L, st = geom
+    if L != 512:
+        pytest.skip("in-repo dialect has n_fft == frameSize; non power-of-two sizes are unsupported on the GPU")
+    sigs = [synth_audio(u, 3000 + 777 * u, fs) for u in range(9)] + [synth_audio(20, 100, fs), np.zeros(700, np.float32)]
+    tables = pkg.preset_inrepo(fs, L, st, delta_order=2)
+    got, _ = _run_plan(api, tables, sigs, variant=variant)
+    cfg, w, fb, dct = O.inrepo_tables(fs, L, st)
+    cfg["delta_order"] = 2
+    for u, s in enumerate(sigs):
+        assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"inrepo {geom} utt {u} variant {variant}")
+
+
+def test_fast_kernel_long_utterance_chunking(ssp):
+    """utterances longer than one workgroup's LDS budget are cut into chunks with recomputed delta halos"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    sigs = [synth_audio(1, 16000 * 20 + 123, 16000), synth_audio(2, 16000 * 3, 16000)]
+    tables = pkg.preset_sidekit(delta_order=2)
+    got, _ = _run_plan(api, tables, sigs, variant=2)
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=2)
+    for u, s in enumerate(sigs):
+        assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"long utt {u}")
+    g1, _ = _run_plan(api, tables, sigs, variant=1)
+    for a, b in zip(got, g1):
+        assert_feat_close(a, b, tol=2e-5, what="fast vs generic")
 
 
 def test_scale_invariance_property(ssp):
