@@ -39,13 +39,14 @@ constexpr int MFCC_FAST_MAX_PASS = 4;  // <= 64 filters in the fused n_fft == 51
 // extra tables / LDS carve of the fused n_fft == 512 kernel (mfcc_fast.hip)
 struct FastArgs {
     const float2* tw16;     // [16][16]  W_256^(k1*n2)
-    const float2* wpost;    // [9][16]   W_512^k, k = 8p + i (i < 8); row 8: k = 128
+    const float2* wpost;    // [9][16]   W_512^k, k = 8p + 1 + i (i < 8); row 8 unused
     const float* melw;      // [total_steps][16]
     const int32_t* mel_lo;  // [n_pass*16]
     const int32_t* mel_id;  // [n_pass*16] filter id, -1 = empty slot
     const float* dctT;      // [n_filt][q_pass*16]
     int32_t mel_steps[MFCC_FAST_MAX_PASS];
-    int32_t n_pass, q_pass, total_steps;
+    int32_t n_pass, q_pass, total_steps, n_filt4;  // mel steps are 4-tap (16-byte) steps
+    float ddw[17];          // delta-delta of interior frames as one convolution over 4N+1 cepstra
     int32_t slen;           // staged samples per quad = 3*hop + 32*NZ
     int32_t stage_floats;   // per-wave stage buffer (>= slen, >= 4*PSTR)
     int32_t ceps_rows;      // capacity of the cepstra buffer (rows)

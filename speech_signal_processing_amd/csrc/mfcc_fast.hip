@@ -31,9 +31,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int ZROW = 144;             // bytes per 16-complex row of the transpose / Z image (128 + 16 pad)
 constexpr int ZFRAME = 16 * ZROW;     // 2304 B per frame (multiple of 256 B: keeps the 4 frames bank-aligned)
-constexpr int PSTR = 260;             // floats per frame of the P (power spectrum) row: 257 bins + pad
+constexpr int PSTR = 264;             // floats per frame of the P (power spectrum) row, storage order sigma(b) below
 constexpr int LMSTR = 64;             // floats per frame of the log-mel row
 constexpr int MAX_PASS = MFCC_FAST_MAX_PASS;
+constexpr int FAST_WAVES = 8;         // waves per workgroup (512 threads): 2 waves per SIMD with one workgroup per CU
+
+// storage index of spectrum bin b in a P row: one dummy slot between bins 128 and 129 (and three leading ones) makes
+// BOTH 8-bin runs a lane produces 16-byte aligned: low run k = 8j+1..8j+8 -> 8j+4.., high run 248-8j..255-8j -> 252-8j..
+__host__ __device__ constexpr int p_sigma(int b) { return b <= 128 ? b + 3 : b + 4; }
 
 __device__ __forceinline__ v2f mul_neg_i(v2f z) { return v2f{z.y, -z.x}; }
 __device__ __forceinline__ v2f cmul(v2f z, v2f w) { return v2f{z.x * w.x - z.y * w.y, z.x * w.y + z.y * w.x}; }
@@ -88,9 +93,11 @@ __device__ __forceinline__ float fast_log(const MfccArgs& a, float v) {
 constexpr int NCH = 5;  // 256-float chunks per quad stage: slen <= 3*256 + 512 = 1280
 
 template <int NZ>
-__global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
+__global__ __launch_bounds__(64 * FAST_WAVES, 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = 64 * FAST_WAVES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-level control flow stays on the SALU
     const int g = lane >> 4, j = lane & 15;
     const int nc = a.n_ceps;
 
@@ -109,15 +116,16 @@ __global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastA
     float* lmrow = reinterpret_cast<float*>(zbuf + 4 * ZFRAME);
 
     // ---- shared tables -> LDS
-    for (int i = tid; i < 512; i += 256) s_win[i] = a.window[i];
-    for (int i = tid; i < 256; i += 256) s_tw16[i] = *reinterpret_cast<const v2f*>(&f.tw16[i]);
-    for (int i = tid; i < 144; i += 256) s_wpost[i] = *reinterpret_cast<const v2f*>(&f.wpost[i]);
-    for (int i = tid; i < f.total_steps * 16; i += 256) s_melw[i] = f.melw[i];
-    for (int i = tid; i < f.n_pass * 16; i += 256) {
+    for (int i = tid; i < 512; i += NT) s_win[i] = a.window[i];
+    for (int i = tid; i < 256; i += NT) s_tw16[i] = *reinterpret_cast<const v2f*>(&f.tw16[i]);
+    for (int i = tid; i < 144; i += NT) s_wpost[i] = *reinterpret_cast<const v2f*>(&f.wpost[i]);
+    for (int i = tid; i < f.total_steps * 64; i += NT) s_melw[i] = f.melw[i];
+    for (int i = tid; i < f.n_pass * 16; i += NT) {
         s_mello[i] = f.mel_lo[i];
         s_melid[i] = f.mel_id[i];
     }
-    for (int i = tid; i < a.n_filt * f.q_pass * 16; i += 256) s_dct[i] = f.dctT[i];
+    for (int i = tid; i < f.n_filt4 * 4 * f.q_pass * 16; i += NT) s_dct[i] = f.dctT[i];
+    for (int i = lane; i < 4 * LMSTR; i += 64) lmrow[i] = 0.f;  // padded filter slots must read as finite zeros
     __syncthreads();
 
     const MfccChunk ch = a.chunks[blockIdx.x];
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastA
     const float pre = a.preemph_mode ? a.preemph : 0.f;
     const int nquads = (tb - ta + 3) >> 2;
 
-    // ---- software prefetch of a quad's samples: HBM -> registers
+    // ---- software prefetch of a quad's samples: HBM -> registers (reads past the utterance end return 0)
     float4 pf[NCH];
     float pfprev[NCH];
     float pfx0 = 0.f;
@@ -142,17 +150,16 @@ __global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastA
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e0 = c * 256 + lane * 4;
+            const int64_t i0 = sq + e0;
+            const int64_t left = (e0 < f.slen) ? N - i0 : 0;  // samples available from i0 on
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e0 < f.slen) {
-                const int64_t i0 = sq + e0;
-                if (i0 + 3 < N) {
-                    const f4u u = *reinterpret_cast<const f4u*>(x + i0);
-                    v = make_float4(u.x, u.y, u.z, u.w);
-                } else {
-                    if (i0 < N) v.x = x[i0];
-                    if (i0 + 1 < N) v.y = x[i0 + 1];
-                    if (i0 + 2 < N) v.z = x[i0 + 2];
-                }
+            if (left >= 4) {
+                const f4u u = *reinterpret_cast<const f4u*>(x + i0);
+                v = make_float4(u.x, u.y, u.z, u.w);
+            } else if (left > 0) {
+                v.x = x[i0];
+                if (left > 1) v.y = x[i0 + 1];
+                if (left > 2) v.z = x[i0 + 2];
             }
             pf[c] = v;
             float p = __shfl_up(v.w, 1);
@@ -167,20 +174,22 @@ __global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastA
     };
 
     if (wave < nquads) prefetch(wave);
-    for (int q = wave; q < nquads; q += 4) {
+    for (int q = wave; q < nquads; q += FAST_WAVES) {
         const int t = ta + 4 * q + g;  // this lane group's frame
-        // ---- 1. pre-emphasis + stage to LDS (the previous quad's P rows in this buffer are dead by now)
+        // ---- 1. pre-emphasis + stage to LDS
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e0 = c * 256 + lane * 4;
-            if (e0 < f.stage_floats) {
-                const float4 v = pf[c];
-                v4f y;
-                y.x = v.x - pre * pfprev[c];
-                y.y = v.y - pre * v.x;
-                y.z = v.z - pre * v.y;
-                y.w = v.w - pre * v.z;
-                *reinterpret_cast<v4f*>(stage + e0) = y;
+            if (c * 256 < f.stage_floats) {
+                if (e0 < f.stage_floats) {
+                    const float4 v = pf[c];
+                    v4f y;
+                    y.x = v.x - pre * pfprev[c];
+                    y.y = v.y - pre * v.x;
+                    y.z = v.z - pre * v.y;
+                    y.w = v.w - pre * v.z;
+                    *reinterpret_cast<v4f*>(stage + e0) = y;
+                }
             }
         }
         const float x0 = pfx0;
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastA
             }
             if (a.preemph_mode && j == 0) z[0].x = f.one_minus_a * x0 * s_win[0];  // y[0] = x[0] - a x[0]
         }
-        if (q + 4 < nquads) prefetch(q + 4);  // next quad's loads fly under the FFT
+        if (q + FAST_WAVES < nquads) prefetch(q + FAST_WAVES);  // next quad's loads fly under the FFT
         // ---- 3. FFT16 over n1, twiddle W_256^(n2 k1)
         fft16(z);
 #pragma unroll
@@ -218,20 +227,24 @@ __global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastA
         }
         // ---- 5. FFT16 over n2: lane j = k1, register = k2
         fft16(z);
-        // ---- 6. Z natural order -> LDS, split step on bin pairs, power / magnitude -> P row
+        // ---- 6. Z natural order -> LDS, split step on bin pairs k = 8j+1..8j+8 <-> 256-k (+ k = 0 on lane 0),
+        //         power / magnitude -> P row (which reuses this frame's Z image: every Z read is issued first)
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<v2f*>(zf + k2 * ZROW + j * 8) = z[k2];
         {
-            float* P = stage + g * PSTR;
-            v2f lo[8], hi[9];
-            const char* plo = zf + (j >> 1) * ZROW + (j & 1) * 64;  // bins 8j .. 8j+7
+            v2f lo[9], hi[8];
+            const char* plo = zf + (j >> 1) * ZROW + (j & 1) * 64;  // Z[8j .. 8j+7]
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const v4f r = *reinterpret_cast<const v4f*>(plo + c * 16);
                 lo[2 * c] = v2f{r.x, r.y};
                 lo[2 * c + 1] = v2f{r.z, r.w};
             }
-            const int mb = 248 - 8 * j;  // aligned block [mb, mb+8); element mb+8 = 256-8j (wraps to 0 for j = 0)
+            {
+                const int me = 8 * j + 8;  // Z[8j+8] (bin 128 for lane 15)
+                lo[8] = *reinterpret_cast<const v2f*>(zf + (me >> 4) * ZROW + (me & 15) * 8);
+            }
+            const int mb = 248 - 8 * j;  // Z[248-8j .. 255-8j]
             const char* phi = zf + (mb >> 4) * ZROW + (mb & 15) * 8;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -239,13 +252,12 @@ __global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastA
                 hi[2 * c] = v2f{r.x, r.y};
                 hi[2 * c + 1] = v2f{r.z, r.w};
             }
-            const int me = (256 - 8 * j) & 255;
-            hi[8] = *reinterpret_cast<const v2f*>(zf + (me >> 4) * ZROW + (me & 15) * 8);
-            const v2f z128 = *reinterpret_cast<const v2f*>(zf + 8 * ZROW);  // bin 128 (self pair, lane 15 keeps it)
+            const v2f z0 = *reinterpret_cast<const v2f*>(zf);  // bin 0 (broadcast read)
+            float plow[8], phigh[8];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const v2f zk = i < 8 ? lo[i] : z128;
-                const v2f zm = i < 8 ? hi[8 - i] : z128;  // Z[256 - k]
+            for (int i = 0; i < 8; ++i) {  // k = 8j + 1 + i  <->  256 - k = 255 - 8j - i
+                const v2f zk = lo[i + 1];
+                const v2f zm = hi[7 - i];
                 const v2f w = s_wpost[i * 16 + j];
                 const v2f e = v2f{zk.x + zm.x, zk.y - zm.y};      // 2E = Z[k] + conj Z[256-k]
                 const v2f d = v2f{zk.x - zm.x, zk.y + zm.y};      // 2D = Z[k] - conj Z[256-k]
@@ -257,48 +269,71 @@ __global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastA
                     pa = sqrtf(pa);
                     pb = sqrtf(pb);
                 }
-                pa *= f.pscale;
-                pb *= f.pscale;
-                if (i < 8) {
-                    P[8 * j + i] = pa;
-                    P[256 - 8 * j - i] = pb;
-                } else if (j == 15) {
-                    P[128] = pa;
-                }
+                plow[i] = pa * f.pscale;
+                phigh[7 - i] = pb * f.pscale;
+            }
+            // k = 0: X[0] = Re + Im, X[256] = Re - Im  (2E = 2 Re, 2(-iD)W^0 = 2 Im)
+            float p0 = 2.f * (z0.x + z0.y), p256 = 2.f * (z0.x - z0.y);
+            p0 = (a.spec_power == 1 ? fabsf(p0) : p0 * p0) * f.pscale;
+            p256 = (a.spec_power == 1 ? fabsf(p256) : p256 * p256) * f.pscale;
+            float* P = reinterpret_cast<float*>(zf);
+            *reinterpret_cast<v4f*>(P + 8 * j + 4) = v4f{plow[0], plow[1], plow[2], plow[3]};        // sigma(8j+1..)
+            *reinterpret_cast<v4f*>(P + 8 * j + 8) = v4f{plow[4], plow[5], plow[6], plow[7]};
+            *reinterpret_cast<v4f*>(P + 252 - 8 * j) = v4f{phigh[0], phigh[1], phigh[2], phigh[3]};  // sigma(248-8j..)
+            *reinterpret_cast<v4f*>(P + 256 - 8 * j) = v4f{phigh[4], phigh[5], phigh[6], phigh[7]};
+            if (j == 0) {
+                P[p_sigma(0)] = p0;
+                P[p_sigma(256)] = p256;
             }
         }
-        // ---- 7. banded filterbank + log: lane = filter slot
+        // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads)
         {
-            const float* P = stage + g * PSTR;
+            const float* P = reinterpret_cast<const float*>(zf);
             float* lm = lmrow + g * LMSTR;
             int wofs = 0;
             for (int pass = 0; pass < f.n_pass; ++pass) {
-                const int steps = f.mel_steps[pass];
-                const int lo = s_mello[pass * 16 + j];
+                const int steps4 = f.mel_steps[pass];  // in units of 4 taps
+                const int lo4 = s_mello[pass * 16 + j];  // storage index, multiple of 4
                 const int id = s_melid[pass * 16 + j];
-                const float* pp = P + lo;
-                const float* ww = s_melw + wofs * 16 + j;
-                float acc = 0.f;
-                for (int s = 0; s < steps; ++s) acc = fmaf(pp[s], ww[s * 16], acc);
-                if (id >= 0) lm[id] = fast_log(a, acc);
-                wofs += steps;
+                const v4f* pp = reinterpret_cast<const v4f*>(P + lo4);
+                const v4f* ww = reinterpret_cast<const v4f*>(s_melw + (size_t)wofs * 64) + j;
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 4
+                for (int s = 0; s < steps4; ++s) {
+                    const v4f pv = pp[s];
+                    const v4f wv = ww[s * 16];
+                    acc0 = fmaf(pv.x, wv.x, acc0);
+                    acc1 = fmaf(pv.y, wv.y, acc1);
+                    acc0 = fmaf(pv.z, wv.z, acc0);
+                    acc1 = fmaf(pv.w, wv.w, acc1);
+                }
+                if (id >= 0) lm[id] = fast_log(a, acc0 + acc1);
+                wofs += steps4;
             }
         }
-        // ---- 8. DCT rows: lane = cepstral index
+        // ---- 8. DCT rows: lane = cepstral index, 4 filters per step
         {
-            const float* lm = lmrow + g * LMSTR;
-            const int qs = f.q_pass * 16;
+            const v4f* lm4 = reinterpret_cast<const v4f*>(lmrow + g * LMSTR);
             for (int qp = 0; qp < f.q_pass; ++qp) {
                 const int qq = qp * 16 + j;
-                float acc = 0.f;
-                for (int jf = 0; jf < a.n_filt; ++jf) acc = fmaf(lm[jf], s_dct[jf * qs + qq], acc);
-                if (qq < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + qq] = acc;
+                const v4f* dd = reinterpret_cast<const v4f*>(s_dct) + qq;
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 2
+                for (int s = 0; s < f.n_filt4; ++s) {
+                    const v4f lv = lm4[s];
+                    const v4f dv = dd[s * f.q_pass * 16];
+                    acc0 = fmaf(lv.x, dv.x, acc0);
+                    acc1 = fmaf(lv.y, dv.y, acc1);
+                    acc0 = fmaf(lv.z, dv.z, acc0);
+                    acc1 = fmaf(lv.w, dv.w, acc1);
+                }
+                if (qq < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + qq] = acc0 + acc1;
             }
         }
     }
     __syncthreads();
 
-    // ---- delta / delta-delta on the fly from the cepstra (edge padding at utterance ends, GMM_UBM.py:64)
+    // ---- delta / delta-delta from the cepstra in LDS (edge padding at utterance ends, GMM_UBM.py:64)
     const int Nd = a.delta_N;
     const float inv = a.delta_inv_denom;
     const int D = a.d_out;
@@ -308,43 +343,80 @@ __global__ __launch_bounds__(256, 2) void mfcc_fused512_kernel(MfccArgs a, FastA
         for (int m = 1; m <= Nd; ++m) acc += (float)m * (cep(min(u + m, T - 1), qq) - cep(max(u - m, 0), qq));
         return acc * inv;
     };
-    auto value = [&](int r, int d) -> float {
-        const int blk = d / nc, qq = d - blk * nc;
-        const int u = t0 + r;
-        if (blk == 0) return cep(u, qq);
-        if (blk == 1) return dl(u, qq);
+    auto ddl = [&](int u, int qq) -> float {
         float acc = 0.f;
         for (int m = 1; m <= Nd; ++m) acc += (float)m * (dl(min(u + m, T - 1), qq) - dl(max(u - m, 0), qq));
         return acc * inv;
     };
-    if (a.cmvn) {
-        for (int d = wave; d < D; d += 4) {
-            float s = 0.f;
-            for (int r = lane; r < n; r += 64) s += value(r, d);
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            const float mean = s / (float)n;
-            float v = 0.f;
-            for (int r = lane; r < n; r += 64) {
-                const float e = value(r, d) - mean;
-                v = fmaf(e, e, v);
+    // c, delta, delta-delta of one (frame, cepstral index): interior frames take ONE sweep over the 4N+1 neighbours
+    // (delta-delta = the cepstra convolved with the auto-convolution of the regression weights), edge frames the
+    // nested edge-padded form
+    auto emit = [&](int u, int qq, float& c0, float& c1, float& c2) {
+        c0 = cep(u, qq);
+        c1 = 0.f;
+        c2 = 0.f;
+        if (a.delta_order == 0) return;
+        if (u - 2 * Nd >= 0 && u + 2 * Nd <= T - 1) {
+            for (int k = -2 * Nd; k <= 2 * Nd; ++k) {
+                const float v = cep(u + k, qq);
+                c2 = fmaf(f.ddw[k + 2 * Nd], v, c2);
+                if (k >= -Nd && k <= Nd) c1 = fmaf((float)k * inv, v, c1);
             }
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            float sd = sqrtf(v / (float)n);
-            if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;
-            if (lane == 0) {
-                s_stats[d] = mean;
-                s_stats[D + d] = 1.0f / sd;
-            }
+        } else {
+            c1 = dl(u, qq);
+            if (a.delta_order >= 2) c2 = ddl(u, qq);
         }
-        __syncthreads();
-    }
+    };
     float* __restrict__ out = a.out + (size_t)(f0 + t0) * D;
-    for (int i = tid; i < n * D; i += 256) {
-        const int r = i / D, d = i - r * D;
-        float v = value(r, d);
-        if (a.cmvn) v = (v - s_stats[d]) * s_stats[D + d];
-        out[i] = v;
+    // thread -> (row r, cepstral index qq): 16 qq lanes x NT/16 rows per sweep; each thread emits c, delta, delta-delta
+    const int qsub = tid & 15, rsub = tid >> 4;
+    if (!a.cmvn) {
+        for (int qq = qsub; qq < nc; qq += 16)
+            for (int r = rsub; r < n; r += NT / 16) {
+                float c0, c1, c2;
+                emit(t0 + r, qq, c0, c1, c2);
+                float* o = out + (size_t)r * D + qq;
+                o[0] = c0;
+                if (a.delta_order >= 1) o[nc] = c1;
+                if (a.delta_order >= 2) o[2 * nc] = c2;
+            }
+        return;
     }
+    // per-utterance CMVN: (x - mean) / std per output dimension, ddof = 0, std < 10 eps -> 1 (sklearn scale)
+    auto value = [&](int r, int d) -> float {
+        const int blk = d / nc, qq = d - blk * nc;
+        float c0, c1, c2;
+        emit(t0 + r, qq, c0, c1, c2);
+        return blk == 0 ? c0 : (blk == 1 ? c1 : c2);
+    };
+    for (int d = wave; d < D; d += FAST_WAVES) {
+        float s = 0.f;
+        for (int r = lane; r < n; r += 64) s += value(r, d);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)n;
+        float v = 0.f;
+        for (int r = lane; r < n; r += 64) {
+            const float e = value(r, d) - mean;
+            v = fmaf(e, e, v);
+        }
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        float sd = sqrtf(v / (float)n);
+        if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;
+        if (lane == 0) {
+            s_stats[d] = mean;
+            s_stats[D + d] = 1.0f / sd;
+        }
+    }
+    __syncthreads();
+    for (int qq = qsub; qq < nc; qq += 16)
+        for (int r = rsub; r < n; r += NT / 16) {
+            float c0, c1, c2;
+            emit(t0 + r, qq, c0, c1, c2);
+            float* o = out + (size_t)r * D + qq;
+            o[0] = (c0 - s_stats[qq]) * s_stats[D + qq];
+            if (a.delta_order >= 1) o[nc] = (c1 - s_stats[nc + qq]) * s_stats[D + nc + qq];
+            if (a.delta_order >= 2) o[2 * nc] = (c2 - s_stats[2 * nc + qq]) * s_stats[D + 2 * nc + qq];
+        }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -364,11 +436,12 @@ int build_fast_tables(ssp_mfcc_plan* p) {
         }
     for (int i = 0; i < 9; ++i)
         for (int pl = 0; pl < 16; ++pl) {
-            const int k = i < 8 ? 8 * pl + i : 128;
+            const int k = i < 8 ? 8 * pl + 1 + i : 0;  // lane pl owns the pairs k = 8 pl + 1 .. 8 pl + 8
             const double ang = -2.0 * M_PI * (double)k / 512.0;
             wpost[i * 16 + pl] = make_float2((float)cos(ang), (float)sin(ang));
         }
-    // banded filters sorted by band length (descending) into slots of 16 lanes
+    // banded filters sorted by band length (descending) into slots of 16 lanes; bands are expressed in P-row STORAGE
+    // coordinates (p_sigma) and cut into 4-tap steps that start on a 16-byte boundary
     std::vector<int32_t> lo(c.n_filt), len(c.n_filt), order(c.n_filt);
     std::vector<float> dense((size_t)c.n_filt * nb);
     SSP_HIP(hipMemcpy(dense.data(), p->fbank_dense.p, dense.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -390,33 +463,49 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     std::vector<float> melw;
     int total = 0;
     for (int ps = 0; ps < n_pass; ++ps) {
-        int steps = 0;
+        int steps4 = 0;
         for (int l = 0; l < 16; ++l) {
             const int s = ps * 16 + l;
-            if (s < c.n_filt) steps = std::max(steps, len[order[s]]);
+            if (s >= c.n_filt || len[order[s]] == 0) continue;
+            const int jf = order[s];
+            const int sl4 = p_sigma(lo[jf]) & ~3, sh = p_sigma(lo[jf] + len[jf] - 1);
+            steps4 = std::max(steps4, (sh - sl4) / 4 + 1);
         }
-        f.mel_steps[ps] = steps;
-        melw.resize((size_t)(total + steps) * 16, 0.f);
+        f.mel_steps[ps] = steps4;
+        melw.resize((size_t)(total + steps4) * 64, 0.f);
         for (int l = 0; l < 16; ++l) {
             const int s = ps * 16 + l;
             if (s >= c.n_filt) continue;
             const int jf = order[s];
             mel_id[s] = jf;
-            // keep lo + steps inside the P row (257 bins + pad): shift the band start down when needed
-            int start = lo[jf];
-            if (start + steps > PSTR) start = PSTR - steps;
-            mel_lo[s] = start;
-            for (int k = 0; k < len[jf]; ++k) melw[(size_t)(total + (lo[jf] - start) + k) * 16 + l] = dense[(size_t)jf * nb + lo[jf] + k];
+            int sl4 = p_sigma(lo[jf]) & ~3;
+            if (sl4 + 4 * steps4 > PSTR) sl4 = (PSTR - 4 * steps4) & ~3;  // keep the sweep inside the P row
+            mel_lo[s] = sl4;
+            for (int k = 0; k < len[jf]; ++k) {
+                const int pos = p_sigma(lo[jf] + k) - sl4;
+                melw[((size_t)(total + pos / 4) * 16 + l) * 4 + (pos & 3)] = dense[(size_t)jf * nb + lo[jf] + k];
+            }
         }
-        total += steps;
+        total += steps4;
     }
     for (int ps = n_pass; ps < MAX_PASS; ++ps) f.mel_steps[ps] = 0;
     const int q_pass = (c.n_ceps + 15) / 16;
-    std::vector<float> dctT((size_t)c.n_filt * q_pass * 16, 0.f), dcth((size_t)c.n_ceps * c.n_filt);
+    const int n_filt4 = (c.n_filt + 3) / 4;
+    // dctT[s][q][e] = dct[q][4 s + e] (zero padded): one 16-byte read per lane per 4 filters
+    std::vector<float> dctT((size_t)n_filt4 * q_pass * 16 * 4, 0.f), dcth((size_t)c.n_ceps * c.n_filt);
     SSP_HIP(hipMemcpy(dcth.data(), p->dct.p, dcth.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (int q = 0; q < c.n_ceps; ++q)
-        for (int jf = 0; jf < c.n_filt; ++jf) dctT[(size_t)jf * q_pass * 16 + q] = dcth[(size_t)q * c.n_filt + jf];
-
+        for (int jf = 0; jf < c.n_filt; ++jf)
+            dctT[((size_t)(jf / 4) * q_pass * 16 + q) * 4 + (jf & 3)] = dcth[(size_t)q * c.n_filt + jf];
+    // delta-delta as ONE convolution for interior frames: auto-convolution of the regression weights n / denom
+    {
+        const int Nd = c.delta_order > 0 ? c.delta_N : 0;
+        double den = 0;
+        for (int i = 1; i <= Nd; ++i) den += 2.0 * i * i;
+        for (int k = 0; k < 17; ++k) f.ddw[k] = 0.f;
+        for (int m = -Nd; m <= Nd; ++m)
+            for (int nn = -Nd; nn <= Nd; ++nn) f.ddw[m + nn + 2 * Nd] += (float)((double)m * nn / (den * den));
+    }
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
         SSP_TRY(b.alloc(bytes));
         if (bytes) SSP_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
@@ -436,10 +525,11 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     f.dctT = p->f_dct.as<float>();
     f.n_pass = n_pass;
     f.q_pass = q_pass;
+    f.n_filt4 = n_filt4;
     f.total_steps = total;
     const int NZ = c.win_len <= 416 ? 13 : 16;
     f.slen = 3 * c.hop + 32 * NZ;
-    f.stage_floats = (std::max(f.slen, 4 * PSTR) + 3) & ~3;
+    f.stage_floats = (f.slen + 3) & ~3;
     f.pscale = (c.spec_power == 2 ? 0.25f : 0.5f) * c.spec_scale;
     f.one_minus_a = 1.0f - c.preemph;
     p->fast_ready = true;
@@ -455,17 +545,17 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     f.off_win = (int32_t)off;    off = al16(off + 512 * 4);
     f.off_tw16 = (int32_t)off;   off = al16(off + 256 * 8);
     f.off_wpost = (int32_t)off;  off = al16(off + 144 * 8);
-    f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 16 * 4);
+    f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 64 * 4);
     f.off_mello = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
     f.off_melid = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
-    f.off_dct = (int32_t)off;    off = al16(off + (size_t)c.n_filt * f.q_pass * 16 * 4);
+    f.off_dct = (int32_t)off;    off = al16(off + (size_t)f.n_filt4 * 4 * f.q_pass * 16 * 4);
     f.ceps_rows = ch + 2 * H;
     f.off_ceps = (int32_t)off;   off = al16(off + (size_t)f.ceps_rows * c.n_ceps * 4);
     f.off_stats = (int32_t)off;  off = al16(off + (size_t)2 * c.n_ceps * (1 + c.delta_order) * 4);
     off = (off + 255) & ~size_t(255);
     f.off_wave = (int32_t)off;
     f.wave_bytes = (int32_t)((al16((size_t)f.stage_floats * 4) + 4 * ZFRAME + 4 * LMSTR * 4 + 255) & ~size_t(255));
-    return off + 4 * (size_t)f.wave_bytes;
+    return off + FAST_WAVES * (size_t)f.wave_bytes;
 }
 
 int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int chunk_frames, hipStream_t stream) {
@@ -477,9 +567,9 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
     const void* fn = nz13 ? reinterpret_cast<const void*>(mfcc_fused512_kernel<13>) : reinterpret_cast<const void*>(mfcc_fused512_kernel<16>);
     if (lds > 64 * 1024) SSP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (nz13)
-        hipLaunchKernelGGL(mfcc_fused512_kernel<13>, dim3(n_chunks), dim3(256), lds, stream, args, f);
+        hipLaunchKernelGGL(mfcc_fused512_kernel<13>, dim3(n_chunks), dim3(64 * FAST_WAVES), lds, stream, args, f);
     else
-        hipLaunchKernelGGL(mfcc_fused512_kernel<16>, dim3(n_chunks), dim3(256), lds, stream, args, f);
+        hipLaunchKernelGGL(mfcc_fused512_kernel<16>, dim3(n_chunks), dim3(64 * FAST_WAVES), lds, stream, args, f);
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }

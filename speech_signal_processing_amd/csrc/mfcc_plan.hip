@@ -73,7 +73,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         // whole utterance per workgroup while 2 workgroups still fit a CU's 160 KiB LDS; longer ones are chunked
         FastArgs tmp = p->fast;
         ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 4096);
-        while (ch > 64 && mfcc_fast_lds(c, tmp, ch) > 80 * 1024 && !whole) ch = (ch * 3) / 4;
+        while (ch > 64 && mfcc_fast_lds(c, tmp, ch) > lds_cap && !whole) ch = (ch * 3) / 4;
         if (whole) {
             ch = (int)std::max<int64_t>(max_T, 1);
             if (mfcc_fast_lds(c, tmp, ch) > lds_cap)
