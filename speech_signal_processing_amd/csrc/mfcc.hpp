@@ -76,6 +76,7 @@ struct ssp_mfcc_plan {
     ssp::MfccArgs args{};
     // fused n_fft == 512 kernel
     bool fast_ready = false;
+    int64_t fast_max_samples = 0;  // longest utterance of the cached work table (32-bit offsets in the fast kernel)
     ssp::FastArgs fast{};
     ssp::DevBuf f_tw16, f_wpost, f_melw, f_mello, f_melid, f_dct;
 };

@@ -21,6 +21,7 @@
 // output feature once.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "mfcc.hpp"
 
@@ -32,9 +33,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int ZROW = 144;             // bytes per 16-complex row of the transpose / Z image (128 + 16 pad)
 constexpr int ZFRAME = 16 * ZROW;     // 2304 B per frame (multiple of 256 B: keeps the 4 frames bank-aligned)
 constexpr int PSTR = 264;             // floats per frame of the P (power spectrum) row, storage order sigma(b) below
-constexpr int LMSTR = 64;             // floats per frame of the log-mel row
 constexpr int MAX_PASS = MFCC_FAST_MAX_PASS;
-constexpr int FAST_WAVES = 8;         // waves per workgroup (512 threads): 2 waves per SIMD with one workgroup per CU
+constexpr int FAST_WAVES_DEFAULT = 12;  // waves per workgroup (768 threads, one workgroup per CU = 3 waves per SIMD)
+constexpr int LM_OFF = 1088;          // byte offset of a frame's log-mel row inside its Z image (after the P row)
 
 // storage index of spectrum bin b in a P row: one dummy slot between bins 128 and 129 (and three leading ones) makes
 // BOTH 8-bin runs a lane produces 16-byte aligned: low run k = 8j+1..8j+8 -> 8j+4.., high run 248-8j..255-8j -> 252-8j..
@@ -92,8 +93,10 @@ __device__ __forceinline__ float fast_log(const MfccArgs& a, float v) {
 
 constexpr int NCH = 5;  // 256-float chunks per quad stage: slen <= 3*256 + 512 = 1280
 
-template <int NZ>
-__global__ __launch_bounds__(64 * FAST_WAVES, 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
+// NZ: non-zero 32-sample rows of the window (13 for win <= 416, else 16); POWER: 1 magnitude | 2 power spectrum;
+// PRE: per-frame pre-emphasis on/off; FAST_WAVES: waves per workgroup
+template <int NZ, int POWER, int PRE, int FAST_WAVES>
+__global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * FAST_WAVES;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,31 +104,28 @@ __global__ __launch_bounds__(64 * FAST_WAVES, 2) void mfcc_fused512_kernel(MfccA
     const int g = lane >> 4, j = lane & 15;
     const int nc = a.n_ceps;
 
-    float* s_win = reinterpret_cast<float*>(smem + f.off_win);
     v2f* s_tw16 = reinterpret_cast<v2f*>(smem + f.off_tw16);
     v2f* s_wpost = reinterpret_cast<v2f*>(smem + f.off_wpost);
     float* s_melw = reinterpret_cast<float*>(smem + f.off_melw);
-    int* s_mello = reinterpret_cast<int*>(smem + f.off_mello);
-    int* s_melid = reinterpret_cast<int*>(smem + f.off_melid);
+    int* s_melpk = reinterpret_cast<int*>(smem + f.off_mello);  // storage start | (filter id + 1) << 16
     float* s_dct = reinterpret_cast<float*>(smem + f.off_dct);
     float* s_ceps = reinterpret_cast<float*>(smem + f.off_ceps);
     float* s_stats = reinterpret_cast<float*>(smem + f.off_stats);
-    char* wbase = smem + f.off_wave + wave * f.wave_bytes;
-    float* stage = reinterpret_cast<float*>(wbase);
-    char* zbuf = wbase + f.stage_floats * 4;
-    float* lmrow = reinterpret_cast<float*>(zbuf + 4 * ZFRAME);
+    // wave-private LDS: ONE region of 4 frame images (2304 B each) that is, in program order, the sample stage of the
+    // quad (first slen floats), then the transpose image, the Z image, the P rows and the log-mel rows
+    char* zbuf = smem + f.off_wave + wave * f.wave_bytes;
+    float* stage = reinterpret_cast<float*>(zbuf);
 
     // ---- shared tables -> LDS
-    for (int i = tid; i < 512; i += NT) s_win[i] = a.window[i];
-    for (int i = tid; i < 256; i += NT) s_tw16[i] = *reinterpret_cast<const v2f*>(&f.tw16[i]);
-    for (int i = tid; i < 144; i += NT) s_wpost[i] = *reinterpret_cast<const v2f*>(&f.wpost[i]);
+    // this lane's window taps stay in registers for the whole kernel: w[32 n1 + 2 j], w[32 n1 + 2 j + 1]
+    v2f wreg[NZ];
+#pragma unroll
+    for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
+    for (int i = tid; i < 240; i += NT) s_tw16[i] = *reinterpret_cast<const v2f*>(&f.tw16[16 + i]);  // rows k1 = 1..15
+    for (int i = tid; i < 128; i += NT) s_wpost[i] = *reinterpret_cast<const v2f*>(&f.wpost[i]);
     for (int i = tid; i < f.total_steps * 64; i += NT) s_melw[i] = f.melw[i];
-    for (int i = tid; i < f.n_pass * 16; i += NT) {
-        s_mello[i] = f.mel_lo[i];
-        s_melid[i] = f.mel_id[i];
-    }
+    for (int i = tid; i < f.n_pass * 16; i += NT) s_melpk[i] = f.mel_lo[i] | ((f.mel_id[i] + 1) << 16);
     for (int i = tid; i < f.n_filt4 * 4 * f.q_pass * 16; i += NT) s_dct[i] = f.dctT[i];
-    for (int i = lane; i < 4 * LMSTR; i += 64) lmrow[i] = 0.f;  // padded filter slots must read as finite zeros
     __syncthreads();
 
     const MfccChunk ch = a.chunks[blockIdx.x];
@@ -138,58 +138,50 @@ __global__ __launch_bounds__(64 * FAST_WAVES, 2) void mfcc_fused512_kernel(MfccA
     const int H = a.delta_order * a.delta_N;
     const int ta = max(t0 - H, 0), tb = min(t0 + n + H, T);
     const int hop = a.hop;
-    const float pre = a.preemph_mode ? a.preemph : 0.f;
+    const float pre = PRE ? a.preemph : 0.f;
     const int nquads = (tb - ta + 3) >> 2;
 
-    // ---- software prefetch of a quad's samples: HBM -> registers (reads past the utterance end return 0)
-    float4 pf[NCH];
+    // ---- software prefetch of a quad's samples: HBM -> registers.  Bounds-checked buffer loads: anything outside the
+    //      utterance [0, N) reads as 0, which is exactly the zero padding / "previous sample of sample 0" we need.
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(N * 4), 0x00020000);
+    v4f pf[NCH];
     float pfprev[NCH];
     float pfx0 = 0.f;
     auto prefetch = [&](int q) {
-        const int64_t sq = (int64_t)(ta + 4 * q) * hop;  // first sample of the quad inside the utterance
+        const int sq = (ta + 4 * q) * hop;  // first sample of the quad inside the utterance
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int e0 = c * 256 + lane * 4;
-            const int64_t i0 = sq + e0;
-            const int64_t left = (e0 < f.slen) ? N - i0 : 0;  // samples available from i0 on
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (left >= 4) {
-                const f4u u = *reinterpret_cast<const f4u*>(x + i0);
-                v = make_float4(u.x, u.y, u.z, u.w);
-            } else if (left > 0) {
-                v.x = x[i0];
-                if (left > 1) v.y = x[i0 + 1];
-                if (left > 2) v.z = x[i0 + 2];
+            if (c * 256 < f.slen) {
+                const int off = (sq + c * 256 + lane * 4) * 4;
+                pf[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                if (PRE) pfprev[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off - 4, 0, 0));
             }
-            pf[c] = v;
-            float p = __shfl_up(v.w, 1);
-            if (lane == 0) {
-                const int64_t ip = sq + c * 256 - 1;
-                p = (ip >= 0 && ip < N && c * 256 < f.slen) ? x[ip] : 0.f;
-            }
-            pfprev[c] = p;
         }
-        const int64_t ix = (int64_t)(ta + 4 * q + g) * hop;
-        pfx0 = (j == 0 && ix < N) ? x[ix] : 0.f;
+        if (PRE) pfx0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (ta + 4 * q + g) * hop * 4, 0, 0));
     };
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        pf[c] = v4f{0.f, 0.f, 0.f, 0.f};
+        pfprev[c] = 0.f;
+    }
 
-    if (wave < nquads) prefetch(wave);
+    prefetch(wave);
     for (int q = wave; q < nquads; q += FAST_WAVES) {
         const int t = ta + 4 * q + g;  // this lane group's frame
         // ---- 1. pre-emphasis + stage to LDS
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int e0 = c * 256 + lane * 4;
-            if (c * 256 < f.stage_floats) {
-                if (e0 < f.stage_floats) {
-                    const float4 v = pf[c];
-                    v4f y;
+            if (c * 256 < f.slen) {
+                const v4f v = pf[c];
+                v4f y = v;
+                if (PRE) {
                     y.x = v.x - pre * pfprev[c];
                     y.y = v.y - pre * v.x;
                     y.z = v.z - pre * v.y;
                     y.w = v.w - pre * v.z;
-                    *reinterpret_cast<v4f*>(stage + e0) = y;
                 }
+                *reinterpret_cast<v4f*>(stage + c * 256 + lane * 4) = y;
             }
         }
         const float x0 = pfx0;
@@ -197,24 +189,22 @@ __global__ __launch_bounds__(64 * FAST_WAVES, 2) void mfcc_fused512_kernel(MfccA
         v2f z[16];
         {
             const float* sp = stage + g * hop + 2 * j;
-            const float* wp = s_win + 2 * j;
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
                 if (n1 < NZ) {
                     const v2f s = *reinterpret_cast<const v2f*>(sp + 32 * n1);
-                    const v2f w = *reinterpret_cast<const v2f*>(wp + 32 * n1);
-                    z[n1] = s * w;
+                    z[n1] = s * wreg[n1 < NZ ? n1 : 0];
                 } else {
                     z[n1] = v2f{0.f, 0.f};
                 }
             }
-            if (a.preemph_mode && j == 0) z[0].x = f.one_minus_a * x0 * s_win[0];  // y[0] = x[0] - a x[0]
+            if (PRE && j == 0) z[0].x = f.one_minus_a * x0 * wreg[0].x;  // y[0] = x[0] - a x[0]
         }
-        if (q + FAST_WAVES < nquads) prefetch(q + FAST_WAVES);  // next quad's loads fly under the FFT
+        prefetch(q + FAST_WAVES);  // next quad's loads fly under the FFT (past the end they read zeros)
         // ---- 3. FFT16 over n1, twiddle W_256^(n2 k1)
         fft16(z);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], s_tw16[k1 * 16 + j]);
+        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], s_tw16[(k1 - 1) * 16 + j]);
         // ---- 4. transpose through LDS
         char* zf = zbuf + g * ZFRAME;
 #pragma unroll
@@ -265,17 +255,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES, 2) void mfcc_fused512_kernel(MfccA
                 const v2f xa = e + o, xb = e - o;
                 float pa = xa.x * xa.x + xa.y * xa.y;
                 float pb = xb.x * xb.x + xb.y * xb.y;
-                if (a.spec_power == 1) {
-                    pa = sqrtf(pa);
-                    pb = sqrtf(pb);
+                if (POWER == 1) {
+                    pa = __builtin_sqrtf(pa);
+                    pb = __builtin_sqrtf(pb);
                 }
                 plow[i] = pa * f.pscale;
                 phigh[7 - i] = pb * f.pscale;
             }
             // k = 0: X[0] = Re + Im, X[256] = Re - Im  (2E = 2 Re, 2(-iD)W^0 = 2 Im)
             float p0 = 2.f * (z0.x + z0.y), p256 = 2.f * (z0.x - z0.y);
-            p0 = (a.spec_power == 1 ? fabsf(p0) : p0 * p0) * f.pscale;
-            p256 = (a.spec_power == 1 ? fabsf(p256) : p256 * p256) * f.pscale;
+            p0 = (POWER == 1 ? fabsf(p0) : p0 * p0) * f.pscale;
+            p256 = (POWER == 1 ? fabsf(p256) : p256 * p256) * f.pscale;
             float* P = reinterpret_cast<float*>(zf);
             *reinterpret_cast<v4f*>(P + 8 * j + 4) = v4f{plow[0], plow[1], plow[2], plow[3]};        // sigma(8j+1..)
             *reinterpret_cast<v4f*>(P + 8 * j + 8) = v4f{plow[4], plow[5], plow[6], plow[7]};
@@ -289,12 +279,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES, 2) void mfcc_fused512_kernel(MfccA
         // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads)
         {
             const float* P = reinterpret_cast<const float*>(zf);
-            float* lm = lmrow + g * LMSTR;
+            float* lm = reinterpret_cast<float*>(zf + LM_OFF);
+            if (j < 4 * f.n_filt4 - a.n_filt) lm[a.n_filt + j] = 0.f;  // padded filter slots must read as finite zeros
             int wofs = 0;
             for (int pass = 0; pass < f.n_pass; ++pass) {
                 const int steps4 = f.mel_steps[pass];  // in units of 4 taps
-                const int lo4 = s_mello[pass * 16 + j];  // storage index, multiple of 4
-                const int id = s_melid[pass * 16 + j];
+                const int pk = s_melpk[pass * 16 + j];
+                const int lo4 = pk & 0xffff;  // storage index, multiple of 4
+                const int id = (pk >> 16) - 1;
                 const v4f* pp = reinterpret_cast<const v4f*>(P + lo4);
                 const v4f* ww = reinterpret_cast<const v4f*>(s_melw + (size_t)wofs * 64) + j;
                 float acc0 = 0.f, acc1 = 0.f;
@@ -313,7 +305,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, 2) void mfcc_fused512_kernel(MfccA
         }
         // ---- 8. DCT rows: lane = cepstral index, 4 filters per step
         {
-            const v4f* lm4 = reinterpret_cast<const v4f*>(lmrow + g * LMSTR);
+            const v4f* lm4 = reinterpret_cast<const v4f*>(zf + LM_OFF);
             for (int qp = 0; qp < f.q_pass; ++qp) {
                 const int qq = qp * 16 + j;
                 const v4f* dd = reinterpret_cast<const v4f*>(s_dct) + qq;
@@ -529,7 +521,7 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     f.total_steps = total;
     const int NZ = c.win_len <= 416 ? 13 : 16;
     f.slen = 3 * c.hop + 32 * NZ;
-    f.stage_floats = (f.slen + 3) & ~3;
+    f.stage_floats = (f.slen + 255) & ~255;  // whole 256-float chunks are staged
     f.pscale = (c.spec_power == 2 ? 0.25f : 0.5f) * c.spec_scale;
     f.one_minus_a = 1.0f - c.preemph;
     p->fast_ready = true;
@@ -539,23 +531,29 @@ int build_fast_tables(ssp_mfcc_plan* p) {
 static size_t al16(size_t x) { return (x + 15) & ~size_t(15); }
 
 // LDS carve for chunks of `ch` frames; returns total bytes
+int mfcc_fast_waves() {
+    const char* e = getenv("SSP_MFCC_WAVES");
+    const int w = e ? atoi(e) : FAST_WAVES_DEFAULT;
+    return (w == 4 || w == 6 || w == 8 || w == 12) ? w : FAST_WAVES_DEFAULT;
+}
+
 size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     const int H = c.delta_order * c.delta_N;
     size_t off = 0;
-    f.off_win = (int32_t)off;    off = al16(off + 512 * 4);
-    f.off_tw16 = (int32_t)off;   off = al16(off + 256 * 8);
-    f.off_wpost = (int32_t)off;  off = al16(off + 144 * 8);
+    f.off_win = 0;
+    f.off_tw16 = (int32_t)off;   off = al16(off + 240 * 8);
+    f.off_wpost = (int32_t)off;  off = al16(off + 128 * 8);
     f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 64 * 4);
     f.off_mello = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
-    f.off_melid = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
+    f.off_melid = f.off_mello;
     f.off_dct = (int32_t)off;    off = al16(off + (size_t)f.n_filt4 * 4 * f.q_pass * 16 * 4);
     f.ceps_rows = ch + 2 * H;
     f.off_ceps = (int32_t)off;   off = al16(off + (size_t)f.ceps_rows * c.n_ceps * 4);
     f.off_stats = (int32_t)off;  off = al16(off + (size_t)2 * c.n_ceps * (1 + c.delta_order) * 4);
     off = (off + 255) & ~size_t(255);
     f.off_wave = (int32_t)off;
-    f.wave_bytes = (int32_t)((al16((size_t)f.stage_floats * 4) + 4 * ZFRAME + 4 * LMSTR * 4 + 255) & ~size_t(255));
-    return off + FAST_WAVES * (size_t)f.wave_bytes;
+    f.wave_bytes = (int32_t)((std::max<size_t>((size_t)f.stage_floats * 4, 4 * ZFRAME) + 255) & ~size_t(255));
+    return off + mfcc_fast_waves() * (size_t)f.wave_bytes;
 }
 
 int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int chunk_frames, hipStream_t stream) {
@@ -563,13 +561,34 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
     FastArgs f = p->fast;
     const size_t lds = mfcc_fast_lds(p->cfg, f, chunk_frames);
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
-    const bool nz13 = p->cfg.win_len <= 416;
-    const void* fn = nz13 ? reinterpret_cast<const void*>(mfcc_fused512_kernel<13>) : reinterpret_cast<const void*>(mfcc_fused512_kernel<16>);
-    if (lds > 64 * 1024) SSP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (nz13)
-        hipLaunchKernelGGL(mfcc_fused512_kernel<13>, dim3(n_chunks), dim3(64 * FAST_WAVES), lds, stream, args, f);
-    else
-        hipLaunchKernelGGL(mfcc_fused512_kernel<16>, dim3(n_chunks), dim3(64 * FAST_WAVES), lds, stream, args, f);
+    if (getenv("SSP_DEBUG"))
+        fprintf(stderr, "[ssp] mfcc fast: chunks=%d chunk_frames=%d lds=%zu B (waves %d x %d B, tables+ceps %d B) mel steps %d/%d/%d/%d\n",
+                n_chunks, chunk_frames, lds, mfcc_fast_waves(), f.wave_bytes, f.off_wave, f.mel_steps[0], f.mel_steps[1],
+                f.mel_steps[2], f.mel_steps[3]);
+    const int nz = p->cfg.win_len <= 416 ? 13 : 16, pw = p->cfg.spec_power, pr = p->cfg.preemph_mode ? 1 : 0;
+    const int nw = mfcc_fast_waves();
+    if ((int64_t)p->fast_max_samples * 4 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): utterance too long for 32-bit offsets");
+    bool launched = false;
+#define SSP_FAST_CASE(NZ_, PW_, PR_, NW_)                                                                              \
+    if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && nw == NW_) {                                              \
+        auto* kfn = mfcc_fused512_kernel<NZ_, PW_, PR_, NW_>;                                                          \
+        if (lds > 64 * 1024)                                                                                           \
+            SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kfn, dim3(n_chunks), dim3(64 * NW_), lds, stream, args, f);                                 \
+        launched = true;                                                                                               \
+    }
+#define SSP_FAST_NW(NZ_, PW_, PR_) SSP_FAST_CASE(NZ_, PW_, PR_, 4) SSP_FAST_CASE(NZ_, PW_, PR_, 6) SSP_FAST_CASE(NZ_, PW_, PR_, 8) SSP_FAST_CASE(NZ_, PW_, PR_, 12)
+    SSP_FAST_NW(13, 2, 1)
+    SSP_FAST_NW(13, 2, 0)
+    SSP_FAST_NW(13, 1, 1)
+    SSP_FAST_NW(13, 1, 0)
+    SSP_FAST_NW(16, 2, 1)
+    SSP_FAST_NW(16, 2, 0)
+    SSP_FAST_NW(16, 1, 1)
+    SSP_FAST_NW(16, 1, 0)
+#undef SSP_FAST_NW
+#undef SSP_FAST_CASE
+    if (!launched) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): no kernel instance for this cfg");
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }

@@ -73,7 +73,9 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         // whole utterance per workgroup while 2 workgroups still fit a CU's 160 KiB LDS; longer ones are chunked
         FastArgs tmp = p->fast;
         ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 4096);
-        while (ch > 64 && mfcc_fast_lds(c, tmp, ch) > lds_cap && !whole) ch = (ch * 3) / 4;
+        // two workgroups per CU (80 KiB each) when a whole utterance fits; else one; else chunk the utterance
+        if (mfcc_fast_lds(c, tmp, ch) > lds_cap / 2)
+            while (ch > 64 && mfcc_fast_lds(c, tmp, ch) > lds_cap && !whole) ch = (ch * 3) / 4;
         if (whole) {
             ch = (int)std::max<int64_t>(max_T, 1);
             if (mfcc_fast_lds(c, tmp, ch) > lds_cap)
@@ -107,6 +109,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     if (chunks.size() > (size_t)INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: too many chunks");
     SSP_TRY(upload(p->chunks, chunks, p->ctx->stream));
     SSP_HIP(hipStreamSynchronize(p->ctx->stream));  // `chunks` (host) dies at return
+    p->fast_max_samples = sseg->max_len();
     p->cache_n_chunks = (int32_t)chunks.size();
     p->cache_chunk_frames = ch;
     p->cache_lds = lds;
