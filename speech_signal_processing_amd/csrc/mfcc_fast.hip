@@ -6,9 +6,10 @@
 //   lane                               = 16 complex points of the 256-point complex FFT that carries the 512-point real FFT
 //
 // Per quad, per wave (no workgroup barrier inside the loop; every LDS region below is wave-private):
-//   1. the wave's 3*hop + 32*NZ samples stream HBM -> registers (prefetched one quad ahead, 16-B loads) -> pre-emphasis
-//      -> LDS stage (each sample is written once and read by the 2.5 frames that overlap it)
-//   2. lane n2 of a frame gathers z[n1] = (y[32 n1 + 2 n2], y[32 n1 + 2 n2 + 1]) * window     (n1 = 0..NZ-1, rest zero)
+//   1. lane n2 of a frame loads ITS OWN FFT inputs (x[e-1], x[e], x[e+1]), e = t*hop + 32 n1 + 2 n2, straight from
+//      global memory one quad ahead (bounds-checked buffer loads; 128 contiguous bytes per frame and n1; the overlap
+//      between neighbouring frames is served by L1/L2, HBM sees every sample once)
+//   2. pre-emphasis + window in registers: z[n1] = (y[32 n1 + 2 n2], y[32 n1 + 2 n2 + 1]) * w     (n1 = 0..NZ-1, rest zero)
 //   3. radix-16 FFT over n1 in registers, twiddle W_256^(n2 k1)
 //   4. 16x16 transpose through LDS (144-B padded rows: conflict-free ds_write_b64 / ds_read_b128)
 //   5. radix-16 FFT over n2 in registers -> Z[k1 + 16 k2]
@@ -35,7 +36,8 @@ constexpr int ZFRAME = 16 * ZROW;     // 2304 B per frame (multiple of 256 B: ke
 constexpr int PSTR = 264;             // floats per frame of the P (power spectrum) row, storage order sigma(b) below
 constexpr int MAX_PASS = MFCC_FAST_MAX_PASS;
 constexpr int FAST_WAVES_DEFAULT = 12;  // waves per workgroup (768 threads, one workgroup per CU = 3 waves per SIMD)
-constexpr int LM_OFF = 1088;          // byte offset of a frame's log-mel row inside its Z image (after the P row)
+constexpr int LM_OFF = 2048;          // byte offset of a frame's log-mel row (64 floats) at the END of its Z image
+constexpr int PSWEEP = LM_OFF / 4;    // filterbank sweeps may run past the P row into stale (finite) Z data, never into log-mel
 
 // storage index of spectrum bin b in a P row: one dummy slot between bins 128 and 129 (and three leading ones) makes
 // BOTH 8-bin runs a lane produces 16-byte aligned: low run k = 8j+1..8j+8 -> 8j+4.., high run 248-8j..255-8j -> 252-8j..
@@ -86,12 +88,12 @@ struct __attribute__((packed, aligned(4))) f4u {
 __device__ __forceinline__ float fast_log(const MfccArgs& a, float v) {
     if (a.floor_mode == 1) v += a.eps;
     else if (a.floor_mode == 2) v = fmaxf(v, a.eps);
-    if (a.log_mode == 0) return logf(v);
-    if (a.log_mode == 1) return log10f(v);
-    return 10.0f * log10f(v);
+    // v_log_f32 (log2, ~1 ulp on the normal range) scaled: ln / log10 / 10 log10
+    const float l2 = __builtin_amdgcn_logf(v);
+    const float k = a.log_mode == 0 ? 0.6931471805599453f : (a.log_mode == 1 ? 0.30102999566398120f : 3.0102999566398120f);
+    return l2 * k;
 }
 
-constexpr int NCH = 5;  // 256-float chunks per quad stage: slen <= 3*256 + 512 = 1280
 
 // NZ: non-zero 32-sample rows of the window (13 for win <= 416, else 16); POWER: 1 magnitude | 2 power spectrum;
 // PRE: per-frame pre-emphasis on/off; FAST_WAVES: waves per workgroup
@@ -111,10 +113,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
     float* s_dct = reinterpret_cast<float*>(smem + f.off_dct);
     float* s_ceps = reinterpret_cast<float*>(smem + f.off_ceps);
     float* s_stats = reinterpret_cast<float*>(smem + f.off_stats);
-    // wave-private LDS: ONE region of 4 frame images (2304 B each) that is, in program order, the sample stage of the
-    // quad (first slen floats), then the transpose image, the Z image, the P rows and the log-mel rows
+    // wave-private LDS: ONE region of 4 frame images (2304 B each) that is, in program order, the transpose image, the
+    // Z image, the P rows and the log-mel rows of the quad
     char* zbuf = smem + f.off_wave + wave * f.wave_bytes;
-    float* stage = reinterpret_cast<float*>(zbuf);
 
     // ---- shared tables -> LDS
     // this lane's window taps stay in registers for the whole kernel: w[32 n1 + 2 j], w[32 n1 + 2 j + 1]
@@ -141,66 +142,47 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
     const float pre = PRE ? a.preemph : 0.f;
     const int nquads = (tb - ta + 3) >> 2;
 
-    // ---- software prefetch of a quad's samples: HBM -> registers.  Bounds-checked buffer loads: anything outside the
-    //      utterance [0, N) reads as 0, which is exactly the zero padding / "previous sample of sample 0" we need.
+    // ---- sample gather: every lane loads ITS OWN FFT inputs straight from global memory, one quad ahead:
+    //      (x[e-1], x[e], x[e+1]) with e = t*hop + 32 n1 + 2 j  (the 16 lanes of a frame read 128 contiguous bytes per
+    //      n1; the 2.5x overlap between neighbouring frames is served by L1/L2, HBM sees every sample once).
+    //      Bounds-checked buffer loads: anything outside the utterance [0, N) reads as 0 = the zero padding we need.
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(N * 4), 0x00020000);
-    v4f pf[NCH];
-    float pfprev[NCH];
-    float pfx0 = 0.f;
+    typedef float v3f __attribute__((ext_vector_type(3)));
+    v3f pf[NZ];
     auto prefetch = [&](int q) {
-        const int sq = (ta + 4 * q) * hop;  // first sample of the quad inside the utterance
+        const int e0 = ((ta + 4 * q + g) * hop + 2 * j - PRE) * 4;  // byte offset of this lane's first element
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c * 256 < f.slen) {
-                const int off = (sq + c * 256 + lane * 4) * 4;
-                pf[c] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-                if (PRE) pfprev[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off - 4, 0, 0));
+        for (int n1 = 0; n1 < NZ; ++n1) {
+            if (PRE) {
+                pf[n1] = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(rs, e0 + 128 * n1, 0, 0));
+            } else {
+                const v2f t2 = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, e0 + 128 * n1, 0, 0));
+                pf[n1] = v3f{t2.x, t2.y, 0.f};
             }
         }
-        if (PRE) pfx0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (ta + 4 * q + g) * hop * 4, 0, 0));
     };
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        pf[c] = v4f{0.f, 0.f, 0.f, 0.f};
-        pfprev[c] = 0.f;
-    }
-
     prefetch(wave);
     for (int q = wave; q < nquads; q += FAST_WAVES) {
         const int t = ta + 4 * q + g;  // this lane group's frame
-        // ---- 1. pre-emphasis + stage to LDS
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c * 256 < f.slen) {
-                const v4f v = pf[c];
-                v4f y = v;
-                if (PRE) {
-                    y.x = v.x - pre * pfprev[c];
-                    y.y = v.y - pre * v.x;
-                    y.z = v.z - pre * v.y;
-                    y.w = v.w - pre * v.z;
-                }
-                *reinterpret_cast<v4f*>(stage + c * 256 + lane * 4) = y;
-            }
-        }
-        const float x0 = pfx0;
-        // ---- 2. gather + window
+        // ---- 1+2. per-frame pre-emphasis (y[0] = x[0] - a x[0], y[n] = x[n] - a x[n-1]) and window, in registers
         v2f z[16];
-        {
-            const float* sp = stage + g * hop + 2 * j;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                if (n1 < NZ) {
-                    const v2f s = *reinterpret_cast<const v2f*>(sp + 32 * n1);
-                    z[n1] = s * wreg[n1 < NZ ? n1 : 0];
+        for (int n1 = 0; n1 < 16; ++n1) {
+            if (n1 < NZ) {
+                const v3f v = pf[n1 < NZ ? n1 : 0];
+                v2f y;
+                if (PRE) {
+                    const float xm1 = (n1 == 0 && j == 0) ? v.y : v.x;
+                    y = v2f{v.y - pre * xm1, v.z - pre * v.y};
                 } else {
-                    z[n1] = v2f{0.f, 0.f};
+                    y = v2f{v.x, v.y};
                 }
+                z[n1] = y * wreg[n1 < NZ ? n1 : 0];
+            } else {
+                z[n1] = v2f{0.f, 0.f};
             }
-            if (PRE && j == 0) z[0].x = f.one_minus_a * x0 * wreg[0].x;  // y[0] = x[0] - a x[0]
         }
-        prefetch(q + FAST_WAVES);  // next quad's loads fly under the FFT (past the end they read zeros)
         // ---- 3. FFT16 over n1, twiddle W_256^(n2 k1)
         fft16(z);
 #pragma unroll
@@ -276,6 +258,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
                 P[p_sigma(256)] = p256;
             }
         }
+        prefetch(q + FAST_WAVES);  // next quad's samples fly under the filterbank / DCT (past the end they read zeros)
         // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads)
         {
             const float* P = reinterpret_cast<const float*>(zf);
@@ -413,7 +396,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
 
 // ------------------------------------------------------------------------------------------------ host side
 bool mfcc_fast_supported(const ssp_mfcc_cfg& c) {
-    return c.n_fft == 512 && c.hop >= 2 && c.hop <= 256 && (c.hop & 1) == 0 && c.n_filt <= 64 && c.n_ceps <= 64 &&
+    return c.n_fft == 512 && c.hop >= 1 && c.n_filt <= 64 && c.n_ceps <= 64 &&
            c.frame_mode != 2 && c.top_db < 0.f && (c.delta_order == 0 || c.delta_N <= 4);
 }
 
@@ -455,13 +438,30 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     std::vector<float> melw;
     int total = 0;
     for (int ps = 0; ps < n_pass; ++ps) {
+        // Bank-conflict-free sweep: the 16 lanes of a pass read P with 16-byte loads that advance in lock step, so the
+        // reads never conflict when the 16 band starts fall into 16 different 16-byte bank groups (start/4 mod 16).
+        // Greedy, longest band first: move a band start DOWN by whole 4-tap steps (zero weights in front) until its
+        // bank group is free; short bands absorb the shift without lengthening the pass.
+        int start4[16], endq[16];
+        bool used[16] = {false};
         int steps4 = 0;
         for (int l = 0; l < 16; ++l) {
             const int s = ps * 16 + l;
+            start4[l] = 0;
+            endq[l] = 0;
             if (s >= c.n_filt || len[order[s]] == 0) continue;
             const int jf = order[s];
             const int sl4 = p_sigma(lo[jf]) & ~3, sh = p_sigma(lo[jf] + len[jf] - 1);
-            steps4 = std::max(steps4, (sh - sl4) / 4 + 1);
+            int pick = sl4;
+            for (int k = 0; k < 16 && sl4 - 4 * k >= 0; ++k)
+                if (!used[((sl4 - 4 * k) / 4) & 15]) {
+                    pick = sl4 - 4 * k;
+                    break;
+                }
+            used[(pick / 4) & 15] = true;
+            start4[l] = pick;
+            endq[l] = sh;
+            steps4 = std::max(steps4, (sh - pick) / 4 + 1);
         }
         f.mel_steps[ps] = steps4;
         melw.resize((size_t)(total + steps4) * 64, 0.f);
@@ -470,11 +470,12 @@ int build_fast_tables(ssp_mfcc_plan* p) {
             if (s >= c.n_filt) continue;
             const int jf = order[s];
             mel_id[s] = jf;
-            int sl4 = p_sigma(lo[jf]) & ~3;
-            if (sl4 + 4 * steps4 > PSTR) sl4 = (PSTR - 4 * steps4) & ~3;  // keep the sweep inside the P row
+            int sl4 = start4[l];
+            if (sl4 + 4 * steps4 > PSWEEP) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): filterbank band layout does not fit the P row");
             mel_lo[s] = sl4;
             for (int k = 0; k < len[jf]; ++k) {
                 const int pos = p_sigma(lo[jf] + k) - sl4;
+                if (pos / 4 >= steps4) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): filterbank band longer than the pass sweep");
                 melw[((size_t)(total + pos / 4) * 16 + l) * 4 + (pos & 3)] = dense[(size_t)jf * nb + lo[jf] + k];
             }
         }
@@ -552,7 +553,7 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     f.off_stats = (int32_t)off;  off = al16(off + (size_t)2 * c.n_ceps * (1 + c.delta_order) * 4);
     off = (off + 255) & ~size_t(255);
     f.off_wave = (int32_t)off;
-    f.wave_bytes = (int32_t)((std::max<size_t>((size_t)f.stage_floats * 4, 4 * ZFRAME) + 255) & ~size_t(255));
+    f.wave_bytes = 4 * ZFRAME;
     return off + mfcc_fast_waves() * (size_t)f.wave_bytes;
 }
 

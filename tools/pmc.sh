@@ -1,0 +1,18 @@
+#!/bin/bash
+# collect SQ counters for the MFCC fast kernel (run on the GPU box):  tools/pmc.sh <tag> [bench args]
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+i=0
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_${tag}_$i -- python3 $R/bench.py --steps 2 --warmup 1 --stages mfcc --no-cpu-baseline --utts 20000 "$@" > /dev/null 2>&1
+done
+python3 - <<PY
+import csv,glob,collections
+for f in sorted(glob.glob('$R/gpurun_out/pmc_${tag}_*/*/*_counter_collection.csv')):
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'mfcc_fused' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    for k,v in agg.items(): print(k, '%.4g'%(sum(v)/len(v)))
+PY
