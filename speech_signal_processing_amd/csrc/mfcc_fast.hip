@@ -43,16 +43,32 @@ constexpr int PSWEEP = LM_OFF / 4;    // filterbank sweeps may run past the P ro
 // BOTH 8-bin runs a lane produces 16-byte aligned: low run k = 8j+1..8j+8 -> 8j+4.., high run 248-8j..255-8j -> 252-8j..
 __host__ __device__ constexpr int p_sigma(int b) { return b <= 128 ? b + 3 : b + 4; }
 
-__device__ __forceinline__ v2f mul_neg_i(v2f z) { return v2f{z.y, -z.x}; }
-__device__ __forceinline__ v2f cmul(v2f z, v2f w) { return v2f{z.x * w.x - z.y * w.y, z.x * w.y + z.y * w.x}; }
-__device__ __forceinline__ v2f cmulc(v2f z, float c, float s) { return v2f{z.x * c - z.y * s, z.x * s + z.y * c}; }
+// Complex helpers written so that every swizzle folds into the op_sel / constant operand of ONE packed instruction
+// (v_pk_fma_f32 / v_pk_mul_f32): no v_mov / v_xor to build swapped or sign-flipped pairs.
+__device__ __forceinline__ v2f swap(v2f z) { return v2f{z.y, z.x}; }
+__device__ __forceinline__ v2f xx(v2f z) { return v2f{z.x, z.x}; }
+__device__ __forceinline__ v2f yy(v2f z) { return v2f{z.y, z.y}; }
+// t + (-i) u  and  t - (-i) u     ((-i) u = (u.y, -u.x))
+__device__ __forceinline__ v2f add_neg_i(v2f t, v2f u) { return __builtin_elementwise_fma(swap(u), v2f{1.f, -1.f}, t); }
+__device__ __forceinline__ v2f sub_neg_i(v2f t, v2f u) { return __builtin_elementwise_fma(swap(u), v2f{-1.f, 1.f}, t); }
+// z * (c + i s), constants known at compile time
+__device__ __forceinline__ v2f cmulc(v2f z, float c, float s) {
+    return __builtin_elementwise_fma(yy(z), v2f{-s, c}, xx(z) * v2f{c, s});
+}
+// z * w, w from a table: wi = (-w.y, w.x) is formed once per twiddle
+__device__ __forceinline__ v2f cmul(v2f z, v2f w) {
+    const v2f wi = swap(w) * v2f{-1.f, 1.f};
+    return __builtin_elementwise_fma(yy(z), wi, xx(z) * w);
+}
+// z * w with both w = (wr, wi) and iw = (-wi, wr) at hand (registers): two packed instructions
+__device__ __forceinline__ v2f cmul2(v2f z, v2f w, v2f iw) { return __builtin_elementwise_fma(yy(z), iw, xx(z) * w); }
 
 __device__ __forceinline__ void dft4(v2f& a, v2f& b, v2f& c, v2f& d) {
-    const v2f t0 = a + c, t1 = a - c, t2 = b + d, t3 = mul_neg_i(b - d);
+    const v2f t0 = a + c, t1 = a - c, t2 = b + d, u = b - d;
     a = t0 + t2;
-    b = t1 + t3;
     c = t0 - t2;
-    d = t1 - t3;
+    b = add_neg_i(t1, u);
+    d = sub_neg_i(t1, u);
 }
 
 // forward 16-point DFT, natural order in, natural order out (4 x 4 Cooley-Tukey, constant twiddles)
@@ -65,7 +81,7 @@ __device__ __forceinline__ void fft16(v2f (&z)[16]) {
     z[6] = cmulc(z[6], R, -R);                    // n2=2,k1=1: W^2
     z[7] = cmulc(z[7], S1, -C1);                  // n2=3,k1=1: W^3
     z[9] = cmulc(z[9], R, -R);                    // n2=1,k1=2: W^2
-    z[10] = mul_neg_i(z[10]);                     // n2=2,k1=2: W^4 = -i
+    z[10] = swap(z[10]) * v2f{1.f, -1.f};         // n2=2,k1=2: W^4 = -i
     z[11] = cmulc(z[11], -R, -R);                 // n2=3,k1=2: W^6
     z[13] = cmulc(z[13], S1, -C1);                // n2=1,k1=3: W^3
     z[14] = cmulc(z[14], -R, -R);                 // n2=2,k1=3: W^6
@@ -148,21 +164,20 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
     //      Bounds-checked buffer loads: anything outside the utterance [0, N) reads as 0 = the zero padding we need.
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(N * 4), 0x00020000);
-    typedef float v3f __attribute__((ext_vector_type(3)));
-    v3f pf[NZ];
+    v2f pf[NZ];   // (x[e],   x[e+1])
+    v2f pfp[NZ];  // (x[e-1], x[e])   the "previous sample" pair of the pre-emphasis, as its own aligned register pair
     auto prefetch = [&](int q) {
-        const int e0 = ((ta + 4 * q + g) * hop + 2 * j - PRE) * 4;  // byte offset of this lane's first element
+        const int e0 = ((ta + 4 * q + g) * hop + 2 * j) * 4;  // byte offset of this lane's first element
 #pragma unroll
         for (int n1 = 0; n1 < NZ; ++n1) {
-            if (PRE) {
-                pf[n1] = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(rs, e0 + 128 * n1, 0, 0));
-            } else {
-                const v2f t2 = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, e0 + 128 * n1, 0, 0));
-                pf[n1] = v3f{t2.x, t2.y, 0.f};
-            }
+            pf[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, e0 + 128 * n1, 0, 0));
+            // aux = 1 (sc0: still served by L1) only keeps the compiler from fusing the two loads into one dwordx3,
+            // whose odd register pair would have to be re-packed with v_mov before the packed FMA
+            if (PRE) pfp[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, e0 + 128 * n1 - 4, 0, 1));
         }
     };
     prefetch(wave);
+    const v2f npre2 = v2f{-pre, -pre};
     for (int q = wave; q < nquads; q += FAST_WAVES) {
         const int t = ta + 4 * q + g;  // this lane group's frame
         // ---- 1+2. per-frame pre-emphasis (y[0] = x[0] - a x[0], y[n] = x[n] - a x[n-1]) and window, in registers
@@ -170,13 +185,11 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NZ) {
-                const v3f v = pf[n1 < NZ ? n1 : 0];
-                v2f y;
+                v2f y = pf[n1 < NZ ? n1 : 0];
                 if (PRE) {
-                    const float xm1 = (n1 == 0 && j == 0) ? v.y : v.x;
-                    y = v2f{v.y - pre * xm1, v.z - pre * v.y};
-                } else {
-                    y = v2f{v.x, v.y};
+                    v2f pv = pfp[n1 < NZ ? n1 : 0];
+                    if (n1 == 0) pv.x = j == 0 ? y.x : pv.x;  // first sample of the frame: its own predecessor
+                    y = __builtin_elementwise_fma(npre2, pv, y);
                 }
                 z[n1] = y * wreg[n1 < NZ ? n1 : 0];
             } else {
@@ -231,23 +244,24 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
                 const v2f zk = lo[i + 1];
                 const v2f zm = hi[7 - i];
                 const v2f w = s_wpost[i * 16 + j];
-                const v2f e = v2f{zk.x + zm.x, zk.y - zm.y};      // 2E = Z[k] + conj Z[256-k]
-                const v2f d = v2f{zk.x - zm.x, zk.y + zm.y};      // 2D = Z[k] - conj Z[256-k]
-                const v2f o = cmul(v2f{d.y, -d.x}, w);            // 2 (-i D) W^k
+                const v2f e = __builtin_elementwise_fma(zm, v2f{1.f, -1.f}, zk);   // 2E = Z[k] + conj Z[256-k]
+                const v2f d = __builtin_elementwise_fma(zm, v2f{-1.f, 1.f}, zk);   // 2D = Z[k] - conj Z[256-k]
+                const v2f o = cmul(swap(d) * v2f{1.f, -1.f}, w);                   // 2 (-i D) W^k
                 const v2f xa = e + o, xb = e - o;
-                float pa = xa.x * xa.x + xa.y * xa.y;
-                float pb = xb.x * xb.x + xb.y * xb.y;
+                const v2f sa = xa * xa, sb = xb * xb;
+                float pa = sa.x + sa.y;
+                float pb = sb.x + sb.y;
                 if (POWER == 1) {
                     pa = __builtin_sqrtf(pa);
                     pb = __builtin_sqrtf(pb);
                 }
-                plow[i] = pa * f.pscale;
-                phigh[7 - i] = pb * f.pscale;
+                plow[i] = pa;       // the 1/4 (power) or 1/2 (magnitude) and spec_scale live in the filterbank weights
+                phigh[7 - i] = pb;
             }
             // k = 0: X[0] = Re + Im, X[256] = Re - Im  (2E = 2 Re, 2(-iD)W^0 = 2 Im)
             float p0 = 2.f * (z0.x + z0.y), p256 = 2.f * (z0.x - z0.y);
-            p0 = (POWER == 1 ? fabsf(p0) : p0 * p0) * f.pscale;
-            p256 = (POWER == 1 ? fabsf(p256) : p256 * p256) * f.pscale;
+            p0 = POWER == 1 ? fabsf(p0) : p0 * p0;
+            p256 = POWER == 1 ? fabsf(p256) : p256 * p256;
             float* P = reinterpret_cast<float*>(zf);
             *reinterpret_cast<v4f*>(P + 8 * j + 4) = v4f{plow[0], plow[1], plow[2], plow[3]};        // sigma(8j+1..)
             *reinterpret_cast<v4f*>(P + 8 * j + 8) = v4f{plow[4], plow[5], plow[6], plow[7]};
@@ -436,6 +450,7 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     FastArgs& f = p->fast;
     std::vector<int32_t> mel_lo(n_pass * 16, 0), mel_id(n_pass * 16, -1);
     std::vector<float> melw;
+    const float pscale = (c.spec_power == 2 ? 0.25f : 0.5f) * c.spec_scale;  // the split step works on 2 X[k]
     int total = 0;
     for (int ps = 0; ps < n_pass; ++ps) {
         // Bank-conflict-free sweep: the 16 lanes of a pass read P with 16-byte loads that advance in lock step, so the
@@ -476,7 +491,7 @@ int build_fast_tables(ssp_mfcc_plan* p) {
             for (int k = 0; k < len[jf]; ++k) {
                 const int pos = p_sigma(lo[jf] + k) - sl4;
                 if (pos / 4 >= steps4) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): filterbank band longer than the pass sweep");
-                melw[((size_t)(total + pos / 4) * 16 + l) * 4 + (pos & 3)] = dense[(size_t)jf * nb + lo[jf] + k];
+                melw[((size_t)(total + pos / 4) * 16 + l) * 4 + (pos & 3)] = pscale * dense[(size_t)jf * nb + lo[jf] + k];
             }
         }
         total += steps4;
