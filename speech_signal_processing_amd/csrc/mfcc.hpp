@@ -39,7 +39,7 @@ constexpr int MFCC_FAST_MAX_PASS = 4;  // <= 64 filters in the fused n_fft == 51
 // extra tables / LDS carve of the fused n_fft == 512 kernel (mfcc_fast.hip)
 struct FastArgs {
     const float2* tw16;     // [16][16]  W_256^(k1*n2)
-    const float2* wpost;    // [9][16]   W_512^k, k = 8p + 1 + i (i < 8); row 8 unused
+    const float2* wpost;    // [9][16]   W_512^k, k = p + 16 i (i < 8); row 8 unused
     const float* melw;      // [total_steps][16]
     const int32_t* mel_lo;  // [n_pass*16]
     const int32_t* mel_id;  // [n_pass*16] filter id, -1 = empty slot

@@ -13,8 +13,9 @@
 //   3. radix-16 FFT over n1 in registers, twiddle W_256^(n2 k1)
 //   4. 16x16 transpose through LDS (144-B padded rows: conflict-free ds_write_b64 / ds_read_b128)
 //   5. radix-16 FFT over n2 in registers -> Z[k1 + 16 k2]
-//   6. Z goes back to LDS in natural order; lane p then owns the bin pairs k = 8p..8p+7 <-> 256-k, forms
-//      X[k], X[256-k] of the REAL spectrum (split step) and the power / magnitude, written to a per-frame P row
+//   6. split step of the real FFT: lane k1 owns the bin pairs k = k1 + 16 k2 <-> 256 - k (k2 < 8); the partners sit in the
+//      upper half of lane 16 - k1's registers, so only that half is exchanged through LDS; power / magnitude go to a
+//      per-frame P row in natural bin order
 //   7. banded filterbank: lane = filter (slots sorted by band length), log
 //   8. DCT rows: lane = cepstral index; cepstra go to the workgroup's LDS buffer
 // After the loop one barrier, then delta / delta-delta (recomputed on the fly from the cepstra in LDS), optional
@@ -33,15 +34,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int ZROW = 144;             // bytes per 16-complex row of the transpose / Z image (128 + 16 pad)
 constexpr int ZFRAME = 16 * ZROW;     // 2304 B per frame (multiple of 256 B: keeps the 4 frames bank-aligned)
-constexpr int PSTR = 264;             // floats per frame of the P (power spectrum) row, storage order sigma(b) below
+constexpr int PSTR = 260;             // floats per frame of the P (power spectrum) row: 257 bins + pad
 constexpr int MAX_PASS = MFCC_FAST_MAX_PASS;
-constexpr int FAST_WAVES_DEFAULT = 12;  // waves per workgroup (768 threads, one workgroup per CU = 3 waves per SIMD)
+constexpr int FAST_WAVES_DEFAULT = 4;  // waves per workgroup; two ~60 KiB workgroups per CU = 2 waves per SIMD, 256-VGPR budget
 constexpr int LM_OFF = 2048;          // byte offset of a frame's log-mel row (64 floats) at the END of its Z image
 constexpr int PSWEEP = LM_OFF / 4;    // filterbank sweeps may run past the P row into stale (finite) Z data, never into log-mel
 
-// storage index of spectrum bin b in a P row: one dummy slot between bins 128 and 129 (and three leading ones) makes
-// BOTH 8-bin runs a lane produces 16-byte aligned: low run k = 8j+1..8j+8 -> 8j+4.., high run 248-8j..255-8j -> 252-8j..
-__host__ __device__ constexpr int p_sigma(int b) { return b <= 128 ? b + 3 : b + 4; }
+// storage index of spectrum bin b in a P row (natural order)
+__host__ __device__ constexpr int p_sigma(int b) { return b; }
 
 // Complex helpers written so that every swizzle folds into the op_sel / constant operand of ONE packed instruction
 // (v_pk_fma_f32 / v_pk_mul_f32): no v_mov / v_xor to build swapped or sign-flipped pairs.
@@ -122,8 +122,6 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
     const int g = lane >> 4, j = lane & 15;
     const int nc = a.n_ceps;
 
-    v2f* s_tw16 = reinterpret_cast<v2f*>(smem + f.off_tw16);
-    v2f* s_wpost = reinterpret_cast<v2f*>(smem + f.off_wpost);
     float* s_melw = reinterpret_cast<float*>(smem + f.off_melw);
     int* s_melpk = reinterpret_cast<int*>(smem + f.off_mello);  // storage start | (filter id + 1) << 16
     float* s_dct = reinterpret_cast<float*>(smem + f.off_dct);
@@ -138,8 +136,13 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
     v2f wreg[NZ];
 #pragma unroll
     for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
-    for (int i = tid; i < 240; i += NT) s_tw16[i] = *reinterpret_cast<const v2f*>(&f.tw16[16 + i]);  // rows k1 = 1..15
-    for (int i = tid; i < 128; i += NT) s_wpost[i] = *reinterpret_cast<const v2f*>(&f.wpost[i]);
+    // this lane's twiddles stay in registers: W_256^(k1 j) for the step between the two radix-16 passes and
+    // W_512^(8j+1+i) for the split step (LDS is the busiest unit of this kernel; registers are not)
+    v2f twr[15], wpr[8];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);  // W_512^(j + 16 i)
     for (int i = tid; i < f.total_steps * 64; i += NT) s_melw[i] = f.melw[i];
     for (int i = tid; i < f.n_pass * 16; i += NT) s_melpk[i] = f.mel_lo[i] | ((f.mel_id[i] + 1) << 16);
     for (int i = tid; i < f.n_filt4 * 4 * f.q_pass * 16; i += NT) s_dct[i] = f.dctT[i];
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
         // ---- 3. FFT16 over n1, twiddle W_256^(n2 k1)
         fft16(z);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], s_tw16[(k1 - 1) * 16 + j]);
+        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], twr[k1 - 1]);
         // ---- 4. transpose through LDS
         char* zf = zbuf + g * ZFRAME;
 #pragma unroll
@@ -212,65 +215,47 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
         }
         // ---- 5. FFT16 over n2: lane j = k1, register = k2
         fft16(z);
-        // ---- 6. Z natural order -> LDS, split step on bin pairs k = 8j+1..8j+8 <-> 256-k (+ k = 0 on lane 0),
-        //         power / magnitude -> P row (which reuses this frame's Z image: every Z read is issued first)
+        // ---- 6. split step.  Lane j (= k1) owns the bin pairs k = j + 16 k2 <-> 256 - k for k2 = 0..7.  Z[256 - k] lives
+        //         in lane 16 - j, register 15 - k2 (lane 0: its own register 16 - k2), i.e. always in the UPPER half
+        //         of the registers: only that half goes through LDS (natural order image, rows 8..15), each lane
+        //         reads its 8 partners back, and every pair is formed exactly once.
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<v2f*>(zf + k2 * ZROW + j * 8) = z[k2];
+        for (int k2 = 8; k2 < 16; ++k2) *reinterpret_cast<v2f*>(zf + k2 * ZROW + j * 8) = z[k2];
         {
-            v2f lo[9], hi[8];
-            const char* plo = zf + (j >> 1) * ZROW + (j & 1) * 64;  // Z[8j .. 8j+7]
+            const char* pbase = zf + (j != 0 ? (16 - j) * 8 : ZROW);
+            v2f zm[8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const v4f r = *reinterpret_cast<const v4f*>(plo + c * 16);
-                lo[2 * c] = v2f{r.x, r.y};
-                lo[2 * c + 1] = v2f{r.z, r.w};
-            }
-            {
-                const int me = 8 * j + 8;  // Z[8j+8] (bin 128 for lane 15)
-                lo[8] = *reinterpret_cast<const v2f*>(zf + (me >> 4) * ZROW + (me & 15) * 8);
-            }
-            const int mb = 248 - 8 * j;  // Z[248-8j .. 255-8j]
-            const char* phi = zf + (mb >> 4) * ZROW + (mb & 15) * 8;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const v4f r = *reinterpret_cast<const v4f*>(phi + c * 16);
-                hi[2 * c] = v2f{r.x, r.y};
-                hi[2 * c + 1] = v2f{r.z, r.w};
-            }
-            const v2f z0 = *reinterpret_cast<const v2f*>(zf);  // bin 0 (broadcast read)
-            float plow[8], phigh[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {  // k = 8j + 1 + i  <->  256 - k = 255 - 8j - i
-                const v2f zk = lo[i + 1];
-                const v2f zm = hi[7 - i];
-                const v2f w = s_wpost[i * 16 + j];
-                const v2f e = __builtin_elementwise_fma(zm, v2f{1.f, -1.f}, zk);   // 2E = Z[k] + conj Z[256-k]
-                const v2f d = __builtin_elementwise_fma(zm, v2f{-1.f, 1.f}, zk);   // 2D = Z[k] - conj Z[256-k]
-                const v2f o = cmul(swap(d) * v2f{1.f, -1.f}, w);                   // 2 (-i D) W^k
-                const v2f xa = e + o, xb = e - o;
-                const v2f sa = xa * xa, sb = xb * xb;
-                float pa = sa.x + sa.y;
-                float pb = sb.x + sb.y;
-                if (POWER == 1) {
-                    pa = __builtin_sqrtf(pa);
-                    pb = __builtin_sqrtf(pb);
-                }
-                plow[i] = pa;       // the 1/4 (power) or 1/2 (magnitude) and spec_scale live in the filterbank weights
-                phigh[7 - i] = pb;
-            }
-            // k = 0: X[0] = Re + Im, X[256] = Re - Im  (2E = 2 Re, 2(-iD)W^0 = 2 Im)
-            float p0 = 2.f * (z0.x + z0.y), p256 = 2.f * (z0.x - z0.y);
-            p0 = POWER == 1 ? fabsf(p0) : p0 * p0;
-            p256 = POWER == 1 ? fabsf(p256) : p256 * p256;
+            for (int k2 = 0; k2 < 8; ++k2) zm[k2] = *reinterpret_cast<const v2f*>(pbase + (15 - k2) * ZROW);
+            if (j == 0) zm[0] = z[0];  // Z[256] := Z[0]
             float* P = reinterpret_cast<float*>(zf);
-            *reinterpret_cast<v4f*>(P + 8 * j + 4) = v4f{plow[0], plow[1], plow[2], plow[3]};        // sigma(8j+1..)
-            *reinterpret_cast<v4f*>(P + 8 * j + 8) = v4f{plow[4], plow[5], plow[6], plow[7]};
-            *reinterpret_cast<v4f*>(P + 252 - 8 * j) = v4f{phigh[0], phigh[1], phigh[2], phigh[3]};  // sigma(248-8j..)
-            *reinterpret_cast<v4f*>(P + 256 - 8 * j) = v4f{phigh[4], phigh[5], phigh[6], phigh[7]};
-            if (j == 0) {
-                P[p_sigma(0)] = p0;
-                P[p_sigma(256)] = p256;
+            float pa[8], pb[8];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const v2f zk = z[k2];
+                const v2f w = wpr[k2];                                                  // W_512^(j + 16 k2)
+                const v2f e = __builtin_elementwise_fma(zm[k2], v2f{1.f, -1.f}, zk);   // 2E = Z[k] + conj Z[256-k]
+                const v2f d = __builtin_elementwise_fma(zm[k2], v2f{-1.f, 1.f}, zk);   // 2D = Z[k] - conj Z[256-k]
+                const v2f o = cmul(swap(d) * v2f{1.f, -1.f}, w);                       // 2 (-i D) W^k
+                const v2f xa = e + o, xb = e - o;                                      // 2 X[k], conj(2 X[256-k])
+                const v2f sa = xa * xa, sb = xb * xb;
+                pa[k2] = sa.x + sa.y;
+                pb[k2] = sb.x + sb.y;
+                if (POWER == 1) {
+                    pa[k2] = __builtin_sqrtf(pa[k2]);
+                    pb[k2] = __builtin_sqrtf(pb[k2]);
+                }
             }
+            // bin 128 pairs with itself: 2 X[128] = 2 conj Z[128] (lane 0, register 8)
+            const v2f s8 = z[8] * z[8];
+            float p128 = 4.f * (s8.x + s8.y);
+            if (POWER == 1) p128 = __builtin_sqrtf(p128);
+            // the 1/4 (power) or 1/2 (magnitude) and spec_scale live in the filterbank weights
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                P[j + 16 * k2] = pa[k2];
+                P[256 - j - 16 * k2] = pb[k2];
+            }
+            if (j == 0) P[128] = p128;
         }
         prefetch(q + FAST_WAVES);  // next quad's samples fly under the filterbank / DCT (past the end they read zeros)
         // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads)
@@ -425,7 +410,7 @@ int build_fast_tables(ssp_mfcc_plan* p) {
         }
     for (int i = 0; i < 9; ++i)
         for (int pl = 0; pl < 16; ++pl) {
-            const int k = i < 8 ? 8 * pl + 1 + i : 0;  // lane pl owns the pairs k = 8 pl + 1 .. 8 pl + 8
+            const int k = i < 8 ? pl + 16 * i : 0;  // lane pl owns the pairs k = pl + 16 i, i = 0..7
             const double ang = -2.0 * M_PI * (double)k / 512.0;
             wpost[i * 16 + pl] = make_float2((float)cos(ang), (float)sin(ang));
         }
@@ -557,8 +542,8 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     const int H = c.delta_order * c.delta_N;
     size_t off = 0;
     f.off_win = 0;
-    f.off_tw16 = (int32_t)off;   off = al16(off + 240 * 8);
-    f.off_wpost = (int32_t)off;  off = al16(off + 128 * 8);
+    f.off_tw16 = 0;
+    f.off_wpost = 0;
     f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 64 * 4);
     f.off_mello = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
     f.off_melid = f.off_mello;
@@ -569,7 +554,7 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     off = (off + 255) & ~size_t(255);
     f.off_wave = (int32_t)off;
     f.wave_bytes = 4 * ZFRAME;
-    return off + mfcc_fast_waves() * (size_t)f.wave_bytes;
+    return off + mfcc_fast_waves() * (size_t)f.wave_bytes + 256;  // + pad: lane 0 reads (and discards) one row past the last image
 }
 
 int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int chunk_frames, hipStream_t stream) {
