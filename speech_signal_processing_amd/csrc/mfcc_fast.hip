@@ -37,8 +37,9 @@ constexpr int ZFRAME = 16 * ZROW;     // 2304 B per frame (multiple of 256 B: ke
 constexpr int PSTR = 260;             // floats per frame of the P (power spectrum) row: 257 bins + pad
 constexpr int MAX_PASS = MFCC_FAST_MAX_PASS;
 constexpr int FAST_WAVES_DEFAULT = 4;  // waves per workgroup; two ~60 KiB workgroups per CU = 2 waves per SIMD, 256-VGPR budget
-constexpr int LM_OFF = 2048;          // byte offset of a frame's log-mel row (64 floats) at the END of its Z image
-constexpr int PSWEEP = LM_OFF / 4;    // filterbank sweeps may run past the P row into stale (finite) Z data, never into log-mel
+constexpr int LM_OFF = 2048;          // byte offset of frame 0's log-mel row (64 floats) at the END of its Z image; frame g
+                                      // sits 64 g bytes lower so the 4 frames' broadcast reads use different banks
+constexpr int PSWEEP = (LM_OFF - 192) / 4;    // filterbank sweeps may run past the P row into stale (finite) Z data, never into log-mel
 
 // storage index of spectrum bin b in a P row (natural order)
 __host__ __device__ constexpr int p_sigma(int b) { return b; }
@@ -114,7 +115,7 @@ __device__ __forceinline__ float fast_log(const MfccArgs& a, float v) {
 // NZ: non-zero 32-sample rows of the window (13 for win <= 416, else 16); POWER: 1 magnitude | 2 power spectrum;
 // PRE: per-frame pre-emphasis on/off; FAST_WAVES: waves per workgroup
 template <int NZ, int POWER, int PRE, int FAST_WAVES>
-__global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
+__global__ __launch_bounds__(64 * FAST_WAVES, FAST_WAVES == 12 ? 3 : 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * FAST_WAVES;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
         // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads)
         {
             const float* P = reinterpret_cast<const float*>(zf);
-            float* lm = reinterpret_cast<float*>(zf + LM_OFF);
+            float* lm = reinterpret_cast<float*>(zf + LM_OFF - 64 * g);
             if (j < 4 * f.n_filt4 - a.n_filt) lm[a.n_filt + j] = 0.f;  // padded filter slots must read as finite zeros
             int wofs = 0;
             for (int pass = 0; pass < f.n_pass; ++pass) {
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void mfcc_fused512_kernel(MfccArgs
         }
         // ---- 8. DCT rows: lane = cepstral index, 4 filters per step
         {
-            const v4f* lm4 = reinterpret_cast<const v4f*>(zf + LM_OFF);
+            const v4f* lm4 = reinterpret_cast<const v4f*>(zf + LM_OFF - 64 * g);
             for (int qp = 0; qp < f.q_pass; ++qp) {
                 const int qq = qp * 16 + j;
                 const v4f* dd = reinterpret_cast<const v4f*>(s_dct) + qq;
