@@ -443,27 +443,56 @@ int build_fast_tables(ssp_mfcc_plan* p) {
         // reads never conflict when the 16 band starts fall into 16 different 16-byte bank groups (start/4 mod 16).
         // Greedy, longest band first: move a band start DOWN by whole 4-tap steps (zero weights in front) until its
         // bank group is free; short bands absorb the shift without lengthening the pass.
-        int start4[16], endq[16];
-        bool used[16] = {false};
-        int steps4 = 0;
+        // (bipartite matching band -> bank group, smallest shift bound that admits a perfect matching)
+        int start4[16], sl4v[16], shv[16], nf = 0, fl[16];
         for (int l = 0; l < 16; ++l) {
             const int s = ps * 16 + l;
             start4[l] = 0;
-            endq[l] = 0;
             if (s >= c.n_filt || len[order[s]] == 0) continue;
             const int jf = order[s];
-            const int sl4 = p_sigma(lo[jf]) & ~3, sh = p_sigma(lo[jf] + len[jf] - 1);
-            int pick = sl4;
-            for (int k = 0; k < 16 && sl4 - 4 * k >= 0; ++k)
-                if (!used[((sl4 - 4 * k) / 4) & 15]) {
-                    pick = sl4 - 4 * k;
-                    break;
-                }
-            used[(pick / 4) & 15] = true;
-            start4[l] = pick;
-            endq[l] = sh;
-            steps4 = std::max(steps4, (sh - pick) / 4 + 1);
+            sl4v[l] = p_sigma(lo[jf]) & ~3;
+            shv[l] = p_sigma(lo[jf] + len[jf] - 1);
+            start4[l] = sl4v[l];
+            fl[nf++] = l;
         }
+        int smin = 1;
+        for (int fi = 0; fi < nf; ++fi) smin = std::max(smin, (shv[fl[fi]] - sl4v[fl[fi]]) / 4 + 1);
+        for (int S = smin; S <= smin + 16; ++S) {  // smallest pass length that admits a perfect matching
+            int owner[16];  // bank group -> index into fl
+            for (int r = 0; r < 16; ++r) owner[r] = -1;
+            auto shift_for = [&](int fi, int r) -> int {  // smallest shift (in 4-tap steps) that puts band fi on group r
+                const int l = fl[fi];
+                for (int k = 0; sl4v[l] - 4 * k >= 0 && (shv[l] - (sl4v[l] - 4 * k)) / 4 + 1 <= S; ++k)
+                    if ((((sl4v[l] - 4 * k) / 4) & 15) == r) return k;
+                return -1;
+            };
+            bool seen[16];
+            struct Rec {
+                static bool go(int fi, int* owner, bool* seen, const decltype(shift_for)& sf) {
+                    for (int r = 0; r < 16; ++r) {
+                        if (seen[r] || sf(fi, r) < 0) continue;
+                        seen[r] = true;
+                        if (owner[r] < 0 || go(owner[r], owner, seen, sf)) {
+                            owner[r] = fi;
+                            return true;
+                        }
+                    }
+                    return false;
+                }
+            };
+            int matched = 0;
+            for (int fi = 0; fi < nf; ++fi) {
+                for (int r = 0; r < 16; ++r) seen[r] = false;
+                if (Rec::go(fi, owner, seen, shift_for)) ++matched;
+            }
+            if (matched == nf) {
+                for (int r = 0; r < 16; ++r)
+                    if (owner[r] >= 0) start4[fl[owner[r]]] = sl4v[fl[owner[r]]] - 4 * shift_for(owner[r], r);
+                break;
+            }
+        }
+        int steps4 = 0;
+        for (int fi = 0; fi < nf; ++fi) steps4 = std::max(steps4, (shv[fl[fi]] - start4[fl[fi]]) / 4 + 1);
         f.mel_steps[ps] = steps4;
         melw.resize((size_t)(total + steps4) * 64, 0.f);
         for (int l = 0; l < 16; ++l) {
