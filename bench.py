@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused fast kernel")
     ap.add_argument("--stages", default="mfcc,gmm,cosine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
     args = ap.parse_args()
 
     import torch
@@ -216,32 +217,53 @@ def main():
         mus = np.stack([mu] + [mu + 0.3 * std * rng.standard_normal((K, D)) for _ in range(S)])
         scorer = api.GmmScorer(ctx, np.stack([wts] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
         g_steps = max(2, min(args.steps, 5))
-        r = scorer.score(feats, fseg)  # warm-up (allocates the per-frame scratch)
-        gms = []
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(g_steps):
-            r = scorer.score(feats, fseg, timing=True)
-            gms.append(r["kernel_ms"])
-            decisions = torch.stack([r["argmax"].to(torch.float32), r["scores"][:, 0]], dim=1)
-            gathered = all_gather_rows(decisions)  # RCCL all-gather of the compact per-utterance result
-        torch.cuda.synchronize()
-        barrier()
-        g_elapsed = max_over_ranks(time.perf_counter() - t0, device)
-        fscores = n_frames * (S + 1) * world * g_steps
         flop = 4.0 * D * K * n_frames * (S + 1)
-        g_ms = float(np.mean(gms))
+
+        def run_gmm(precision):
+            r = scorer.score(feats, fseg, precision=precision)  # warm-up (allocates the per-frame scratch)
+            gms = []
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(g_steps):
+                r = scorer.score(feats, fseg, precision=precision, timing=True)
+                gms.append(r["kernel_ms"])
+                decisions = torch.stack([r["argmax"].to(torch.float32), r["scores"][:, 0]], dim=1)
+                gathered = all_gather_rows(decisions)  # RCCL all-gather of the compact per-utterance result
+            torch.cuda.synchronize()
+            barrier()
+            g_elapsed = max_over_ranks(time.perf_counter() - t0, device)
+            return r, float(np.mean(gms)), g_elapsed, int(gathered.shape[0])
+
+        r0, g_ms, g_elapsed, n_gath = run_gmm(0)
+        fscores = n_frames * (S + 1) * world * g_steps
         result["gmm"] = {
             "metric": "GMM frame-scores/s (diag, K=%d, D=%d, %d models)" % (K, D, S + 1),
             "value": fscores / g_elapsed, "unit": "frame-scores/s", "ms_per_step": g_elapsed / g_steps * 1e3,
-            "steps": g_steps, "dtype": "f32", "gathered_rows": int(gathered.shape[0]),
+            "steps": g_steps, "dtype": "f32", "gathered_rows": n_gath,
             "config": {"workload": "configs[2]: the MFCC stream above vs 64-mix diag UBM + 50 speaker GMMs"},
             "roofline": {"bound": "mfma", "achieved": flop / (g_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": flop / (g_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                         "kernel": "gmm_loglik + utt_reduce", "kernel_ms": g_ms, "algorithmic_flop_per_launch": flop},
+                         "kernel": "gmm_loglik (v_mfma_f32_32x32x2_f32) + utt_reduce", "kernel_ms": g_ms,
+                         "algorithmic_flop_per_launch": flop},
         }
-        del scorer, r
+        # bf16 hi/lo split path: 3 bf16 MFMAs per k-step, same tolerance class; priced against the dense bf16 peak with
+        # the ALGORITHMIC flops (the kernel executes 3x as many)
+        r1, g1_ms, g1_elapsed, _ = run_gmm(1)
+        sc0, sc1 = r0["scores"], r1["scores"]
+        result["gmm_bf16x3"] = {
+            "metric": "GMM frame-scores/s, bf16x3 split-precision MFMA path", "value": fscores / g1_elapsed,
+            "unit": "frame-scores/s", "ms_per_step": g1_elapsed / g_steps * 1e3, "steps": g_steps, "dtype": "bf16x3->f32",
+            "max_abs_diff_vs_fp32_path": float((sc1 - sc0).abs().max().item()),
+            "max_abs_score": float(sc0.abs().max().item()),
+            "argmax_agreement_vs_fp32_path": float((r0["argmax"] == r1["argmax"]).float().mean().item()),
+            "roofline": {"bound": "mfma", "achieved": flop / (g1_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": flop / (g1_ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
+                         "kernel": "gmm_loglik_bf16x3 (v_mfma_f32_32x32x16_bf16, 3 MFMAs per k-step) + utt_reduce",
+                         "kernel_ms": g1_ms, "algorithmic_flop_per_launch": flop, "executed_mfma_flop_per_launch": 3 * flop * 80.0 / 78.0},
+        }
+        r = r1
+        del scorer, r, r0, r1
 
     # ------------------------------------------------------------------ cosine stage (configs[4])
     if "cosine" in stages:

@@ -35,6 +35,7 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ tile, float
 struct GmmArgs {
     const float* feats;   // [F x D]
     const float* wimg;    // [n_tiles][NQ][2][32][4]  packed row tiles (32 mixtures each)
+    const char* wimg16;   // bf16x3 path: [n_tiles][NK][hi|lo][2][32][8 bf16] + [2][16] fp32 constants + pad (see pack)
     float* llT;           // [n_models x F] model-major per-frame log-likelihood
     int64_t F;            // total frames (rows of feats)
     int32_t D, n_models, tiles_per_model, n_tiles;
@@ -138,6 +139,130 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
     }
 }
 
+// ---- bf16 x 3 split-precision path (precision = 1) ---------------------------------------------------------------
+// Same contraction on v_mfma_f32_32x32x16_bf16 (16x the per-clock rate of the fp32-input MFMA): every operand is split
+// into hi = bf16(v) and lo = bf16(v - hi) and the product is accumulated as  Wh.ah + Wh.al + Wl.ah  in fp32 (the lo.lo
+// term, 2^-16 relative, is dropped) — 3 bf16 MFMAs per k-step instead of 8 fp32 ones.  The additive constant of every
+// mixture stays exact: it is the fp32 INITIAL VALUE of the accumulator, not a matrix column.  aug = [x, x^2].
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NK>
+__device__ __forceinline__ void stage_tile16(const char* __restrict__ tile, char* dst, int wave, int lane) {
+#pragma unroll
+    for (int p = 0; p < (2 * NK + 3) / 4; ++p) {
+        const int piece = wave + 4 * p;
+        if (piece < 2 * NK)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(tile + piece * 1024 + lane * 16), (lds_ptr_t)(dst + piece * 1024), 16, 0, 0);
+    }
+    if (wave == 3)  // the 64 constants (2 x 16 used + pad) ride along as one 256-byte piece
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(tile + 2 * NK * 1024 + lane * 4), (lds_ptr_t)(dst + 2 * NK * 1024), 4, 0, 0);
+}
+
+template <int NK, int CT>
+__global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_BYTES = 2 * NK * 1024 + 256;
+    constexpr int FRAMES_WG = 4 * CT * 32;
+    char* wbuf = smem;                                                 // [2][TILE_BYTES]
+    float* xs = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);        // [FRAMES_WG * D]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 31, h = lane >> 5;
+    const int D = a.D;
+    const int64_t f0 = (int64_t)blockIdx.x * FRAMES_WG;
+    const int n_valid = (int)min((int64_t)FRAMES_WG, a.F - f0);
+    {
+        const float* __restrict__ src = a.feats + f0 * D;
+        const int tot = n_valid * D;
+        for (int i = tid; i < FRAMES_WG * D; i += 256) xs[i] = i < tot ? src[i] : 0.f;
+    }
+    stage_tile16<NK>(a.wimg16, wbuf, wave, lane);
+    __syncthreads();
+
+    // B operand: lane (frame fl, half h) holds aug[frame][16 ks + 8 h + j], j = 0..7, as hi and lo bf16 fragments
+    bf16x8 bh[CT][NK], bl[CT][NK];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const float* xr = xs + (size_t)((wave * CT + ct) * 32 + fl) * D;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int ai = 16 * ks + 8 * h + jj;
+                const float xv = xr[ai < D ? ai : (ai < 2 * D ? ai - D : 0)];
+                const float v = ai < D ? xv : (ai < 2 * D ? xv * xv : 0.0f);
+                const __bf16 hi = (__bf16)v;
+                bh[ct][ks][jj] = hi;
+                bl[ct][ks][jj] = (__bf16)(v - (float)hi);
+            }
+    }
+    float run_m[CT], run_s[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        run_m[ct] = -INFINITY;
+        run_s[ct] = 0.f;
+    }
+    int rt = 0, model = 0;
+    for (int r = 0; r < a.n_tiles; ++r) {
+        const char* wcur = wbuf + (r & 1) * TILE_BYTES;
+        if (r + 1 < a.n_tiles)
+            stage_tile16<NK>(a.wimg16 + (size_t)(r + 1) * TILE_BYTES, wbuf + ((r + 1) & 1) * TILE_BYTES, wave, lane);
+        f32x16 acc[CT];
+        {
+            const f32x4* ci = reinterpret_cast<const f32x4*>(wcur + 2 * NK * 1024 + h * 64);
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const f32x4 cv = ci[c4];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    acc[ct][4 * c4 + 0] = cv[0];
+                    acc[ct][4 * c4 + 1] = cv[1];
+                    acc[ct][4 * c4 + 2] = cv[2];
+                    acc[ct][4 * c4 + 3] = cv[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wcur + (((ks * 2 + 0) * 2 + h) * 32 + fl) * 16);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(wcur + (((ks * 2 + 1) * 2 + h) * 32 + fl) * 16);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ct][ks], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ct][ks], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ct][ks], acc[ct], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float tm = acc[ct][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) tm = fmaxf(tm, acc[ct][i]);
+            const float nm = fmaxf(run_m[ct], tm);
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc += __expf(acc[ct][i] - nm);
+            run_s[ct] = run_s[ct] * __expf(run_m[ct] - nm) + sacc;
+            run_m[ct] = nm;
+        }
+        if (++rt == a.tiles_per_model) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float m2 = __shfl_xor(run_m[ct], 32), s2 = __shfl_xor(run_s[ct], 32);
+                const float mm = fmaxf(run_m[ct], m2);
+                const float ss = run_s[ct] * __expf(run_m[ct] - mm) + s2 * __expf(m2 - mm);
+                const int fidx = (wave * CT + ct) * 32 + fl;
+                if (h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = mm + logf(ss);
+                run_m[ct] = -INFINITY;
+                run_s[ct] = 0.f;
+            }
+            rt = 0;
+            ++model;
+        }
+        __syncthreads();
+    }
+}
+
 // per-utterance mean over frames (GaussianMixture.score), score differences against the UBM and arg-max
 // (GMM_UBM.py:185-187).  One workgroup per utterance, fixed summation order => bitwise reproducible.
 __global__ __launch_bounds__(256) void gmm_utt_reduce_kernel(const float* __restrict__ llT, int64_t F,
@@ -198,6 +323,20 @@ static int launch_loglik(const GmmArgs& a, hipStream_t s) {
     return SSP_OK;
 }
 
+template <int NK, int CT>
+static int launch_loglik16(const GmmArgs& a, hipStream_t s) {
+    constexpr int FRAMES_WG = 4 * CT * 32;
+    const size_t lds = (size_t)2 * (2 * NK * 1024 + 256) + (size_t)FRAMES_WG * a.D * sizeof(float);
+    const int64_t grid = ceil_div<int64_t>(a.F, FRAMES_WG);
+    if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many frames for one launch");
+    if (lds > 64 * 1024)
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_loglik_bf16x3_kernel<NK, CT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gmm_loglik_bf16x3_kernel<NK, CT>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
+}
+
 static const int kNQ[] = {4, 7, 10, 16, 24, 32};
 
 static int pick_nq(int D) {
@@ -214,6 +353,8 @@ struct ssp_gmm {
     int32_t n_models = 0, K = 0, D = 0, has_ubm = 0;
     int32_t nq = 0, tiles_per_model = 0;
     ssp::DevBuf wimg;
+    ssp::DevBuf wimg16;   // bf16 hi/lo image of the same models (precision = 1)
+    int32_t nk16 = 0;     // k-depth / 16 of the bf16 image (0: D too large for the bf16 kernels)
     ssp::DevBuf scratch;  // llT when the caller does not ask for it (grow-only)
 };
 
@@ -263,6 +404,62 @@ int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const dou
                 tile[((size_t)(q * 2 + hh) * 32 + mix) * 4 + e] = (float)w[j];
             }
         }
+    // ---- bf16 hi/lo image: [tile][ks][hi|lo][h][mix][8] bf16, then [h][16] fp32 constants in accumulator order + pad
+    auto to_bf16 = [](double v) -> uint16_t {  // round to nearest even on the fp32 bit pattern
+        float f = (float)v;
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    auto from_bf16 = [](uint16_t b) -> double {
+        uint32_t u = (uint32_t)b << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return (double)f;
+    };
+    const int nk16_need = (2 * D + 15) / 16;
+    int nk16 = 0;
+    for (int v : {1, 2, 3, 4, 5, 6, 8})
+        if (v >= nk16_need) {
+            nk16 = v;
+            break;
+        }
+    std::vector<unsigned char> img16;
+    if (nk16 > 0) {
+        const size_t tb = (size_t)2 * nk16 * 1024 + 256;
+        img16.assign(n_tiles * tb, 0);
+        for (int m = 0; m < n_models; ++m)
+            for (int k = 0; k < tpm * 32; ++k) {
+                unsigned char* tile = img16.data() + ((size_t)m * tpm + k / 32) * tb;
+                const int mix = k & 31;
+                double cst = -1.0e30;
+                std::vector<double> wv((size_t)nk16 * 16, 0.0);
+                if (k < K) {
+                    const double* mu = means + ((size_t)m * K + k) * D;
+                    const double* cv = covars + ((size_t)m * K + k) * D;
+                    cst = std::log(weights[(size_t)m * K + k]) - 0.5 * D * ln2pi;
+                    for (int d = 0; d < D; ++d) {
+                        const double P = 1.0 / cv[d];
+                        wv[d] = mu[d] * P;
+                        wv[D + d] = -0.5 * P;
+                        cst += 0.5 * std::log(P) - 0.5 * mu[d] * mu[d] * P;
+                    }
+                }
+                for (int j = 0; j < nk16 * 16; ++j) {
+                    const int ks = j >> 4, hh = (j >> 3) & 1, e = j & 7;
+                    const uint16_t hi = to_bf16(wv[j]);
+                    const uint16_t lo = to_bf16(wv[j] - from_bf16(hi));
+                    uint16_t* ph = reinterpret_cast<uint16_t*>(tile + ((((size_t)ks * 2 + 0) * 2 + hh) * 32 + mix) * 16) + e;
+                    uint16_t* pl = reinterpret_cast<uint16_t*>(tile + ((((size_t)ks * 2 + 1) * 2 + hh) * 32 + mix) * 16) + e;
+                    *ph = hi;
+                    *pl = lo;
+                }
+                // accumulator order: lane half h, register i  <->  row (i & 3) + 8 (i >> 2) + 4 h
+                const int hh = (mix >> 2) & 1, i = (mix & 3) + 4 * (mix >> 3);
+                reinterpret_cast<float*>(tile + (size_t)2 * nk16 * 1024)[hh * 16 + i] = (float)cst;
+            }
+    }
     ssp_gmm* g = new (std::nothrow) ssp_gmm;
     if (!g) SSP_FAIL(SSP_ERR_NOMEM, "gmm: host alloc");
     g->ctx = ctx;
@@ -272,7 +469,15 @@ int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const dou
     g->has_ubm = has_ubm ? 1 : 0;
     g->nq = nq;
     g->tiles_per_model = tpm;
+    g->nk16 = nk16;
     int rc = g->wimg.alloc(img.size() * sizeof(float));
+    if (rc == SSP_OK && nk16 > 0) {
+        rc = g->wimg16.alloc(img16.size());
+        if (rc == SSP_OK && hipMemcpyAsync(g->wimg16.p, img16.data(), img16.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            set_error("gmm: bf16 image upload failed");
+            rc = SSP_ERR_HIP;
+        }
+    }
     if (rc == SSP_OK) {
         hipError_t e = hipMemcpyAsync(g->wimg.p, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -305,7 +510,8 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     ssp_ctx* ctx = gmm->ctx;
     SSP_TRY(use_ctx(ctx));
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: where");
-    if (precision != 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_score: precision %d not built (0 = fp32 MFMA)", precision);
+    if (precision != 0 && precision != 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: precision must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA)");
+    if (precision == 1 && gmm->nk16 == 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_score: bf16x3 path covers D <= 64");
     if (kernel_ms) *kernel_ms = 0.f;
     const int64_t F = frame_seg->host.back();
     const int64_t n_utt = frame_seg->n;
@@ -334,6 +540,7 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     GmmArgs a{};
     a.feats = d_feats;
     a.wimg = gmm->wimg.as<float>();
+    a.wimg16 = gmm->wimg16.as<char>();
     a.llT = d_ll;
     a.F = F;
     a.D = gmm->D;
@@ -342,7 +549,18 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     a.n_tiles = M * gmm->tiles_per_model;
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, s));
-    if (F > 0) {
+    if (F > 0 && precision == 1) {
+        switch (gmm->nk16) {
+            case 1: SSP_TRY((launch_loglik16<1, 2>(a, s))); break;
+            case 2: SSP_TRY((launch_loglik16<2, 2>(a, s))); break;
+            case 3: SSP_TRY((launch_loglik16<3, 2>(a, s))); break;
+            case 4: SSP_TRY((launch_loglik16<4, 2>(a, s))); break;
+            case 5: SSP_TRY((launch_loglik16<5, 2>(a, s))); break;
+            case 6: SSP_TRY((launch_loglik16<6, 2>(a, s))); break;
+            case 8: SSP_TRY((launch_loglik16<8, 2>(a, s))); break;
+            default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no bf16 kernel for nk=%d", gmm->nk16);
+        }
+    } else if (F > 0) {
         switch (gmm->nq) {
             case 4: SSP_TRY((launch_loglik<4, 2>(a, s))); break;
             case 7: SSP_TRY((launch_loglik<7, 2>(a, s))); break;

@@ -253,15 +253,17 @@ def test_cmvn_vs_sklearn_golden(golden, ssp):
 
 
 # ----------------------------------------------------------------------------------------- GMM scoring
+# precision 0 = exact-fp32 MFMA (parity path), 1 = bf16 hi/lo split, 3 bf16 MFMAs per k-step (same tolerance class)
+@pytest.mark.parametrize("precision", [0, 1])
 @pytest.mark.parametrize("K,D", [(1, 13), (16, 26), (64, 39), (5, 7), (40, 39)])
-def test_gmm_score_samples_vs_sklearn_golden(golden, ssp, K, D):
+def test_gmm_score_samples_vs_sklearn_golden(golden, ssp, K, D, precision):
     pkg, api = ssp
     g = golden("gmm")
     ctx = api.default_context()
     sc = api.GmmScorer(ctx, g[f"w_{K}_{D}"][None], g[f"mu_{K}_{D}"][None], g[f"cov_{K}_{D}"][None], has_ubm=False)
     X = g[f"X_{K}_{D}"]
     seg = api.Segments.from_lengths(ctx, [X.shape[0]])
-    r = sc.score(X, seg, loglik=True, scores=True, argmax=False)
+    r = sc.score(X, seg, loglik=True, scores=True, argmax=False, precision=precision)
     ref = g[f"ss_{K}_{D}"]
     assert np.abs(r["loglik"][0] - ref).max() <= 1e-4 * np.abs(ref).max()
     np.testing.assert_allclose(r["loglik"][0], ref, rtol=1e-4, atol=1e-4)
@@ -296,7 +298,8 @@ def test_gmm_score_matrix_vs_reference_loop(golden, ssp):
         GMM_UBM.GMM(None, feats, y, feats, y, model=False)
 
 
-def test_gmm_cfg3_shape_vs_oracle(ssp):
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gmm_cfg3_shape_vs_oracle(ssp, precision):
     """cfg3 geometry at oracle-friendly size: D=39, K=64 UBM + 50 speaker GMMs (mean offsets), ragged utterances."""
     pkg, api = ssp
     from oracle import ref_cpu as O
@@ -314,7 +317,7 @@ def test_gmm_cfg3_shape_vs_oracle(ssp):
     ctx = api.default_context()
     sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), np.stack(mus), np.stack([cov] * (S + 1)), has_ubm=True)
     seg = api.Segments.from_lengths(ctx, lens)
-    r = sc.score(np.vstack(feats), seg, loglik=True)
+    r = sc.score(np.vstack(feats), seg, loglik=True, precision=precision)
     ref_pred, ref_am = O.score_matrix([(w, m, cov) for m in mus[1:]], (w, mu, cov), feats)
     got_pred = r["scores"][:, 1:].astype(np.float64) - r["scores"][:, :1]
     ref_scores = np.array([[O.gmm_score(w, m, cov, f) for m in mus] for f in feats])
