@@ -206,6 +206,148 @@ __global__ __launch_bounds__(256) void cosine_kernel(CosArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Register-resident variant for d <= 256 (the d-vector sizes of the reference: 128 / 256): the embeddings of a wave
+// (32 columns) stay in registers as the MFMA B operand for the whole sweep, the pre-normalised centroids stream through
+// LDS as 32-row A tiles by LDS-DMA (double buffered), so the MFMA pipe sees one ds_read_b128 per 4 MFMAs and no barrier
+// inside a tile.  Same epilogue as above.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// centroid image: [tile][q][h][row 32][e 4] = c_hat[tile*32 + row][8q + 2e + h]  (unit-norm rows, zero padded)
+__global__ __launch_bounds__(256) void cos_pack_kernel(const float* __restrict__ C, int S, int d, int nq, float* __restrict__ img) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_rows = ((S + 31) / 32) * 32;
+    if (row >= n_rows) return;
+    float ss = 0.f;
+    if (row < S)
+        for (int k = lane; k < d; k += 64) ss = fmaf(C[(size_t)row * d + k], C[(size_t)row * d + k], ss);
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float inv = 1.0f / sqrtf(ss);
+    float* tile = img + (size_t)(row >> 5) * nq * 256;
+    for (int k = lane; k < nq * 8; k += 64) {
+        const float v = (row < S && k < d) ? C[(size_t)row * d + k] * inv : 0.f;
+        tile[((size_t)((k >> 3) * 2 + (k & 1)) * 32 + (row & 31)) * 4 + ((k & 7) >> 1)] = v;
+    }
+}
+
+struct CosRegArgs {
+    const float* X;
+    const float* img;
+    float* dist;
+    int32_t* argmin;
+    float* minval;
+    int64_t N;
+    int32_t d, S, n_tiles;
+};
+
+template <int NQ>
+__global__ __launch_bounds__(256) void cosine_reg_kernel(CosRegArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_FLOATS = NQ * 256;
+    float* wbuf = reinterpret_cast<float*>(smem);  // [2][TILE_FLOATS]; the first bytes double as the X staging area
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 31, h = lane >> 5;
+    const int d = a.d;
+    const int64_t col0 = (int64_t)blockIdx.x * 128 + wave * 32;  // this wave's 32 embeddings
+
+    // ---- B operand: b[q][e] = x[col][8q + 2e + h]; staged through LDS in 64-wide k chunks so HBM reads stay coalesced
+    float b[NQ][4];
+    float ss = 0.f;
+    {
+        float* xs = wbuf + wave * (32 * 65);  // [32 rows][64 + 1 pad]
+#pragma unroll
+        for (int kc = 0; kc < NQ / 8; ++kc) {
+            for (int i = lane; i < 32 * 64; i += 64) {
+                const int r = i >> 6, k = kc * 64 + (i & 63);
+                const int64_t gc = col0 + r;
+                xs[r * 65 + (i & 63)] = (gc < a.N && k < d) ? a.X[gc * d + k] : 0.f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = xs[fl * 65 + 8 * q8 + 2 * e + h];
+                    b[kc * 8 + q8][e] = v;
+                    ss = fmaf(v, v, ss);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    ss += __shfl_xor(ss, 32);
+    const float ix = 1.0f / sqrtf(ss);
+    __syncthreads();  // staging area is about to be overwritten by tile 0
+
+    auto stage = [&](int tile, float* dst) {
+        const float* src = a.img + (size_t)tile * TILE_FLOATS;
+#pragma unroll
+        for (int p = 0; p < NQ / 4; ++p) {
+            const int piece = wave + 4 * p;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + piece * 256 + lane * 4), (lds_ptr_t)(dst + piece * 256), 16, 0, 0);
+        }
+    };
+    stage(0, wbuf);
+    __syncthreads();
+
+    float best = INFINITY;
+    int besti = 0x7fffffff;
+    const int64_t gc = col0 + fl;
+    for (int t = 0; t < a.n_tiles; ++t) {
+        const float* wcur = wbuf + (t & 1) * TILE_FLOATS;
+        if (t + 1 < a.n_tiles) stage(t + 1, wbuf + ((t + 1) & 1) * TILE_FLOATS);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(wcur + ((q * 2 + h) * 32 + fl) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b[q][e], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row < a.S) {
+                float dv = 1.0f - acc[i] * ix;
+                dv = fminf(fmaxf(dv, 0.0f), 2.0f);
+                if (a.dist && gc < a.N) a.dist[gc * a.S + row] = dv;
+                if (dv < best || (dv == best && row < besti)) {
+                    best = dv;
+                    besti = row;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const float ob = __shfl_xor(best, 32);
+    const int oi = __shfl_xor(besti, 32);
+    if (ob < best || (ob == best && oi < besti)) {
+        best = ob;
+        besti = oi;
+    }
+    if (h == 0 && gc < a.N) {
+        if (a.argmin) a.argmin[gc] = besti == 0x7fffffff ? 0 : besti;
+        if (a.minval) a.minval[gc] = best;
+    }
+}
+
+template <int NQ>
+static int launch_cos_reg(const CosRegArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * NQ * 256 * sizeof(float) > (size_t)4 * 32 * 65 * 4 ? (size_t)2 * NQ * 256 * sizeof(float) : (size_t)4 * 32 * 65 * 4;
+    const int64_t grid = ceil_div<int64_t>(a.N, 128);
+    if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
+    if (lds > 64 * 1024)
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_reg_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(cosine_reg_kernel<NQ>, dim3((unsigned)grid), dim3(256), lds, s, a);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
+}
+
 }  // namespace ssp
 
 using namespace ssp;
@@ -233,23 +375,40 @@ int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, cons
     SSP_TRY(rc);
     float* dM = (float*)sm.out(min_out, (size_t)N * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    DevBuf inc;
-    SSP_TRY(inc.alloc((size_t)S * sizeof(float)));
-    const int64_t grid = ceil_div<int64_t>(N, BN);
-    if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
-    CosArgs a{dX, dC, inc.as<float>(), dD, dA, dM, N, d, S};
-    constexpr size_t lds = (size_t)(2 * (BK / 8) * 2 * 128 * 4 + BN + 2 * BN) * sizeof(float) + 2 * BN * sizeof(int);
+    DevBuf inc, img;
     Timer tm;
-    SSP_TRY(tm.start(kernel_ms != nullptr, s));
-    hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, s, dC, (int64_t)S, d, inc.as<float>());
-    SSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(cosine_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
-    SSP_HIP(hipGetLastError());
-    SSP_TRY(tm.stop(s, kernel_ms));
+    if (d <= 256) {  // register-resident embeddings, LDS-DMA streamed centroid tiles
+        const int nq = d <= 64 ? 8 : (d <= 128 ? 16 : (d <= 192 ? 24 : 32));
+        const int n_tiles = (S + 31) / 32;
+        SSP_TRY(img.alloc((size_t)n_tiles * nq * 256 * sizeof(float)));
+        CosRegArgs ra{dX, img.as<float>(), dD, dA, dM, N, d, S, n_tiles};
+        SSP_TRY(tm.start(kernel_ms != nullptr, s));
+        hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>());
+        SSP_HIP(hipGetLastError());
+        switch (nq) {
+            case 8: SSP_TRY(launch_cos_reg<8>(ra, s)); break;
+            case 16: SSP_TRY(launch_cos_reg<16>(ra, s)); break;
+            case 24: SSP_TRY(launch_cos_reg<24>(ra, s)); break;
+            default: SSP_TRY(launch_cos_reg<32>(ra, s)); break;
+        }
+        SSP_TRY(tm.stop(s, kernel_ms));
+    } else {
+        SSP_TRY(inc.alloc((size_t)S * sizeof(float)));
+        const int64_t grid = ceil_div<int64_t>(N, BN);
+        if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
+        CosArgs a{dX, dC, inc.as<float>(), dD, dA, dM, N, d, S};
+        constexpr size_t lds = (size_t)(2 * (BK / 8) * 2 * 128 * 4 + BN + 2 * BN) * sizeof(float) + 2 * BN * sizeof(int);
+        SSP_TRY(tm.start(kernel_ms != nullptr, s));
+        hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, s, dC, (int64_t)S, d, inc.as<float>());
+        SSP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(cosine_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+        SSP_HIP(hipGetLastError());
+        SSP_TRY(tm.stop(s, kernel_ms));
+    }
     SSP_TRY(sd.back(ctx, dist_out, (size_t)N * S * sizeof(float), where));
     SSP_TRY(sa.back(ctx, argmin_out, (size_t)N * sizeof(int32_t), where));
     SSP_TRY(sm.back(ctx, min_out, (size_t)N * sizeof(float), where));
-    SSP_HIP(hipStreamSynchronize(s));  // `inc` is freed at return
+    SSP_HIP(hipStreamSynchronize(s));  // `inc` / `img` are freed at return
     return SSP_OK;
 }
 
