@@ -115,7 +115,7 @@ __device__ __forceinline__ float fast_log(const MfccArgs& a, float v) {
 // NZ: non-zero 32-sample rows of the window (13 for win <= 416, else 16); POWER: 1 magnitude | 2 power spectrum;
 // PRE: per-frame pre-emphasis on/off; FAST_WAVES: waves per workgroup
 template <int NZ, int POWER, int PRE, int FAST_WAVES>
-__global__ __launch_bounds__(64 * FAST_WAVES, FAST_WAVES == 12 ? 3 : 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
+__global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES == 6) ? 3 : 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * FAST_WAVES;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -168,32 +168,41 @@ __global__ __launch_bounds__(64 * FAST_WAVES, FAST_WAVES == 12 ? 3 : 2) void mfc
     //      Bounds-checked buffer loads: anything outside the utterance [0, N) reads as 0 = the zero padding we need.
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(N * 4), 0x00020000);
-    v2f pf[NZ];   // (x[e],   x[e+1])
-    v2f pfp[NZ];  // (x[e-1], x[e])   the "previous sample" pair of the pre-emphasis, as its own aligned register pair
+    v2f pf[NZ];   // (x[e], x[e+1])
     auto prefetch = [&](int q) {
         const int e0 = ((ta + 4 * q + g) * hop + 2 * j) * 4;  // byte offset of this lane's first element
 #pragma unroll
         for (int n1 = 0; n1 < NZ; ++n1) {
+#if (defined(SSP_ABL) && SSP_ABL >= 5) || defined(SSP_NOLOAD)
+            pf[n1] = v2f{(float)(e0 & 255) * 1e-3f, 0.5f}; continue;
+#endif
             pf[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, e0 + 128 * n1, 0, 0));
-            // aux = 1 (sc0: still served by L1) only keeps the compiler from fusing the two loads into one dwordx3,
-            // whose odd register pair would have to be re-packed with v_mov before the packed FMA
-            if (PRE) pfp[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, e0 + 128 * n1 - 4, 0, 1));
         }
     };
     prefetch(wave);
-    const v2f npre2 = v2f{-pre, -pre};
+    const float npre = -pre;
     for (int q = wave; q < nquads; q += FAST_WAVES) {
         const int t = ta + 4 * q + g;  // this lane group's frame
-        // ---- 1+2. per-frame pre-emphasis (y[0] = x[0] - a x[0], y[n] = x[n] - a x[n-1]) and window, in registers
+        // ---- 1+2. per-frame pre-emphasis (y[0] = x[0] - a x[0], y[n] = x[n] - a x[n-1]) and window, in registers.
+        //      x[e-1] is the neighbouring lane's second sample (DPP row_shr:1); lane 0 of a frame takes it from lane 15's
+        //      previous row (DPP row_ror:1), or from itself for the very first sample of the frame.
         v2f z[16];
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NZ) {
                 v2f y = pf[n1 < NZ ? n1 : 0];
                 if (PRE) {
-                    v2f pv = pfp[n1 < NZ ? n1 : 0];
-                    if (n1 == 0) pv.x = j == 0 ? y.x : pv.x;  // first sample of the frame: its own predecessor
-                    y = __builtin_elementwise_fma(npre2, pv, y);
+                    // (scalar copies first: __builtin_bit_cast on a vector ELEMENT is mis-evaluated by this clang)
+                    const float cur_x = y.x, cur_y = y.y;
+                    float prev_row_last = cur_x;
+                    if (n1 > 0) {
+                        const float last_y = pf[n1 > 0 ? n1 - 1 : 0].y;
+                        prev_row_last = __builtin_amdgcn_update_dpp(0.f, last_y, 0x121 /*row_ror:1*/, 0xF, 0xF, false);
+                    }
+                    const float xm1 = __builtin_amdgcn_update_dpp(prev_row_last, cur_y, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+                    const float y0 = __builtin_fmaf(npre, xm1, y.x);
+                    const float y1 = __builtin_fmaf(npre, y.x, y.y);
+                    y = v2f{y0, y1};
                 }
                 z[n1] = y * wreg[n1 < NZ ? n1 : 0];
             } else {
@@ -201,11 +210,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES, FAST_WAVES == 12 ? 3 : 2) void mfc
             }
         }
         // ---- 3. FFT16 over n1, twiddle W_256^(n2 k1)
+#ifndef SSP_NO_FFT1
         fft16(z);
+#endif
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], twr[k1 - 1]);
         // ---- 4. transpose through LDS
         char* zf = zbuf + g * ZFRAME;
+#if (!defined(SSP_ABL) || SSP_ABL < 3) && !defined(SSP_NO_T2)
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) *reinterpret_cast<v2f*>(zf + k1 * ZROW + j * 8) = z[k1];
 #pragma unroll
@@ -216,6 +228,12 @@ __global__ __launch_bounds__(64 * FAST_WAVES, FAST_WAVES == 12 ? 3 : 2) void mfc
         }
         // ---- 5. FFT16 over n2: lane j = k1, register = k2
         fft16(z);
+#endif
+#if (defined(SSP_ABL) && SSP_ABL >= 2) || defined(SSP_NO_SPLIT)
+        { float* P = reinterpret_cast<float*>(zf);
+#pragma unroll
+          for (int k2 = 0; k2 < 16; ++k2) P[j + 16 * k2] = z[k2].x * z[k2].x + z[k2].y * z[k2].y; }
+#else
         // ---- 6. split step.  Lane j (= k1) owns the bin pairs k = j + 16 k2 <-> 256 - k for k2 = 0..7.  Z[256 - k] lives
         //         in lane 16 - j, register 15 - k2 (lane 0: its own register 16 - k2), i.e. always in the UPPER half
         //         of the registers: only that half goes through LDS (natural order image, rows 8..15), each lane
@@ -258,8 +276,10 @@ __global__ __launch_bounds__(64 * FAST_WAVES, FAST_WAVES == 12 ? 3 : 2) void mfc
             }
             if (j == 0) P[128] = p128;
         }
+#endif
         prefetch(q + FAST_WAVES);  // next quad's samples fly under the filterbank / DCT (past the end they read zeros)
         // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads)
+#if (!defined(SSP_ABL) || SSP_ABL < 1) && !defined(SSP_NO_MEL)
         {
             const float* P = reinterpret_cast<const float*>(zf);
             float* lm = reinterpret_cast<float*>(zf + LM_OFF - 64 * g);
@@ -305,9 +325,16 @@ __global__ __launch_bounds__(64 * FAST_WAVES, FAST_WAVES == 12 ? 3 : 2) void mfc
                 if (qq < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + qq] = acc0 + acc1;
             }
         }
+#else
+        if (j < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + j] = reinterpret_cast<const float*>(zf)[j + 7];  // ablation: no filterbank / DCT
+#endif
     }
     __syncthreads();
 
+#if (defined(SSP_ABL) && SSP_ABL >= 4) || defined(SSP_NO_TAIL)
+    if (tid == 0) a.out[(size_t)(f0 + t0) * a.d_out] = s_ceps[0];
+    return;
+#endif
     // ---- delta / delta-delta from the cepstra in LDS (edge padding at utterance ends, GMM_UBM.py:64)
     const int Nd = a.delta_N;
     const float inv = a.delta_inv_denom;
@@ -332,10 +359,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES, FAST_WAVES == 12 ? 3 : 2) void mfc
         c2 = 0.f;
         if (a.delta_order == 0) return;
         if (u - 2 * Nd >= 0 && u + 2 * Nd <= T - 1) {
-            for (int k = -2 * Nd; k <= 2 * Nd; ++k) {
-                const float v = cep(u + k, qq);
-                c2 = fmaf(f.ddw[k + 2 * Nd], v, c2);
-                if (k >= -Nd && k <= Nd) c1 = fmaf((float)k * inv, v, c1);
+            // all 4N+1 neighbours are fetched first (one LDS round trip), then reduced from registers (delta_N <= 4)
+            float cv[17];
+#pragma unroll
+            for (int k = 0; k < 17; ++k) cv[k] = (k >= 8 - 2 * Nd && k <= 8 + 2 * Nd) ? cep(u + k - 8, qq) : 0.f;
+#pragma unroll
+            for (int k = 0; k < 17; ++k) {
+                c2 = fmaf(f.ddw[min(max(k - 8 + 2 * Nd, 0), 16)], cv[k], c2);  // cv[k] == 0 outside the 4N+1 window
+                if (k >= 8 - Nd && k <= 8 + Nd) c1 = fmaf((float)(k - 8) * inv, cv[k], c1);
             }
         } else {
             c1 = dl(u, qq);
@@ -343,55 +374,70 @@ __global__ __launch_bounds__(64 * FAST_WAVES, FAST_WAVES == 12 ? 3 : 2) void mfc
         }
     };
     float* __restrict__ out = a.out + (size_t)(f0 + t0) * D;
-    // thread -> (row r, cepstral index qq): 16 qq lanes x NT/16 rows per sweep; each thread emits c, delta, delta-delta
+    // ---- output: blocks of rows are assembled as a contiguous (rows x D) image in the waves' transpose LDS (idle by
+    //      now) and leave with 16-byte coalesced stores; thread -> (row, cepstral index) emits c, delta, delta-delta.
+    float* obuf = reinterpret_cast<float*>(smem + f.off_wave);
+    const int rows_blk = max(1, (FAST_WAVES * f.wave_bytes) / (D * 4));
     const int qsub = tid & 15, rsub = tid >> 4;
-    if (!a.cmvn) {
+    if (a.cmvn) {
+        // per-utterance CMVN: (x - mean) / std per output dimension, ddof = 0, std < 10 eps -> 1 (sklearn scale)
+        auto value = [&](int r, int d) -> float {
+            const int blk = d / nc, qq = d - blk * nc;
+            float c0, c1, c2;
+            emit(t0 + r, qq, c0, c1, c2);
+            return blk == 0 ? c0 : (blk == 1 ? c1 : c2);
+        };
+        for (int d = wave; d < D; d += FAST_WAVES) {
+            float s = 0.f;
+            for (int r = lane; r < n; r += 64) s += value(r, d);
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s / (float)n;
+            float v = 0.f;
+            for (int r = lane; r < n; r += 64) {
+                const float e = value(r, d) - mean;
+                v = fmaf(e, e, v);
+            }
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            float sd = sqrtf(v / (float)n);
+            if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;
+            if (lane == 0) {
+                s_stats[d] = mean;
+                s_stats[D + d] = 1.0f / sd;
+            }
+        }
+        __syncthreads();
+    }
+    for (int r0 = 0; r0 < n; r0 += rows_blk) {
+        const int nr = min(rows_blk, n - r0);
         for (int qq = qsub; qq < nc; qq += 16)
-            for (int r = rsub; r < n; r += NT / 16) {
+            for (int r = rsub; r < nr; r += NT / 16) {
                 float c0, c1, c2;
-                emit(t0 + r, qq, c0, c1, c2);
-                float* o = out + (size_t)r * D + qq;
+                emit(t0 + r0 + r, qq, c0, c1, c2);
+                float* o = obuf + (size_t)r * D + qq;
+                if (a.cmvn) {
+                    c0 = (c0 - s_stats[qq]) * s_stats[D + qq];
+                    if (a.delta_order >= 1) c1 = (c1 - s_stats[nc + qq]) * s_stats[D + nc + qq];
+                    if (a.delta_order >= 2) c2 = (c2 - s_stats[2 * nc + qq]) * s_stats[D + 2 * nc + qq];
+                }
                 o[0] = c0;
                 if (a.delta_order >= 1) o[nc] = c1;
                 if (a.delta_order >= 2) o[2 * nc] = c2;
             }
-        return;
+        __syncthreads();
+        // coalesced copy of nr * D floats: scalar head up to a 16-byte boundary of the destination, float4 body, scalar tail
+        float* dst = out + (size_t)r0 * D;
+        const int tot = nr * D;
+        const int head = min(tot, (int)(((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15) >> 2));
+        if (tid < head) dst[tid] = obuf[tid];
+        const int nvec = (tot - head) >> 2;
+        for (int i = tid; i < nvec; i += NT) {
+            const float* sp = obuf + head + 4 * i;
+            *reinterpret_cast<v4f*>(dst + head + 4 * i) = v4f{sp[0], sp[1], sp[2], sp[3]};
+        }
+        const int done = head + 4 * nvec;
+        if (tid < tot - done) dst[done + tid] = obuf[done + tid];
+        __syncthreads();
     }
-    // per-utterance CMVN: (x - mean) / std per output dimension, ddof = 0, std < 10 eps -> 1 (sklearn scale)
-    auto value = [&](int r, int d) -> float {
-        const int blk = d / nc, qq = d - blk * nc;
-        float c0, c1, c2;
-        emit(t0 + r, qq, c0, c1, c2);
-        return blk == 0 ? c0 : (blk == 1 ? c1 : c2);
-    };
-    for (int d = wave; d < D; d += FAST_WAVES) {
-        float s = 0.f;
-        for (int r = lane; r < n; r += 64) s += value(r, d);
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float mean = s / (float)n;
-        float v = 0.f;
-        for (int r = lane; r < n; r += 64) {
-            const float e = value(r, d) - mean;
-            v = fmaf(e, e, v);
-        }
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        float sd = sqrtf(v / (float)n);
-        if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;
-        if (lane == 0) {
-            s_stats[d] = mean;
-            s_stats[D + d] = 1.0f / sd;
-        }
-    }
-    __syncthreads();
-    for (int qq = qsub; qq < nc; qq += 16)
-        for (int r = rsub; r < n; r += NT / 16) {
-            float c0, c1, c2;
-            emit(t0 + r, qq, c0, c1, c2);
-            float* o = out + (size_t)r * D + qq;
-            o[0] = (c0 - s_stats[qq]) * s_stats[D + qq];
-            if (a.delta_order >= 1) o[nc] = (c1 - s_stats[nc + qq]) * s_stats[D + nc + qq];
-            if (a.delta_order >= 2) o[2 * nc] = (c2 - s_stats[2 * nc + qq]) * s_stats[D + 2 * nc + qq];
-        }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
