@@ -104,6 +104,19 @@ int ssp_mfcc_frame_segments(ssp_mfcc_plan* plan, const ssp_segments* sample_seg,
 int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
                  const float* samples, float* feats_out, int where, int variant, float* kernel_ms);
 
+/* ---- stand-alone framing and cepstrum steps of the in-repo dialect (kept for API parity; ssp_mfcc_run fuses them) ---- */
+/* utils.processing.enframe (utils/processing.py:19-38): frame i = x[i*step : i*step+frame_size], zero padded tail, times
+ * window; n_frames = ceil(n/step).  frames_out: float[frame_size x n_frames] row-major, exactly the reference's
+ * ndarray (element (k, i) = windowed sample k of frame i). */
+int ssp_enframe(ssp_ctx* ctx, const float* samples, int64_t n, int32_t frame_size, int32_t step, const float* window /* HOST float[frame_size] */,
+                float* frames_out, int where, float* kernel_ms);
+/* utils.processing.stMFCC (utils/processing.py:91-107) on a batch of spectra: out = DCT(log(X . fbank^T (+eps | floor)))
+ * X: float[n_rows x n_bins]; fbank: HOST float[n_filt x n_bins]; dct: HOST float[n_ceps x n_filt]; out: float[n_rows x n_ceps].
+ * log_mode / floor_mode / eps as in ssp_mfcc_cfg. */
+int ssp_cepstrum(ssp_ctx* ctx, const float* X, int64_t n_rows, int32_t n_bins, const float* fbank, int32_t n_filt,
+                 const float* dct, int32_t n_ceps, int32_t log_mode, int32_t floor_mode, float eps, float* out, int where,
+                 float* kernel_ms);
+
 /* ---- stand-alone delta / CMVN on feature matrices (GMM_UBM.delta, preprocessing.scale) - */
 int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim, int32_t N,
               float* out, int where, float* kernel_ms);

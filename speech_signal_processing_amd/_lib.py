@@ -49,6 +49,9 @@ SIGNATURES = {
     "ssp_mfcc_out_dim": (C.c_int, [C.POINTER(ssp_mfcc_cfg), C.POINTER(C.c_int32)]),
     "ssp_mfcc_frame_segments": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "ssp_mfcc_run": (C.c_int, [_P, _P, _P, _F32P, _F32P, C.c_int, C.c_int, _MSP]),
+    "ssp_enframe": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, C.c_int32, _F32P, _F32P, C.c_int, _MSP]),
+    "ssp_cepstrum": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, C.c_int32, _F32P, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_float, _F32P, C.c_int, _MSP]),
     "ssp_delta": (C.c_int, [_P, _F32P, _P, C.c_int32, C.c_int32, _F32P, C.c_int, _MSP]),
     "ssp_cmvn": (C.c_int, [_P, _F32P, _P, C.c_int32, _F32P, C.c_int, _MSP]),
     "ssp_gmm_pack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.POINTER(_P)]),

@@ -197,6 +197,38 @@ class MfccPlan:
             pass
 
 
+def enframe(ctx: Context, samples, frame_size: int, step: int, window):
+    """(frame_size, ceil(n/step)) float32 frames, zero padded tail, times window — utils/processing.py:19-38."""
+    keep, ptr, where = _as_f32(samples, "samples")
+    if keep.ndim != 1:
+        raise ValueError("samples must be 1-D")
+    n = int(keep.shape[0])
+    n_frames = -(-n // step)
+    w = np.ascontiguousarray(window, dtype=np.float32)
+    if w.shape != (frame_size,):
+        raise ValueError("window must have frame_size taps")
+    out = ctx._empty((frame_size, n_frames), where)
+    optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
+    _lib.check(ctx._lib.ssp_enframe(ctx._h, ptr, n, int(frame_size), int(step), w.ctypes.data, optr, where, None))
+    return out
+
+
+def cepstrum(ctx: Context, X, fbank, dct, log_mode: int, floor_mode: int, eps: float):
+    """DCT(log(X . fbank^T)) per row of X — utils/processing.py:91-107 on a batch of spectra."""
+    keep, ptr, where = _as_f32(X, "X")
+    if keep.ndim != 2:
+        raise ValueError("X must be (rows, bins)")
+    fb = np.ascontiguousarray(fbank, dtype=np.float32)
+    dc = np.ascontiguousarray(dct, dtype=np.float32)
+    if fb.ndim != 2 or fb.shape[1] != keep.shape[1] or dc.shape != (dc.shape[0], fb.shape[0]):
+        raise ValueError("fbank must be (n_filt, bins) and dct (n_ceps, n_filt)")
+    out = ctx._empty((int(keep.shape[0]), dc.shape[0]), where)
+    optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
+    _lib.check(ctx._lib.ssp_cepstrum(ctx._h, ptr, int(keep.shape[0]), int(keep.shape[1]), fb.ctypes.data, fb.shape[0], dc.ctypes.data,
+                                     dc.shape[0], int(log_mode), int(floor_mode), float(eps), optr, where, None))
+    return out
+
+
 def delta_features(ctx: Context, feats, frame_seg: Segments, N: int = 2, timing: bool = False):
     keep, ptr, where = _as_f32(feats, "feats")
     if keep.ndim != 2:

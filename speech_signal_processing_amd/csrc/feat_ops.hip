@@ -72,11 +72,113 @@ __global__ __launch_bounds__(256) void cmvn_kernel(const float* __restrict__ in,
     }
 }
 
+// utils/processing.py:19-38 — framing + window; out is row-major (frame_size, n_frames) like the reference ndarray
+__global__ __launch_bounds__(256) void enframe_kernel(const float* __restrict__ x, int64_t n, int frame_size, int step,
+                                                      int64_t n_frames, const float* __restrict__ window,
+                                                      float* __restrict__ out) {
+    const int64_t total = (int64_t)frame_size * n_frames;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t k = i / n_frames, fr = i - k * n_frames;  // element (k, fr)
+        const int64_t src = fr * step + k;
+        out[i] = src < n ? x[src] * window[k] : 0.0f;
+    }
+}
+
+// utils/processing.py:91-107 — one workgroup per spectrum row: filterbank dot products, log, DCT rows
+__global__ __launch_bounds__(256) void cepstrum_kernel(const float* __restrict__ X, int n_bins, const float* __restrict__ fbank,
+                                                       int n_filt, const float* __restrict__ dct, int n_ceps, int log_mode,
+                                                       int floor_mode, float eps, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lm = reinterpret_cast<float*>(smem);
+    const int64_t row = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* __restrict__ xr = X + row * n_bins;
+    for (int jf = wave; jf < n_filt; jf += 4) {
+        const float* __restrict__ w = fbank + (size_t)jf * n_bins;
+        float acc = 0.f;
+        for (int k = lane; k < n_bins; k += 64) acc = fmaf(xr[k], w[k], acc);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) {
+            float v = acc;
+            if (floor_mode == 1) v += eps;
+            else if (floor_mode == 2) v = fmaxf(v, eps);
+            lm[jf] = log_mode == 0 ? logf(v) : (log_mode == 1 ? log10f(v) : 10.0f * log10f(v));
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < n_ceps; q += 256) {
+        const float* __restrict__ d = dct + (size_t)q * n_filt;
+        float acc = 0.f;
+        for (int jf = 0; jf < n_filt; ++jf) acc = fmaf(lm[jf], d[jf], acc);
+        out[row * n_ceps + q] = acc;
+    }
+}
+
 }  // namespace ssp
 
 using namespace ssp;
 
 extern "C" {
+
+int ssp_enframe(ssp_ctx* ctx, const float* samples, int64_t n, int32_t frame_size, int32_t step, const float* window,
+                float* frames_out, int where, float* kernel_ms) {
+    SSP_TRY(use_ctx(ctx));
+    if (n < 0 || frame_size < 1 || step < 1 || !window) SSP_FAIL(SSP_ERR_INVALID, "ssp_enframe: bad argument");
+    if (kernel_ms) *kernel_ms = 0.f;
+    const int64_t n_frames = (n + step - 1) / step;  // math.ceil(wlen / step), utils/processing.py:27
+    if (n_frames == 0) return SSP_OK;
+    if (!samples || !frames_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_enframe: null data pointer");
+    const size_t out_bytes = (size_t)frame_size * n_frames * sizeof(float);
+    Staged sin, sout, sw;
+    int rc;
+    const float* d_in = (const float*)sin.in(ctx, samples, (size_t)n * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    const float* d_w = (const float*)sw.in(ctx, window, (size_t)frame_size * sizeof(float), SSP_HOST, &rc);
+    SSP_TRY(rc);
+    float* d_out = (float*)sout.out(frames_out, out_bytes, where, &rc);
+    SSP_TRY(rc);
+    const int grid = (int)std::min<int64_t>(ceil_div<int64_t>((int64_t)frame_size * n_frames, 256), (int64_t)ctx->num_cu * 8);
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
+    hipLaunchKernelGGL(enframe_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_in, n, frame_size, step, n_frames, d_w, d_out);
+    SSP_HIP(hipGetLastError());
+    SSP_TRY(tm.stop(ctx->stream, kernel_ms));
+    SSP_TRY(sout.back(ctx, frames_out, out_bytes, where));
+    SSP_HIP(hipStreamSynchronize(ctx->stream));  // the staged window copy dies at return
+    return SSP_OK;
+}
+
+int ssp_cepstrum(ssp_ctx* ctx, const float* X, int64_t n_rows, int32_t n_bins, const float* fbank, int32_t n_filt,
+                 const float* dct, int32_t n_ceps, int32_t log_mode, int32_t floor_mode, float eps, float* out, int where,
+                 float* kernel_ms) {
+    SSP_TRY(use_ctx(ctx));
+    if (n_rows < 0 || n_bins < 1 || n_filt < 1 || n_filt > 4096 || n_ceps < 1 || !fbank || !dct || log_mode < 0 || log_mode > 2 ||
+        floor_mode < 0 || floor_mode > 2)
+        SSP_FAIL(SSP_ERR_INVALID, "ssp_cepstrum: bad argument");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n_rows == 0) return SSP_OK;
+    if (!X || !out) SSP_FAIL(SSP_ERR_INVALID, "ssp_cepstrum: null data pointer");
+    if (n_rows > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_cepstrum: too many rows");
+    Staged sx, so, sf, sd;
+    int rc;
+    const float* dX = (const float*)sx.in(ctx, X, (size_t)n_rows * n_bins * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    const float* dF = (const float*)sf.in(ctx, fbank, (size_t)n_filt * n_bins * sizeof(float), SSP_HOST, &rc);
+    SSP_TRY(rc);
+    const float* dD = (const float*)sd.in(ctx, dct, (size_t)n_ceps * n_filt * sizeof(float), SSP_HOST, &rc);
+    SSP_TRY(rc);
+    float* dO = (float*)so.out(out, (size_t)n_rows * n_ceps * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
+    hipLaunchKernelGGL(cepstrum_kernel, dim3((unsigned)n_rows), dim3(256), (size_t)n_filt * sizeof(float), ctx->stream, dX, n_bins, dF,
+                       n_filt, dD, n_ceps, log_mode, floor_mode, eps, dO);
+    SSP_HIP(hipGetLastError());
+    SSP_TRY(tm.stop(ctx->stream, kernel_ms));
+    SSP_TRY(so.back(ctx, out, (size_t)n_rows * n_ceps * sizeof(float), where));
+    SSP_HIP(hipStreamSynchronize(ctx->stream));  // staged tables die at return
+    return SSP_OK;
+}
 
 int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim, int32_t N, float* out,
               int where, float* kernel_ms) {

@@ -6,7 +6,6 @@ done by the fused HIP MFCC kernel through the C-ABI (include/ssp.h).  No CPU fal
 from __future__ import annotations
 
 import functools
-import math
 
 import numpy as np
 
@@ -28,25 +27,22 @@ def mfccInitFilterBanks(fs, nfft):
 
 
 def enframe(wavData, frameSize=400, step=160):
-    """utils/processing.py:19-38 — (frameSize, ceil(N/step)) float64, zero padded tail, symmetric Hamming applied.
-
-    Framing is pure data movement (no arithmetic beyond the window multiply); it is the first stage of the fused
-    kernel and is exposed here as a strided host view for API completeness."""
-    x = np.asarray(wavData, dtype=np.float64)
-    wlen = x.shape[0]
-    n_frames = math.ceil(wlen / step)
-    padded = np.zeros((n_frames - 1) * step + frameSize if n_frames else 0)
-    padded[: min(wlen, padded.shape[0])] = x[: padded.shape[0]]
-    view = np.lib.stride_tricks.as_strided(padded, shape=(frameSize, n_frames),
-                                           strides=(padded.strides[0], padded.strides[0] * step), writeable=False)
-    return view * np.hamming(frameSize)[:, None]
+    """utils/processing.py:19-38 — (frameSize, ceil(N/step)) float64, zero padded tail, symmetric Hamming applied
+    (pre-emphasis is a commented-out line in the reference and is not applied).  Runs on the GPU (ssp_enframe)."""
+    x = np.ascontiguousarray(np.asarray(wavData).reshape(-1), dtype=np.float32)
+    frames = api.enframe(api.default_context(), x, int(frameSize), int(step), np.hamming(frameSize))
+    return np.asarray(frames, dtype=np.float64)
 
 
 def stMFCC(X, fbank, n_mfcc_feats):
-    """utils/processing.py:91-107 — cepstrum of ONE magnitude spectrum (host; a 40x512 mat-vec + 40-point DCT).
-    Kept for signature parity; bulk extraction goes through MFCC()."""
-    mspec = np.log10(np.dot(X, np.asarray(fbank).T) + eps)
-    return np.dot(mspec, frontend.dct2_ortho(mspec.shape[-1], 0, n_mfcc_feats).T)
+    """utils/processing.py:91-107 — ceps = DCT-II_ortho(log10(X . fbank^T + 1e-8))[:n_mfcc_feats] for one spectrum X
+    (or a batch on the leading axis).  Runs on the GPU (ssp_cepstrum)."""
+    X = np.asarray(X)
+    fbank = np.asarray(fbank)
+    rows = np.ascontiguousarray(X.reshape(-1, X.shape[-1]), dtype=np.float32)
+    dct = frontend.dct2_ortho(fbank.shape[0], 0, int(n_mfcc_feats))
+    out = api.cepstrum(api.default_context(), rows, fbank, dct, frontend.LOG_LOG10, frontend.FLOOR_ADD_EPS, eps)
+    return np.asarray(out, dtype=np.float64).reshape(X.shape[:-1] + (int(n_mfcc_feats),))
 
 
 def MFCC(raw_signal, fs=8000, frameSize=512, step=256):

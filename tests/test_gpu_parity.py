@@ -74,8 +74,16 @@ def test_enframe_and_tables(golden, ssp):
     g = golden("mfcc_inrepo")
     for n in SIGNALS:
         x = g[f"x_{n}"].astype(np.float64)
-        np.testing.assert_allclose(P.enframe(x, 400, 160), g[f"enframe_{n}_400_160"], rtol=1e-14, atol=1e-13)
-    np.testing.assert_allclose(P.stMFCC(g["stmfcc_X"], g["fbank_8000_512"], 13), g["stmfcc_out"], atol=1e-11)
+        for L, st in [(400, 160), (512, 256)]:
+            ref = g[f"enframe_{n}_{L}_{st}"]
+            got = P.enframe(x, L, st)
+            assert got.shape == ref.shape and got.dtype == np.float64
+            np.testing.assert_allclose(got, ref, rtol=2e-7, atol=2e-7 * max(1.0, np.abs(ref).max()))  # fp32 product
+    got = P.stMFCC(g["stmfcc_X"], g["fbank_8000_512"], 13)
+    assert got.shape == (13,)
+    np.testing.assert_allclose(got, g["stmfcc_out"], rtol=0, atol=1e-4)
+    batch = P.stMFCC(np.stack([g["stmfcc_X"], 2 * g["stmfcc_X"]]), g["fbank_8000_512"], 13)
+    np.testing.assert_allclose(batch[0], g["stmfcc_out"], rtol=0, atol=1e-4)
 
 
 # ----------------------------------------------------------------------------------------- sidekit / librosa presets vs oracle
