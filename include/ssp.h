@@ -142,6 +142,12 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
  *      (d_vector.py:315-319, 346-361) ---- */
 /* X: float[N x d]; C: float[S x d]; dist_out (nullable): float[N x S] = clip(1 - cos, 0, 2);
  * argmin_out (nullable): int32[N] (first index on ties); min_out (nullable): float[N]. */
+/* per-speaker centroids avg[s] = mean(X[labels == s]) with a float64 accumulator in row order (d_vector.py:310-313,
+ * and nn_model.enroll d_vector.py:331 with one label).  X: float[N x d]; labels: int32[N] in [0, S); out: float[S x d]
+ * (a speaker without rows gives NaN like numpy's mean of an empty slice). */
+int ssp_centroids(ssp_ctx* ctx, const float* X, const int32_t* labels, int64_t N, int32_t d, int32_t S, float* out,
+                  int where, float* kernel_ms);
+
 int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S,
                         float* dist_out, int32_t* argmin_out, float* min_out, int where, float* kernel_ms);
 

@@ -326,6 +326,26 @@ class GmmScorer:
             pass
 
 
+def centroids(ctx: Context, X, labels, num: int):
+    """avg[s] = mean(X[labels == s]) (float64 accumulator, row order) — d_vector.py:310-313."""
+    keep, ptr, where = _as_f32(X, "X")
+    if keep.ndim != 2:
+        raise ValueError("X must be (N, d)")
+    if where == _lib.DEVICE:
+        import torch
+        lab = labels.to(torch.int32).contiguous()
+        lptr = lab.data_ptr()
+    else:
+        lab = np.ascontiguousarray(labels, dtype=np.int32)
+        lptr = lab.ctypes.data
+    if int(lab.shape[0]) != int(keep.shape[0]):
+        raise ValueError("one label per row of X")
+    out = ctx._empty((int(num), int(keep.shape[1])), where)
+    optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
+    _lib.check(ctx._lib.ssp_centroids(ctx._h, ptr, lptr, int(keep.shape[0]), int(keep.shape[1]), int(num), optr, where, None))
+    return out
+
+
 def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True, minval: bool = True,
                     timing: bool = False) -> dict:
     """dist[i,j] = clip(1 - cos(X[i], C[j]), 0, 2); argmin over j (first index on ties) — d_vector.py:315-319."""

@@ -348,11 +348,55 @@ static int launch_cos_reg(const CosRegArgs& a, hipStream_t s) {
     return SSP_OK;
 }
 
+// d_vector.py:310-313 — one workgroup per speaker; every thread owns output dimensions and walks the rows in order
+// (fixed summation order, float64 accumulator like numpy's mean on the reference's float64 `avg`)
+__global__ __launch_bounds__(256) void centroid_kernel(const float* __restrict__ X, const int32_t* __restrict__ labels, int64_t N, int d,
+                                                       float* __restrict__ out) {
+    const int s = blockIdx.x;
+    for (int k0 = 0; k0 < d; k0 += 256) {
+        const int k = k0 + threadIdx.x;
+        double acc = 0.0;
+        int64_t cnt = 0;
+        for (int64_t r = 0; r < N; ++r) {
+            if (labels[r] == s) {  // uniform across the workgroup
+                ++cnt;
+                if (k < d) acc += (double)X[r * d + k];
+            }
+        }
+        if (k < d) out[(size_t)s * d + k] = (float)(acc / (double)cnt);
+    }
+}
+
 }  // namespace ssp
 
 using namespace ssp;
 
 extern "C" {
+
+int ssp_centroids(ssp_ctx* ctx, const float* X, const int32_t* labels, int64_t N, int32_t d, int32_t S, float* out, int where,
+                  float* kernel_ms) {
+    SSP_TRY(use_ctx(ctx));
+    if (N < 0 || d < 1 || S < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_centroids: bad shape");
+    if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_centroids: where");
+    if (!out || (N > 0 && (!X || !labels))) SSP_FAIL(SSP_ERR_INVALID, "ssp_centroids: null pointer");
+    if (kernel_ms) *kernel_ms = 0.f;
+    Staged sx, sl, so;
+    int rc;
+    const float* dX = (const float*)sx.in(ctx, X, (size_t)N * d * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    const int32_t* dL = (const int32_t*)sl.in(ctx, labels, (size_t)N * sizeof(int32_t), where, &rc);
+    SSP_TRY(rc);
+    float* dO = (float*)so.out(out, (size_t)S * d * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
+    hipLaunchKernelGGL(centroid_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, dX, dL, N, d, dO);
+    SSP_HIP(hipGetLastError());
+    SSP_TRY(tm.stop(ctx->stream, kernel_ms));
+    SSP_TRY(so.back(ctx, out, (size_t)S * d * sizeof(float), where));
+    if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(ctx->stream));
+    return SSP_OK;
+}
 
 int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,
                         int32_t* argmin_out, float* min_out, int where, float* kernel_ms) {

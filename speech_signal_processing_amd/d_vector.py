@@ -75,12 +75,9 @@ class nn_model:
     def test(self, X_train, Y_train, X_val, Y_val):
         """d_vector.py:296-320: per-speaker centroids of X_train (one-hot Y_train), cosine distance of every
         X_val row to every centroid, accuracy of the arg-min."""
-        X_train = np.asarray(X_train)
         num = Y_train.shape[1]
-        lab = np.argmax(Y_train, axis=1)
-        avg = np.zeros((num, X_train.shape[1]))
-        for i in range(num):  # segmented mean, float64 accumulator (d_vector.py:310-313); S small rows, host-side
-            avg[i, :] = X_train[lab == i].mean(axis=0)
+        lab = np.argmax(Y_train, axis=1)  # decoding the one-hot labels is index bookkeeping, not arithmetic
+        avg = np.asarray(api.centroids(api.default_context(), np.asarray(X_train, dtype=np.float32), lab, num))
         pred = identify(np.asarray(X_val, dtype=np.float32), avg)
         return (np.argmax(Y_val, axis=1) == pred).sum() / X_val.shape[0]
 
@@ -88,7 +85,8 @@ class nn_model:
         """d_vector.py:322-344: store the mean embedding under ``name`` (overwrites, like the reference)."""
         if name in self.d_vector:
             print("sample already exists")
-        self.d_vector[name] = np.asarray(X_train).mean(axis=0)
+        X = np.asarray(X_train, dtype=np.float32)
+        self.d_vector[name] = np.asarray(api.centroids(api.default_context(), X, np.zeros(len(X), np.int32), 1))[0]
 
     def eval(self, target):
         """d_vector.py:346-361: linear scan in dict order; the minimum is kept only while < 1; returns the name or None."""
