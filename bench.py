@@ -299,7 +299,7 @@ def main():
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline_mfcc(2000, n_samp, fs)
+        result["cpu_baseline"] = cpu_baseline_mfcc(20000, n_samp, fs)
         if "gmm" in result:
             result["gmm"]["cpu_baseline"] = cpu_baseline_gmm(plan.d_out, 64, 51)
         if "cosine" in result:

@@ -118,6 +118,7 @@ template <int NZ, int POWER, int PRE, int FAST_WAVES>
 __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES == 6) ? 3 : 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * FAST_WAVES;
+    constexpr bool TABREG = FAST_WAVES != 12;  // 3 waves/SIMD (12-wave workgroup) has no registers to spare: tables in LDS
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-level control flow stays on the SALU
     const int g = lane >> 4, j = lane & 15;
@@ -135,15 +136,26 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     // ---- shared tables -> LDS
     // this lane's window taps stay in registers for the whole kernel: w[32 n1 + 2 j], w[32 n1 + 2 j + 1]
     v2f wreg[NZ];
+    float* s_win = reinterpret_cast<float*>(smem + f.off_win);
+    v2f* s_tw16 = reinterpret_cast<v2f*>(smem + f.off_tw16);
+    v2f* s_wpost = reinterpret_cast<v2f*>(smem + f.off_wpost);
+    if (TABREG) {
 #pragma unroll
-    for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
+        for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
+    } else {
+        for (int i = tid; i < 512; i += NT) s_win[i] = a.window[i];
+        for (int i = tid; i < 240; i += NT) s_tw16[i] = *reinterpret_cast<const v2f*>(&f.tw16[16 + i]);
+        for (int i = tid; i < 128; i += NT) s_wpost[i] = *reinterpret_cast<const v2f*>(&f.wpost[i]);
+    }
     // this lane's twiddles stay in registers: W_256^(k1 j) for the step between the two radix-16 passes and
     // W_512^(8j+1+i) for the split step (LDS is the busiest unit of this kernel; registers are not)
     v2f twr[15], wpr[8];
+    if (TABREG) {
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
+        for (int k1 = 1; k1 < 16; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);  // W_512^(j + 16 i)
+        for (int i = 0; i < 8; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);  // W_512^(j + 16 i)
+    }
     for (int i = tid; i < f.total_steps * 64; i += NT) s_melw[i] = f.melw[i];
     for (int i = tid; i < f.n_pass * 16; i += NT) s_melpk[i] = f.mel_lo[i] | ((f.mel_id[i] + 1) << 16);
     for (int i = tid; i < f.n_filt4 * 4 * f.q_pass * 16; i += NT) s_dct[i] = f.dctT[i];
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
                     const float y1 = __builtin_fmaf(npre, y.x, y.y);
                     y = v2f{y0, y1};
                 }
-                z[n1] = y * wreg[n1 < NZ ? n1 : 0];
+                z[n1] = y * (TABREG ? wreg[n1 < NZ ? n1 : 0] : *reinterpret_cast<const v2f*>(s_win + 32 * n1 + 2 * j));
             } else {
                 z[n1] = v2f{0.f, 0.f};
             }
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         fft16(z);
 #endif
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], twr[k1 - 1]);
+        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], TABREG ? twr[k1 - 1] : s_tw16[(k1 - 1) * 16 + j]);
         // ---- 4. transpose through LDS
         char* zf = zbuf + g * ZFRAME;
 #if (!defined(SSP_ABL) || SSP_ABL < 3) && !defined(SSP_NO_T2)
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
                 const v2f zk = z[k2];
-                const v2f w = wpr[k2];                                                  // W_512^(j + 16 k2)
+                const v2f w = TABREG ? wpr[k2] : s_wpost[k2 * 16 + j];                  // W_512^(j + 16 k2)
                 const v2f e = __builtin_elementwise_fma(zm[k2], v2f{1.f, -1.f}, zk);   // 2E = Z[k] + conj Z[256-k]
                 const v2f d = __builtin_elementwise_fma(zm[k2], v2f{-1.f, 1.f}, zk);   // 2D = Z[k] - conj Z[256-k]
                 const v2f o = cmul(swap(d) * v2f{1.f, -1.f}, w);                       // 2 (-i D) W^k
@@ -617,9 +629,9 @@ int mfcc_fast_waves() {
 size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     const int H = c.delta_order * c.delta_N;
     size_t off = 0;
-    f.off_win = 0;
-    f.off_tw16 = 0;
-    f.off_wpost = 0;
+    f.off_win = (int32_t)off;    off = al16(off + (mfcc_fast_waves() == 12 ? 512 * 4 : 0));
+    f.off_tw16 = (int32_t)off;   off = al16(off + (mfcc_fast_waves() == 12 ? 240 * 8 : 0));
+    f.off_wpost = (int32_t)off;  off = al16(off + (mfcc_fast_waves() == 12 ? 128 * 8 : 0));
     f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 64 * 4);
     f.off_mello = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
     f.off_melid = f.off_mello;

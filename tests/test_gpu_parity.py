@@ -337,6 +337,27 @@ def test_gmm_cfg3_shape_vs_oracle(ssp, precision):
     np.testing.assert_allclose(r["loglik"][3], ll_ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gmm_cfg4_shape_512_mixtures(ssp, precision):
+    """configs[3] geometry at oracle-friendly size: 512-mixture UBM + speaker models (16 row tiles per model, online LSE)."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(21)
+    K, D, S = 512, 39, 3
+    w = rng.dirichlet(2 * np.ones(K))
+    mu = rng.standard_normal((K, D)) * 2
+    cov = rng.uniform(0.3, 2.0, (K, D))
+    mus = [mu] + [mu + 0.2 * rng.standard_normal((K, D)) for _ in range(S)]
+    lens = np.array([37, 1, 300, 64])
+    feats = [(mus[1 + j % S][rng.choice(K, size=n, p=w)] + rng.standard_normal((n, D))).astype(np.float32) for j, n in enumerate(lens)]
+    ctx = api.default_context()
+    sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), np.stack(mus), np.stack([cov] * (S + 1)), has_ubm=True)
+    r = sc.score(np.vstack(feats), api.Segments.from_lengths(ctx, lens), loglik=True, precision=precision)
+    ref = np.array([[O.gmm_score(w, m, cov, f) for m in mus] for f in feats])
+    np.testing.assert_allclose(r["scores"], ref, rtol=1e-4)
+    np.testing.assert_allclose(r["loglik"][2], O.gmm_score_samples(w, mus[2], cov, np.vstack(feats)), rtol=1e-4, atol=1e-4)
+
+
 def test_gmm_batch_permutation_property(ssp):
     """Utterances are independent: permuting them permutes the outputs bit-exactly; the frame mean is reproducible."""
     pkg, api = ssp
