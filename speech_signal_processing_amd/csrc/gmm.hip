@@ -41,6 +41,35 @@ struct GmmArgs {
     int32_t D, n_models, tiles_per_model, n_tiles;
 };
 
+// Online log-sum-exp over one 32x32 accumulator tile (16 mixtures per lane).  The packed weights carry a factor log2(e),
+// so the accumulator is log2 p: exponentials are bare v_exp_f32, the result is converted back with one multiply by ln 2.
+__device__ __forceinline__ void lse2_update(const f32x16& acc, float& run_m, float& run_s) {
+    float tm = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) tm = fmaxf(fmaxf(tm, acc[i]), acc[i + 1]);
+    tm = fmaxf(tm, acc[15]);
+    const float nm = fmaxf(run_m, tm);
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    const v2f_ nm2 = v2f_{nm, nm};
+    v2f_ sacc = v2f_{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {  // packed subtract / add on register pairs, transcendental per element
+        const v2f_ dlt = v2f_{acc[i], acc[i + 1]} - nm2;
+        sacc += v2f_{__builtin_amdgcn_exp2f(dlt.x), __builtin_amdgcn_exp2f(dlt.y)};
+    }
+    const float s0 = sacc.x, s1 = sacc.y;
+    run_s = run_s * __builtin_amdgcn_exp2f(run_m - nm) + (s0 + s1);
+    run_m = nm;
+}
+
+// final value of a model for one frame: combine the two lane halves, back to natural log
+__device__ __forceinline__ float lse2_finish(float run_m, float run_s) {
+    const float m2 = __shfl_xor(run_m, 32), s2 = __shfl_xor(run_s, 32);
+    const float mm = fmaxf(run_m, m2);
+    const float ss = run_s * __builtin_amdgcn_exp2f(run_m - mm) + s2 * __builtin_amdgcn_exp2f(m2 - mm);
+    return (mm + __builtin_amdgcn_logf(ss)) * 0.6931471805599453f;
+}
+
 // NQ = k-depth / 8 of the packed image (k-depth >= 2D+1); CT = 32-frame column tiles per wave
 template <int NQ, int CT>
 __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
@@ -110,25 +139,13 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
         }
         // online log-sum-exp over this tile's 16 mixtures per lane
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            float tm = acc[ct][0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) tm = fmaxf(tm, acc[ct][i]);
-            const float nm = fmaxf(run_m[ct], tm);
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s += __expf(acc[ct][i] - nm);
-            run_s[ct] = run_s[ct] * __expf(run_m[ct] - nm) + s;
-            run_m[ct] = nm;
-        }
+        for (int ct = 0; ct < CT; ++ct) lse2_update(acc[ct], run_m[ct], run_s[ct]);
         if (++rt == a.tiles_per_model) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const float m2 = __shfl_xor(run_m[ct], 32), s2 = __shfl_xor(run_s[ct], 32);
-                const float mm = fmaxf(run_m[ct], m2);
-                const float ss = run_s[ct] * __expf(run_m[ct] - mm) + s2 * __expf(m2 - mm);
+                const float ll = lse2_finish(run_m[ct], run_s[ct]);
                 const int fidx = (wave * CT + ct) * 32 + fl;
-                if (h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = mm + logf(ss);
+                if (h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = ll;
                 run_m[ct] = -INFINITY;
                 run_s[ct] = 0.f;
             }
@@ -162,9 +179,11 @@ template <int NK, int CT>
 __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_BYTES = 2 * NK * 1024 + 256;
+    constexpr int GROUP = 2;                       // row tiles staged (and consumed) per workgroup barrier
+    constexpr int GROUP_BYTES = GROUP * TILE_BYTES;
     constexpr int FRAMES_WG = 4 * CT * 32;
-    char* wbuf = smem;                                                 // [2][TILE_BYTES]
-    float* xs = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);        // [FRAMES_WG * D]
+    // LDS: a ring of [2][GROUP_BYTES] tile slots; its first bytes stage the frames once
+    float* xs = reinterpret_cast<float*>(smem);          // [FRAMES_WG * D] (dead before the first tile lands)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 31, h = lane >> 5;
@@ -176,7 +195,6 @@ __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
         const int tot = n_valid * D;
         for (int i = tid; i < FRAMES_WG * D; i += 256) xs[i] = i < tot ? src[i] : 0.f;
     }
-    stage_tile16<NK>(a.wimg16, wbuf, wave, lane);
     __syncthreads();
 
     // B operand: lane (frame fl, half h) holds aug[frame][16 ks + 8 h + j], j = 0..7, as hi and lo bf16 fragments
@@ -196,6 +214,20 @@ __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
                 bl[ct][ks][jj] = (__bf16)(v - (float)hi);
             }
     }
+    __syncthreads();  // every wave has its fragments: the staging area becomes the tile ring
+    // stage the (up to GROUP) tiles of group g into ring slot `slot` (offsets are formed from the LDS base directly so
+    // the address stays in the LDS address space)
+#define SSP_STAGE_GROUP(g_, slot_)                                                                                        \
+    {                                                                                                                     \
+        _Pragma("unroll") for (int t_ = 0; t_ < GROUP; ++t_) {                                                            \
+            const int tile_ = (g_) * GROUP + t_;                                                                          \
+            if (tile_ < a.n_tiles)                                                                                        \
+                stage_tile16<NK>(a.wimg16 + (size_t)tile_ * TILE_BYTES, smem + (slot_) * GROUP_BYTES + t_ * TILE_BYTES, wave, lane); \
+        }                                                                                                                 \
+    }
+    SSP_STAGE_GROUP(0, 0)
+    __syncthreads();
+
     float run_m[CT], run_s[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -203,61 +235,53 @@ __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
         run_s[ct] = 0.f;
     }
     int rt = 0, model = 0;
-    for (int r = 0; r < a.n_tiles; ++r) {
-        const char* wcur = wbuf + (r & 1) * TILE_BYTES;
-        if (r + 1 < a.n_tiles)
-            stage_tile16<NK>(a.wimg16 + (size_t)(r + 1) * TILE_BYTES, wbuf + ((r + 1) & 1) * TILE_BYTES, wave, lane);
-        f32x16 acc[CT];
-        {
-            const f32x4* ci = reinterpret_cast<const f32x4*>(wcur + 2 * NK * 1024 + h * 64);
+    const int n_groups = (a.n_tiles + GROUP - 1) / GROUP;
+    for (int g = 0; g < n_groups; ++g) {
+        if (g + 1 < n_groups) SSP_STAGE_GROUP(g + 1, (g + 1) & 1)
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const f32x4 cv = ci[c4];
+        for (int t = 0; t < GROUP; ++t) {
+            if (g * GROUP + t >= a.n_tiles) break;
+            const char* wcur = smem + (g & 1) * GROUP_BYTES + t * TILE_BYTES;
+            f32x16 acc[CT];
+            {
+                const f32x4* ci = reinterpret_cast<const f32x4*>(wcur + 2 * NK * 1024 + h * 64);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    acc[ct][4 * c4 + 0] = cv[0];
-                    acc[ct][4 * c4 + 1] = cv[1];
-                    acc[ct][4 * c4 + 2] = cv[2];
-                    acc[ct][4 * c4 + 3] = cv[3];
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const f32x4 cv = ci[c4];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        acc[ct][4 * c4 + 0] = cv[0];
+                        acc[ct][4 * c4 + 1] = cv[1];
+                        acc[ct][4 * c4 + 2] = cv[2];
+                        acc[ct][4 * c4 + 3] = cv[3];
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wcur + (((ks * 2 + 0) * 2 + h) * 32 + fl) * 16);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(wcur + (((ks * 2 + 1) * 2 + h) * 32 + fl) * 16);
+            for (int ks = 0; ks < NK; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wcur + (((ks * 2 + 0) * 2 + h) * 32 + fl) * 16);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wcur + (((ks * 2 + 1) * 2 + h) * 32 + fl) * 16);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ct][ks], acc[ct], 0, 0, 0);
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ct][ks], acc[ct], 0, 0, 0);
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ct][ks], acc[ct], 0, 0, 0);
+                for (int ct = 0; ct < CT; ++ct) {
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ct][ks], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ct][ks], acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ct][ks], acc[ct], 0, 0, 0);
+                }
             }
-        }
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            float tm = acc[ct][0];
+            for (int ct = 0; ct < CT; ++ct) lse2_update(acc[ct], run_m[ct], run_s[ct]);
+            if (++rt == a.tiles_per_model) {
 #pragma unroll
-            for (int i = 1; i < 16; ++i) tm = fmaxf(tm, acc[ct][i]);
-            const float nm = fmaxf(run_m[ct], tm);
-            float sacc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc += __expf(acc[ct][i] - nm);
-            run_s[ct] = run_s[ct] * __expf(run_m[ct] - nm) + sacc;
-            run_m[ct] = nm;
-        }
-        if (++rt == a.tiles_per_model) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const float m2 = __shfl_xor(run_m[ct], 32), s2 = __shfl_xor(run_s[ct], 32);
-                const float mm = fmaxf(run_m[ct], m2);
-                const float ss = run_s[ct] * __expf(run_m[ct] - mm) + s2 * __expf(m2 - mm);
-                const int fidx = (wave * CT + ct) * 32 + fl;
-                if (h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = mm + logf(ss);
-                run_m[ct] = -INFINITY;
-                run_s[ct] = 0.f;
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float ll = lse2_finish(run_m[ct], run_s[ct]);
+                    const int fidx = (wave * CT + ct) * 32 + fl;
+                    if (h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = ll;
+                    run_m[ct] = -INFINITY;
+                    run_s[ct] = 0.f;
+                }
+                rt = 0;
+                ++model;
             }
-            rt = 0;
-            ++model;
         }
         __syncthreads();
     }
@@ -326,7 +350,7 @@ static int launch_loglik(const GmmArgs& a, hipStream_t s) {
 template <int NK, int CT>
 static int launch_loglik16(const GmmArgs& a, hipStream_t s) {
     constexpr int FRAMES_WG = 4 * CT * 32;
-    const size_t lds = (size_t)2 * (2 * NK * 1024 + 256) + (size_t)FRAMES_WG * a.D * sizeof(float);
+    const size_t lds = std::max<size_t>((size_t)2 * 2 * (2 * NK * 1024 + 256), (size_t)FRAMES_WG * a.D * sizeof(float));
     const int64_t grid = ceil_div<int64_t>(a.F, FRAMES_WG);
     if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many frames for one launch");
     if (lds > 64 * 1024)
@@ -377,6 +401,7 @@ int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const dou
     const size_t n_tiles = (size_t)n_models * tpm;
     std::vector<float> img(n_tiles * tile_floats, 0.f);
     const double ln2pi = std::log(2.0 * M_PI);
+    const double LOG2E = 1.4426950408889634;
     std::vector<double> w((size_t)nq * 8);
     for (int m = 0; m < n_models; ++m)
         for (int k = 0; k < tpm * 32; ++k) {
@@ -389,11 +414,11 @@ int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const dou
                 for (int d = 0; d < D; ++d) {
                     if (!(cv[d] > 0.0)) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_pack: non-positive covariance (model %d, mix %d)", m, k);
                     const double P = 1.0 / cv[d];
-                    w[d] = mu[d] * P;
-                    w[D + d] = -0.5 * P;
+                    w[d] = mu[d] * P * LOG2E;   // everything in log2 units: the kernels exponentiate with bare v_exp_f32
+                    w[D + d] = -0.5 * P * LOG2E;
                     c += 0.5 * std::log(P) - 0.5 * mu[d] * mu[d] * P;
                 }
-                w[2 * D] = c;
+                w[2 * D] = c * LOG2E;
             } else {
                 w[2 * D] = -1.0e30;  // padded mixture: contributes exp(-1e30 - max) = 0 to the LSE
             }
@@ -441,10 +466,11 @@ int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const dou
                     cst = std::log(weights[(size_t)m * K + k]) - 0.5 * D * ln2pi;
                     for (int d = 0; d < D; ++d) {
                         const double P = 1.0 / cv[d];
-                        wv[d] = mu[d] * P;
-                        wv[D + d] = -0.5 * P;
+                        wv[d] = mu[d] * P * LOG2E;
+                        wv[D + d] = -0.5 * P * LOG2E;
                         cst += 0.5 * std::log(P) - 0.5 * mu[d] * mu[d] * P;
                     }
+                    cst *= LOG2E;
                 }
                 for (int j = 0; j < nk16 * 16; ++j) {
                     const int ks = j >> 4, hh = (j >> 3) & 1, e = j & 7;
