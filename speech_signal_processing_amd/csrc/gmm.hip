@@ -10,6 +10,7 @@
 // log-sum-exp over the mixtures of each model.  Mixtures are the MFMA ROWS and frames the COLUMNS, so the 16 accumulator
 // registers of a lane all belong to ONE frame: the LSE is in-lane plus one exchange with lane^32.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -290,14 +291,14 @@ __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
 // per-utterance mean over frames (GaussianMixture.score), score differences against the UBM and arg-max
 // (GMM_UBM.py:185-187).  One workgroup per utterance, fixed summation order => bitwise reproducible.
 __global__ __launch_bounds__(256) void gmm_utt_reduce_kernel(const float* __restrict__ llT, int64_t F,
-                                                             const int64_t* __restrict__ frame_off, int n_models,
-                                                             int has_ubm, float* __restrict__ scores,
+                                                             const int64_t* __restrict__ frame_off, int64_t frame_base,
+                                                             int n_models, int has_ubm, float* __restrict__ scores,
                                                              int32_t* __restrict__ argmax_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = reinterpret_cast<float*>(smem);
     const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t a0 = frame_off[u];
-    const int T = (int)(frame_off[u + 1] - a0);
+    const int64_t a0 = frame_off[u] - frame_base;  // column of the utterance's first frame in this batch's llT
+    const int T = (int)(frame_off[u + 1] - frame_off[u]);
     for (int m = wave; m < n_models; m += 4) {
         const float* __restrict__ p = llT + (size_t)m * F + a0;
         float s = 0.f;
@@ -550,59 +551,87 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     const float* d_feats = (const float*)sin.in(ctx, feats, (size_t)F * gmm->D * sizeof(float), where, &rc);
     SSP_TRY(rc);
     const size_t ll_bytes = (size_t)M * (size_t)std::max<int64_t>(F, 1) * sizeof(float);
+    // Per-frame log-likelihoods are model-major [M x frames].  When the caller wants them the whole [M x F] matrix is
+    // produced in one pass; otherwise they are scratch, and utterances are processed in batches so that the scratch
+    // stays below a fixed cap (configs[3]: 1252 models x 4.5e7 frames per GPU would otherwise need 224 GB).
+    const size_t scratch_cap = (size_t)4 << 30;
+    const char* cap_env = getenv("SSP_GMM_SCRATCH_BYTES");
+    const size_t cap = cap_env ? (size_t)strtoull(cap_env, nullptr, 10) : scratch_cap;
     float* d_ll = nullptr;
+    int64_t batch_frames_cap = F;
     if (loglik_out) {
         d_ll = (float*)sll.out(loglik_out, ll_bytes, where, &rc);
         SSP_TRY(rc);
     } else {
-        if (gmm->scratch.bytes < ll_bytes) SSP_TRY(gmm->scratch.alloc(ll_bytes));
+        batch_frames_cap = std::max<int64_t>((int64_t)(cap / ((size_t)M * sizeof(float))), 1);
+        const int64_t need_frames = std::min<int64_t>(std::max<int64_t>(F, 1), std::max<int64_t>(batch_frames_cap, frame_seg->max_len()));
+        const size_t need = (size_t)M * (size_t)need_frames * sizeof(float);
+        if (gmm->scratch.bytes < need) SSP_TRY(gmm->scratch.alloc(need));
         d_ll = gmm->scratch.as<float>();
     }
     float* d_sc = (float*)ssc.out(scores_out, (size_t)n_utt * M * sizeof(float), where, &rc);
     SSP_TRY(rc);
     int32_t* d_am = (int32_t*)sam.out(argmax_out, (size_t)n_utt * sizeof(int32_t), where, &rc);
     SSP_TRY(rc);
+    if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many utterances");
 
-    GmmArgs a{};
-    a.feats = d_feats;
-    a.wimg = gmm->wimg.as<float>();
-    a.wimg16 = gmm->wimg16.as<char>();
-    a.llT = d_ll;
-    a.F = F;
-    a.D = gmm->D;
-    a.n_models = M;
-    a.tiles_per_model = gmm->tiles_per_model;
-    a.n_tiles = M * gmm->tiles_per_model;
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, s));
-    if (F > 0 && precision == 1) {
-        switch (gmm->nk16) {
-            case 1: SSP_TRY((launch_loglik16<1, 2>(a, s))); break;
-            case 2: SSP_TRY((launch_loglik16<2, 2>(a, s))); break;
-            case 3: SSP_TRY((launch_loglik16<3, 2>(a, s))); break;
-            case 4: SSP_TRY((launch_loglik16<4, 2>(a, s))); break;
-            case 5: SSP_TRY((launch_loglik16<5, 2>(a, s))); break;
-            case 6: SSP_TRY((launch_loglik16<6, 2>(a, s))); break;
-            case 8: SSP_TRY((launch_loglik16<8, 2>(a, s))); break;
-            default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no bf16 kernel for nk=%d", gmm->nk16);
+    const int64_t f_begin = frame_seg->host.front();
+    int64_t u0 = 0;
+    while (u0 < n_utt) {
+        // batch = utterances [u0, u1): as many as fit the frame cap (at least one)
+        int64_t u1 = u0 + 1;
+        if (loglik_out) {
+            u1 = n_utt;
+        } else {
+            while (u1 < n_utt && frame_seg->host[u1 + 1] - frame_seg->host[u0] <= batch_frames_cap) ++u1;
         }
-    } else if (F > 0) {
-        switch (gmm->nq) {
-            case 4: SSP_TRY((launch_loglik<4, 2>(a, s))); break;
-            case 7: SSP_TRY((launch_loglik<7, 2>(a, s))); break;
-            case 10: SSP_TRY((launch_loglik<10, 2>(a, s))); break;
-            case 16: SSP_TRY((launch_loglik<16, 2>(a, s))); break;
-            case 24: SSP_TRY((launch_loglik<24, 1>(a, s))); break;
-            case 32: SSP_TRY((launch_loglik<32, 1>(a, s))); break;
-            default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no kernel for nq=%d", gmm->nq);
+        const int64_t fb0 = loglik_out ? 0 : frame_seg->host[u0];
+        const int64_t fb1 = loglik_out ? F : frame_seg->host[u1];
+        const int64_t Fb = fb1 - fb0;
+        GmmArgs a{};
+        a.feats = d_feats + (size_t)fb0 * gmm->D;
+        a.wimg = gmm->wimg.as<float>();
+        a.wimg16 = gmm->wimg16.as<char>();
+        a.llT = d_ll;
+        a.F = Fb;
+        a.D = gmm->D;
+        a.n_models = M;
+        a.tiles_per_model = gmm->tiles_per_model;
+        a.n_tiles = M * gmm->tiles_per_model;
+        if (Fb > 0 && precision == 1) {
+            switch (gmm->nk16) {
+                case 1: SSP_TRY((launch_loglik16<1, 2>(a, s))); break;
+                case 2: SSP_TRY((launch_loglik16<2, 2>(a, s))); break;
+                case 3: SSP_TRY((launch_loglik16<3, 2>(a, s))); break;
+                case 4: SSP_TRY((launch_loglik16<4, 2>(a, s))); break;
+                case 5: SSP_TRY((launch_loglik16<5, 2>(a, s))); break;
+                case 6: SSP_TRY((launch_loglik16<6, 2>(a, s))); break;
+                case 8: SSP_TRY((launch_loglik16<8, 2>(a, s))); break;
+                default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no bf16 kernel for nk=%d", gmm->nk16);
+            }
+        } else if (Fb > 0) {
+            switch (gmm->nq) {
+                case 4: SSP_TRY((launch_loglik<4, 2>(a, s))); break;
+                case 7: SSP_TRY((launch_loglik<7, 2>(a, s))); break;
+                case 10: SSP_TRY((launch_loglik<10, 2>(a, s))); break;
+                case 16: SSP_TRY((launch_loglik<16, 2>(a, s))); break;
+                case 24: SSP_TRY((launch_loglik<24, 1>(a, s))); break;
+                case 32: SSP_TRY((launch_loglik<32, 1>(a, s))); break;
+                default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no kernel for nq=%d", gmm->nq);
+            }
         }
+        if (scores_out || argmax_out) {
+            // the reduce kernel indexes llT columns by (frame offset - frame_base): batch frames start at column 0
+            hipLaunchKernelGGL(gmm_utt_reduce_kernel, dim3((unsigned)(u1 - u0)), dim3(256), (size_t)M * sizeof(float), s, d_ll, Fb,
+                               frame_seg->dev.as<int64_t>() + u0, fb0, M, gmm->has_ubm, d_sc ? d_sc + (size_t)u0 * M : nullptr,
+                               d_am ? d_am + u0 : nullptr);
+            SSP_HIP(hipGetLastError());
+        }
+        u0 = u1;
     }
-    if (scores_out || argmax_out) {
-        if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many utterances");
-        hipLaunchKernelGGL(gmm_utt_reduce_kernel, dim3((unsigned)n_utt), dim3(256), (size_t)M * sizeof(float), s, d_ll, F,
-                           frame_seg->dev.as<int64_t>(), M, gmm->has_ubm, d_sc, d_am);
-        SSP_HIP(hipGetLastError());
-    }
+    (void)f_begin;
     SSP_TRY(tm.stop(s, kernel_ms));
     SSP_TRY(sll.back(ctx, loglik_out, ll_bytes, where));
     SSP_TRY(ssc.back(ctx, scores_out, (size_t)n_utt * M * sizeof(float), where));

@@ -358,6 +358,26 @@ def test_gmm_cfg4_shape_512_mixtures(ssp, precision):
     np.testing.assert_allclose(r["loglik"][2], O.gmm_score_samples(w, mus[2], cov, np.vstack(feats)), rtol=1e-4, atol=1e-4)
 
 
+def test_gmm_bounded_scratch_batches(ssp, monkeypatch):
+    """the per-frame log-likelihood scratch is capped: scoring in many small utterance batches gives bit-identical results"""
+    pkg, api = ssp
+    rng = np.random.default_rng(8)
+    K, D, M = 16, 13, 6
+    ctx = api.default_context()
+    sc = api.GmmScorer(ctx, rng.dirichlet(np.ones(K), size=M), rng.standard_normal((M, K, D)), rng.uniform(0.5, 2, (M, K, D)), has_ubm=True)
+    lens = rng.integers(0, 200, 50)
+    lens[7] = 0
+    feats = rng.standard_normal((int(lens.sum()), D)).astype(np.float32)
+    seg = api.Segments.from_lengths(ctx, lens)
+    ref = sc.score(feats, seg)
+    monkeypatch.setenv("SSP_GMM_SCRATCH_BYTES", str(M * 4 * 300))  # ~300 frames per batch
+    got = sc.score(feats, seg)
+    ok = lens > 0
+    assert np.array_equal(np.asarray(ref["scores"])[ok], np.asarray(got["scores"])[ok])
+    assert np.array_equal(np.asarray(ref["argmax"])[ok], np.asarray(got["argmax"])[ok])
+    assert np.isnan(np.asarray(got["scores"])[7]).all()  # mean over zero frames, like numpy
+
+
 def test_gmm_batch_permutation_property(ssp):
     """Utterances are independent: permuting them permutes the outputs bit-exactly; the frame mean is reproducible."""
     pkg, api = ssp
