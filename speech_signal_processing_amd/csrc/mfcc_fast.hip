@@ -31,6 +31,7 @@ namespace ssp {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int ZROW = 144;             // bytes per 16-complex row of the transpose / Z image (128 + 16 pad)
 constexpr int ZFRAME = 16 * ZROW;     // 2304 B per frame (multiple of 256 B: keeps the 4 frames bank-aligned)
@@ -98,6 +99,22 @@ __device__ __forceinline__ void fft16(v2f (&z)[16]) {
     for (int i = 0; i < 16; ++i) z[i] = o[i];
 }
 
+#ifdef SSP_STAMP
+// Diagnostic build only (never shipped): per-phase cycle accounting of the quad loop with s_memtime stamps.
+__device__ unsigned long long g_stamps[16];
+#define STAMP(ph)                                                                                   \
+    {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        st_acc[ph] += t_ - st_last;                                                                 \
+        st_last = t_;                                                                               \
+    }
+#else
+#define STAMP(ph)
+#endif
+
 struct __attribute__((packed, aligned(4))) f4u {
     float x, y, z, w;
 };
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
 #pragma unroll
         for (int i = 0; i < 8; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);  // W_512^(j + 16 i)
     }
-    for (int i = tid; i < f.total_steps * 64; i += NT) s_melw[i] = f.melw[i];
+    for (int i = tid; i < f.total_steps * 128; i += NT) s_melw[i] = f.melw[i];
     for (int i = tid; i < f.n_pass * 16; i += NT) s_melpk[i] = f.mel_lo[i] | ((f.mel_id[i] + 1) << 16);
     for (int i = tid; i < f.n_filt4 * 4 * f.q_pass * 16; i += NT) s_dct[i] = f.dctT[i];
     __syncthreads();
@@ -174,23 +191,30 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     const float pre = PRE ? a.preemph : 0.f;
     const int nquads = (tb - ta + 3) >> 2;
 
-    // ---- sample gather: every lane loads ITS OWN FFT inputs straight from global memory, one quad ahead:
-    //      (x[e-1], x[e], x[e+1]) with e = t*hop + 32 n1 + 2 j  (the 16 lanes of a frame read 128 contiguous bytes per
-    //      n1; the 2.5x overlap between neighbouring frames is served by L1/L2, HBM sees every sample once).
-    //      Bounds-checked buffer loads: anything outside the utterance [0, N) reads as 0 = the zero padding we need.
+    // ---- sample path: the wave's 3*hop + 32*NZ samples of a quad stream HBM -> LDS by LDS-DMA (coalesced 16-byte
+    //      buffer loads that write the wave-private stage directly: no VGPRs, 4 instructions per quad, every sample
+    //      crosses L2 ~1.4x instead of the 2.1x of per-lane gathers), one quad ahead.  Bounds-checked: anything
+    //      outside the utterance [0, N) lands as 0 = the zero padding the dialects need.
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(N * 4), 0x00020000);
-    v2f pf[NZ];   // (x[e], x[e+1])
+    float* stage = reinterpret_cast<float*>(zbuf + 4 * ZFRAME);
+    const bool dma16 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((hop & 3) == 0);  // wave-uniform
+    const int n_piece = (f.slen + 255) >> 8;  // 1 KiB pieces
     auto prefetch = [&](int q) {
-        const int e0 = ((ta + 4 * q + g) * hop + 2 * j) * 4;  // byte offset of this lane's first element
-#pragma unroll
-        for (int n1 = 0; n1 < NZ; ++n1) {
-#if (defined(SSP_ABL) && SSP_ABL >= 5) || defined(SSP_NOLOAD)
-            pf[n1] = v2f{(float)(e0 & 255) * 1e-3f, 0.5f}; continue;
-#endif
-            pf[n1] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, e0 + 128 * n1, 0, 0));
+        const int sq4 = (ta + 4 * q) * hop * 4;  // byte offset of the quad's first sample inside the utterance
+        if (dma16) {
+            for (int c = 0; c < n_piece; ++c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage + c * 256), 16, sq4 + c * 1024 + lane * 16, 0, 0, 0);
+        } else {  // ragged batches whose utterances do not start on 16-byte boundaries: 4-byte DMA pieces
+            for (int c = 0; c < 4 * n_piece; ++c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage + c * 64), 4, sq4 + c * 256 + lane * 4, 0, 0, 0);
         }
     };
+    v2f pf[NZ];   // (x[e], x[e+1]),  e = g*hop + 32 n1 + 2 j inside the staged quad
+#ifdef SSP_STAMP
+    unsigned long long st_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
     prefetch(wave);
     const float npre = -pre;
     for (int q = wave; q < nquads; q += FAST_WAVES) {
@@ -199,6 +223,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         //      x[e-1] is the neighbouring lane's second sample (DPP row_shr:1); lane 0 of a frame takes it from lane 15's
         //      previous row (DPP row_ror:1), or from itself for the very first sample of the frame.
         v2f z[16];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this quad's DMA has landed (issued one iteration ago)
+        STAMP(10)  // wait for the DMA
+        {
+            const float* sp = stage + g * hop + 2 * j;
+#pragma unroll
+            for (int n1 = 0; n1 < NZ; ++n1) pf[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is in registers: the next quad may overwrite it
+        STAMP(11)  // stage reads
+        prefetch(q + FAST_WAVES);  // flies under this whole iteration (past the end it stages zeros)
+        STAMP(12)  // DMA issue
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NZ) {
@@ -221,12 +256,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
                 z[n1] = v2f{0.f, 0.f};
             }
         }
+        STAMP(0)  // DMA landed + stage reads + next DMA issue + pre-emphasis + window
         // ---- 3. FFT16 over n1, twiddle W_256^(n2 k1)
 #ifndef SSP_NO_FFT1
         fft16(z);
 #endif
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], TABREG ? twr[k1 - 1] : s_tw16[(k1 - 1) * 16 + j]);
+        STAMP(1)  // FFT1 + twiddle
         // ---- 4. transpose through LDS
         char* zf = zbuf + g * ZFRAME;
 #if (!defined(SSP_ABL) || SSP_ABL < 3) && !defined(SSP_NO_T2)
@@ -238,26 +275,33 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
             z[2 * c] = v2f{r.x, r.y};
             z[2 * c + 1] = v2f{r.z, r.w};
         }
+        STAMP(2)  // transpose write + read
         // ---- 5. FFT16 over n2: lane j = k1, register = k2
         fft16(z);
 #endif
+        STAMP(3)  // FFT2
 #if (defined(SSP_ABL) && SSP_ABL >= 2) || defined(SSP_NO_SPLIT)
         { float* P = reinterpret_cast<float*>(zf);
 #pragma unroll
           for (int k2 = 0; k2 < 16; ++k2) P[j + 16 * k2] = z[k2].x * z[k2].x + z[k2].y * z[k2].y; }
 #else
         // ---- 6. split step.  Lane j (= k1) owns the bin pairs k = j + 16 k2 <-> 256 - k for k2 = 0..7.  Z[256 - k] lives
-        //         in lane 16 - j, register 15 - k2 (lane 0: its own register 16 - k2), i.e. always in the UPPER half
-        //         of the registers: only that half goes through LDS (natural order image, rows 8..15), each lane
-        //         reads its 8 partners back, and every pair is formed exactly once.
-#pragma unroll
-        for (int k2 = 8; k2 < 16; ++k2) *reinterpret_cast<v2f*>(zf + k2 * ZROW + j * 8) = z[k2];
+        //         in lane 16 - j, register 15 - k2 (lane 0: its own register 16 - k2): the partners are fetched with two
+        //         DPP row permutes per value (LDS is the binding unit of this kernel, the VALU is not), and every pair
+        //         is formed exactly once.
         {
-            const char* pbase = zf + (j != 0 ? (16 - j) * 8 : ZROW);
+            // partner exchange inside the 16-lane row, no LDS: dst[j] = src[(16 - j) & 15] = row_ror:1(row_mirror(src))
             v2f zm[8];
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) zm[k2] = *reinterpret_cast<const v2f*>(pbase + (15 - k2) * ZROW);
-            if (j == 0) zm[0] = z[0];  // Z[256] := Z[0]
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const float sx = z[15 - k2].x, sy = z[15 - k2].y;
+                float mx = __builtin_amdgcn_update_dpp(0.f, sx, 0x140 /*row_mirror*/, 0xF, 0xF, false);
+                float my = __builtin_amdgcn_update_dpp(0.f, sy, 0x140 /*row_mirror*/, 0xF, 0xF, false);
+                mx = __builtin_amdgcn_update_dpp(0.f, mx, 0x121 /*row_ror:1*/, 0xF, 0xF, false);
+                my = __builtin_amdgcn_update_dpp(0.f, my, 0x121 /*row_ror:1*/, 0xF, 0xF, false);
+                const v2f own = z[(16 - k2) & 15];  // lane 0 pairs with itself: Z[256 - 16 k2] = its register 16 - k2
+                zm[k2] = v2f{j == 0 ? own.x : mx, j == 0 ? own.y : my};
+            }
             float* P = reinterpret_cast<float*>(zf);
             float pa[8], pb[8];
 #pragma unroll
@@ -282,66 +326,72 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
             if (POWER == 1) p128 = __builtin_sqrtf(p128);
             // the 1/4 (power) or 1/2 (magnitude) and spec_scale live in the filterbank weights
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) {
-                P[j + 16 * k2] = pa[k2];
-                P[256 - j - 16 * k2] = pb[k2];
-            }
+            for (int k2 = 0; k2 < 8; ++k2) P[j + 16 * k2] = pa[k2];      // grouped by base so the stores pair into ds_write2_b32
+            float* Pm = P + 144 - j;                                       // P[256 - j - 16 k2] = Pm[16 (7 - k2)]
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) Pm[16 * (7 - k2)] = pb[k2];
             if (j == 0) P[128] = p128;
         }
 #endif
-        prefetch(q + FAST_WAVES);  // next quad's samples fly under the filterbank / DCT (past the end they read zeros)
-        // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads)
+        STAMP(4)  // partner exchange + split step + P row
+        // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads).  Two passes are swept
+        //         together (slot A of pass 2p, slot B of pass 2p+1) in blocks of 4 fully unrolled steps, so a sweep is a
+        //         few rounds of independent loads instead of a long chain of dependent round trips.
 #if (!defined(SSP_ABL) || SSP_ABL < 1) && !defined(SSP_NO_MEL)
         {
             const float* P = reinterpret_cast<const float*>(zf);
             float* lm = reinterpret_cast<float*>(zf + LM_OFF - 64 * g);
-            if (j < 4 * f.n_filt4 - a.n_filt) lm[a.n_filt + j] = 0.f;  // padded filter slots must read as finite zeros
+            if (j < f.lm_pad) lm[a.n_filt + j] = 0.f;  // padded filter slots must read as finite zeros
             int wofs = 0;
-            for (int pass = 0; pass < f.n_pass; ++pass) {
-                const int steps4 = f.mel_steps[pass];  // in units of 4 taps
-                const int pk = s_melpk[pass * 16 + j];
-                const int lo4 = pk & 0xffff;  // storage index, multiple of 4
-                const int id = (pk >> 16) - 1;
-                const v4f* pp = reinterpret_cast<const v4f*>(P + lo4);
-                const v4f* ww = reinterpret_cast<const v4f*>(s_melw + (size_t)wofs * 64) + j;
-                float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 4
-                for (int s = 0; s < steps4; ++s) {
-                    const v4f pv = pp[s];
-                    const v4f wv = ww[s * 16];
-                    acc0 = fmaf(pv.x, wv.x, acc0);
-                    acc1 = fmaf(pv.y, wv.y, acc1);
-                    acc0 = fmaf(pv.z, wv.z, acc0);
-                    acc1 = fmaf(pv.w, wv.w, acc1);
+            for (int pp2 = 0; pp2 < f.n_pass; pp2 += 2) {
+                const int nblk = f.mel_blocks[pp2 >> 1];           // 4-step blocks of this pass pair (max of the two passes)
+                const int pkA = s_melpk[pp2 * 16 + j], pkB = s_melpk[(pp2 + 1) * 16 + j];
+                const v4f* pA = reinterpret_cast<const v4f*>(P + (pkA & 0xffff));
+                const v4f* pB = reinterpret_cast<const v4f*>(P + (pkB & 0xffff));
+                const v4f* wA = reinterpret_cast<const v4f*>(s_melw + (size_t)wofs * 128) + j;  // [step][A|B][lane][4]
+                const v4f* wB = wA + 16;
+                v4f accA = v4f{0.f, 0.f, 0.f, 0.f}, accB = v4f{0.f, 0.f, 0.f, 0.f};
+                for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int st = blk * 4 + u;
+                        accA = __builtin_elementwise_fma(pA[st], wA[st * 32], accA);
+                        accB = __builtin_elementwise_fma(pB[st], wB[st * 32], accB);
+                    }
                 }
-                if (id >= 0) lm[id] = fast_log(a, acc0 + acc1);
-                wofs += steps4;
+                const int idA = (pkA >> 16) - 1, idB = (pkB >> 16) - 1;
+                if (idA >= 0) lm[idA] = fast_log(a, (accA.x + accA.y) + (accA.z + accA.w));
+                if (idB >= 0) lm[idB] = fast_log(a, (accB.x + accB.y) + (accB.z + accB.w));
+                wofs += nblk * 4;
             }
         }
-        // ---- 8. DCT rows: lane = cepstral index, 4 filters per step
+        STAMP(5)  // filterbank + log
+        // ---- 8. DCT rows: lane = cepstral index, 4 filters per step, blocks of 4 fully unrolled steps
         {
             const v4f* lm4 = reinterpret_cast<const v4f*>(zf + LM_OFF - 64 * g);
             for (int qp = 0; qp < f.q_pass; ++qp) {
                 const int qq = qp * 16 + j;
                 const v4f* dd = reinterpret_cast<const v4f*>(s_dct) + qq;
-                float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 2
-                for (int s = 0; s < f.n_filt4; ++s) {
-                    const v4f lv = lm4[s];
-                    const v4f dv = dd[s * f.q_pass * 16];
-                    acc0 = fmaf(lv.x, dv.x, acc0);
-                    acc1 = fmaf(lv.y, dv.y, acc1);
-                    acc0 = fmaf(lv.z, dv.z, acc0);
-                    acc1 = fmaf(lv.w, dv.w, acc1);
+                v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+                for (int blk = 0; blk < f.n_filt4 / 4; ++blk) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int st = blk * 4 + u;
+                        acc = __builtin_elementwise_fma(lm4[st], dd[st * f.q_pass * 16], acc);
+                    }
                 }
-                if (qq < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + qq] = acc0 + acc1;
+                if (qq < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + qq] = (acc.x + acc.y) + (acc.z + acc.w);
             }
         }
 #else
         if (j < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + j] = reinterpret_cast<const float*>(zf)[j + 7];  // ablation: no filterbank / DCT
 #endif
+        STAMP(6)  // DCT + cepstra
     }
+    STAMP(7)  // loop exit
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may still be landing when the stage is reused below
     __syncthreads();
+    STAMP(8)  // barrier wait
 
 #if (defined(SSP_ABL) && SSP_ABL >= 4) || defined(SSP_NO_TAIL)
     if (tid == 0) a.out[(size_t)(f0 + t0) * a.d_out] = s_ceps[0];
@@ -370,7 +420,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         c1 = 0.f;
         c2 = 0.f;
         if (a.delta_order == 0) return;
-        if (u - 2 * Nd >= 0 && u + 2 * Nd <= T - 1) {
+        if (Nd == 2 && u >= 4 && u + 4 <= T - 1) {
+            // the reference's N = 2 (GMM_UBM.py:53): 9 neighbours, no predicates
+            const float* cp = s_ceps + (size_t)(u - ta) * nc + qq;
+            const float m4 = cp[-4 * nc], m3 = cp[-3 * nc], m2 = cp[-2 * nc], m1 = cp[-nc], p1 = cp[nc], p2 = cp[2 * nc],
+                        p3 = cp[3 * nc], p4 = cp[4 * nc];
+            c1 = ((p1 - m1) + 2.f * (p2 - m2)) * inv;
+            c2 = f.ddw[0] * (m4 + p4) + f.ddw[1] * (m3 + p3) + f.ddw[2] * (m2 + p2) + f.ddw[3] * (m1 + p1) + f.ddw[4] * c0;
+        } else if (u - 2 * Nd >= 0 && u + 2 * Nd <= T - 1) {
             // all 4N+1 neighbours are fetched first (one LDS round trip), then reduced from registers (delta_N <= 4)
             float cv[17];
 #pragma unroll
@@ -450,11 +507,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         if (tid < tot - done) dst[done + tid] = obuf[done + tid];
         __syncthreads();
     }
+    STAMP(9)  // delta / CMVN / output tail
+#ifdef SSP_STAMP
+    if (lane == 0)
+        for (int i = 0; i < 13; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+    if (tid == 0) atomicAdd(&g_stamps[15], 1ull);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 bool mfcc_fast_supported(const ssp_mfcc_cfg& c) {
-    return c.n_fft == 512 && c.hop >= 1 && c.n_filt <= 64 && c.n_ceps <= 64 &&
+    return c.n_fft == 512 && c.hop >= 2 && (c.hop & 1) == 0 && c.n_filt <= 64 && c.n_ceps <= 64 &&
            c.frame_mode != 2 && c.top_db < 0.f && (c.delta_order == 0 || c.delta_N <= 4);
 }
 
@@ -492,10 +555,11 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len[x] > len[y]; });
     const int n_pass = (c.n_filt + 15) / 16;
     FastArgs& f = p->fast;
-    std::vector<int32_t> mel_lo(n_pass * 16, 0), mel_id(n_pass * 16, -1);
-    std::vector<float> melw;
+    const int n_pass2 = (n_pass + 1) & ~1;  // passes are swept in pairs
+    std::vector<int32_t> mel_lo(n_pass2 * 16, 0), mel_id(n_pass2 * 16, -1);
+    std::vector<std::vector<float>> wpass(n_pass2);  // [pass][step][lane][4]
+    std::vector<int> psteps(n_pass2, 0);
     const float pscale = (c.spec_power == 2 ? 0.25f : 0.5f) * c.spec_scale;  // the split step works on 2 X[k]
-    int total = 0;
     for (int ps = 0; ps < n_pass; ++ps) {
         // Bank-conflict-free sweep: the 16 lanes of a pass read P with 16-byte loads that advance in lock step, so the
         // reads never conflict when the 16 band starts fall into 16 different 16-byte bank groups (start/4 mod 16).
@@ -552,26 +616,46 @@ int build_fast_tables(ssp_mfcc_plan* p) {
         int steps4 = 0;
         for (int fi = 0; fi < nf; ++fi) steps4 = std::max(steps4, (shv[fl[fi]] - start4[fl[fi]]) / 4 + 1);
         f.mel_steps[ps] = steps4;
-        melw.resize((size_t)(total + steps4) * 64, 0.f);
+        psteps[ps] = steps4;
+        wpass[ps].assign((size_t)steps4 * 64, 0.f);
         for (int l = 0; l < 16; ++l) {
             const int s = ps * 16 + l;
             if (s >= c.n_filt) continue;
             const int jf = order[s];
             mel_id[s] = jf;
-            int sl4 = start4[l];
-            if (sl4 + 4 * steps4 > PSWEEP) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): filterbank band layout does not fit the P row");
+            const int sl4 = start4[l];
             mel_lo[s] = sl4;
             for (int k = 0; k < len[jf]; ++k) {
                 const int pos = p_sigma(lo[jf] + k) - sl4;
                 if (pos / 4 >= steps4) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): filterbank band longer than the pass sweep");
-                melw[((size_t)(total + pos / 4) * 16 + l) * 4 + (pos & 3)] = pscale * dense[(size_t)jf * nb + lo[jf] + k];
+                wpass[ps][((size_t)(pos / 4) * 16 + l) * 4 + (pos & 3)] = pscale * dense[(size_t)jf * nb + lo[jf] + k];
             }
         }
-        total += steps4;
     }
+    // pack pass pairs: [step][A|B][lane][4], blocks of 4 steps, zero padded; every sweep must stay inside the P row +
+    // the stale-but-finite Z data behind it (never reach the log-mel rows)
+    std::vector<float> melw;
+    int total = 0;
+    for (int pr = 0; pr < n_pass2 / 2; ++pr) {
+        const int nblk = (std::max(psteps[2 * pr], psteps[2 * pr + 1]) + 3) / 4;
+        f.mel_blocks[pr] = nblk;
+        melw.resize((size_t)(total + nblk * 4) * 128, 0.f);
+        for (int ab = 0; ab < 2; ++ab) {
+            const int ps = 2 * pr + ab;
+            for (int st = 0; st < psteps[ps]; ++st)
+                for (int l = 0; l < 16; ++l)
+                    for (int e = 0; e < 4; ++e)
+                        melw[(((size_t)(total + st) * 2 + ab) * 16 + l) * 4 + e] = wpass[ps][((size_t)st * 16 + l) * 4 + e];
+            for (int l = 0; l < 16; ++l)
+                if (mel_lo[ps * 16 + l] + 16 * nblk > PSWEEP)
+                    SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): filterbank sweep does not fit the P row");
+        }
+        total += nblk * 4;
+    }
+    for (int pr = n_pass2 / 2; pr < MAX_PASS / 2; ++pr) f.mel_blocks[pr] = 0;
     for (int ps = n_pass; ps < MAX_PASS; ++ps) f.mel_steps[ps] = 0;
     const int q_pass = (c.n_ceps + 15) / 16;
-    const int n_filt4 = (c.n_filt + 3) / 4;
+    const int n_filt4 = (((c.n_filt + 3) / 4) + 3) & ~3;  // 4-filter steps, padded to whole blocks of 4 steps
     // dctT[s][q][e] = dct[q][4 s + e] (zero padded): one 16-byte read per lane per 4 filters
     std::vector<float> dctT((size_t)n_filt4 * q_pass * 16 * 4, 0.f), dcth((size_t)c.n_ceps * c.n_filt);
     SSP_HIP(hipMemcpy(dcth.data(), p->dct.p, dcth.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -604,7 +688,8 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     f.mel_lo = p->f_mello.as<int32_t>();
     f.mel_id = p->f_melid.as<int32_t>();
     f.dctT = p->f_dct.as<float>();
-    f.n_pass = n_pass;
+    f.n_pass = n_pass2;
+    f.lm_pad = n_filt4 * 4 - c.n_filt;
     f.q_pass = q_pass;
     f.n_filt4 = n_filt4;
     f.total_steps = total;
@@ -632,7 +717,7 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     f.off_win = (int32_t)off;    off = al16(off + (mfcc_fast_waves() == 12 ? 512 * 4 : 0));
     f.off_tw16 = (int32_t)off;   off = al16(off + (mfcc_fast_waves() == 12 ? 240 * 8 : 0));
     f.off_wpost = (int32_t)off;  off = al16(off + (mfcc_fast_waves() == 12 ? 128 * 8 : 0));
-    f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 64 * 4);
+    f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 128 * 4);
     f.off_mello = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
     f.off_melid = f.off_mello;
     f.off_dct = (int32_t)off;    off = al16(off + (size_t)f.n_filt4 * 4 * f.q_pass * 16 * 4);
@@ -641,7 +726,7 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     f.off_stats = (int32_t)off;  off = al16(off + (size_t)2 * c.n_ceps * (1 + c.delta_order) * 4);
     off = (off + 255) & ~size_t(255);
     f.off_wave = (int32_t)off;
-    f.wave_bytes = 4 * ZFRAME;
+    f.wave_bytes = 4 * ZFRAME + (((f.slen + 255) >> 8) << 10);  // transpose images + the LDS-DMA sample stage
     return off + mfcc_fast_waves() * (size_t)f.wave_bytes + 256;  // + pad: lane 0 reads (and discards) one row past the last image
 }
 
@@ -652,8 +737,8 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
     if (getenv("SSP_DEBUG"))
         fprintf(stderr, "[ssp] mfcc fast: chunks=%d chunk_frames=%d lds=%zu B (waves %d x %d B, tables+ceps %d B) mel steps %d/%d/%d/%d\n",
-                n_chunks, chunk_frames, lds, mfcc_fast_waves(), f.wave_bytes, f.off_wave, f.mel_steps[0], f.mel_steps[1],
-                f.mel_steps[2], f.mel_steps[3]);
+                n_chunks, chunk_frames, lds, mfcc_fast_waves(), f.wave_bytes, f.off_wave, f.mel_blocks[0] * 4, f.mel_blocks[1] * 4,
+                f.mel_steps[0], f.mel_steps[1]);
     const int nz = p->cfg.win_len <= 416 ? 13 : 16, pw = p->cfg.spec_power, pr = p->cfg.preemph_mode ? 1 : 0;
     const int nw = mfcc_fast_waves();
     if ((int64_t)p->fast_max_samples * 4 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): utterance too long for 32-bit offsets");
@@ -683,3 +768,14 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
 }
 
 }  // namespace ssp
+
+#ifdef SSP_STAMP
+extern "C" int ssp_debug_stamps(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ssp::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ssp::g_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

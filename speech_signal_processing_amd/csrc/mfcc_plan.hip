@@ -193,7 +193,10 @@ int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* win
         set_error("mfcc plan: table upload failed");
         rc = SSP_ERR_HIP;
     }
-    if (rc == SSP_OK && mfcc_fast_supported(*cfg)) rc = build_fast_tables(p);
+    if (rc == SSP_OK && mfcc_fast_supported(*cfg)) {
+        const int frc = build_fast_tables(p);  // a filterbank the fused kernel cannot lay out only disables that kernel
+        if (frc != SSP_OK && frc != SSP_ERR_UNSUPPORTED) rc = frc;
+    }
     if (rc != SSP_OK) {
         delete p;
         return rc;
@@ -273,8 +276,8 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
             SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: frame segment %lld does not match the framing rule", (long long)u);
     }
     int v = variant;
-    if (v == 0) v = mfcc_fast_supported(plan->cfg) ? 2 : 1;
-    if (v == 2 && !mfcc_fast_supported(plan->cfg))
+    if (v == 0) v = (mfcc_fast_supported(plan->cfg) && plan->fast_ready) ? 2 : 1;
+    if (v == 2 && !(mfcc_fast_supported(plan->cfg) && plan->fast_ready))
         SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the fused fast kernel does not cover this cfg");
     if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_variant != v)
         SSP_TRY(build_work(plan, sample_seg, frame_seg, v));
