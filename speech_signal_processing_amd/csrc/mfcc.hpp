@@ -45,7 +45,7 @@ struct FastArgs {
     const int32_t* mel_id;  // [n_pass*16] filter id, -1 = empty slot
     const float* dctT;      // [n_filt][q_pass*16]
     int32_t mel_steps[MFCC_FAST_MAX_PASS];
-    int32_t mel_blocks[MFCC_FAST_MAX_PASS / 2];  // 4-step blocks per swept pass PAIR
+    int32_t mel_blocks[MFCC_FAST_MAX_PASS];      // 4-step blocks per pass
     int32_t lm_pad;                               // zero-padded log-mel entries behind the n_filt real ones
     int32_t n_pass, q_pass, total_steps, n_filt4;  // mel steps are 4-tap (16-byte) steps
     float ddw[17];          // delta-delta of interior frames as one convolution over 4N+1 cepstra

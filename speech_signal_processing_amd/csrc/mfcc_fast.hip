@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
 #pragma unroll
         for (int i = 0; i < 8; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);  // W_512^(j + 16 i)
     }
-    for (int i = tid; i < f.total_steps * 128; i += NT) s_melw[i] = f.melw[i];
+    for (int i = tid; i < f.total_steps * 64; i += NT) s_melw[i] = f.melw[i];
     for (int i = tid; i < f.n_pass * 16; i += NT) s_melpk[i] = f.mel_lo[i] | ((f.mel_id[i] + 1) << 16);
     for (int i = tid; i < f.n_filt4 * 4 * f.q_pass * 16; i += NT) s_dct[i] = f.dctT[i];
     __syncthreads();
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         }
 #endif
         STAMP(4)  // partner exchange + split step + P row
-        // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads).  Two passes are swept
-        //         together (slot A of pass 2p, slot B of pass 2p+1) in blocks of 4 fully unrolled steps, so a sweep is a
+        // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads), swept in blocks of
+        //         4 fully unrolled steps (weights zero padded to whole blocks), so a pass is a
         //         few rounds of independent loads instead of a long chain of dependent round trips.
 #if (!defined(SSP_ABL) || SSP_ABL < 1) && !defined(SSP_NO_MEL)
         {
@@ -343,25 +343,21 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
             float* lm = reinterpret_cast<float*>(zf + LM_OFF - 64 * g);
             if (j < f.lm_pad) lm[a.n_filt + j] = 0.f;  // padded filter slots must read as finite zeros
             int wofs = 0;
-            for (int pp2 = 0; pp2 < f.n_pass; pp2 += 2) {
-                const int nblk = f.mel_blocks[pp2 >> 1];           // 4-step blocks of this pass pair (max of the two passes)
-                const int pkA = s_melpk[pp2 * 16 + j], pkB = s_melpk[(pp2 + 1) * 16 + j];
-                const v4f* pA = reinterpret_cast<const v4f*>(P + (pkA & 0xffff));
-                const v4f* pB = reinterpret_cast<const v4f*>(P + (pkB & 0xffff));
-                const v4f* wA = reinterpret_cast<const v4f*>(s_melw + (size_t)wofs * 128) + j;  // [step][A|B][lane][4]
-                const v4f* wB = wA + 16;
-                v4f accA = v4f{0.f, 0.f, 0.f, 0.f}, accB = v4f{0.f, 0.f, 0.f, 0.f};
+            for (int ps = 0; ps < f.n_pass; ++ps) {
+                const int nblk = f.mel_blocks[ps];  // 4-step blocks of this pass (weights zero padded to whole blocks)
+                const int pk = s_melpk[ps * 16 + j];
+                const v4f* pp = reinterpret_cast<const v4f*>(P + (pk & 0xffff));
+                const v4f* ww = reinterpret_cast<const v4f*>(s_melw + (size_t)wofs * 64) + j;  // [step][lane][4]
+                v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
                 for (int blk = 0; blk < nblk; ++blk) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int st = blk * 4 + u;
-                        accA = __builtin_elementwise_fma(pA[st], wA[st * 32], accA);
-                        accB = __builtin_elementwise_fma(pB[st], wB[st * 32], accB);
+                        acc = __builtin_elementwise_fma(pp[st], ww[st * 16], acc);
                     }
                 }
-                const int idA = (pkA >> 16) - 1, idB = (pkB >> 16) - 1;
-                if (idA >= 0) lm[idA] = fast_log(a, (accA.x + accA.y) + (accA.z + accA.w));
-                if (idB >= 0) lm[idB] = fast_log(a, (accB.x + accB.y) + (accB.z + accB.w));
+                const int id = (pk >> 16) - 1;
+                if (id >= 0) lm[id] = fast_log(a, (acc.x + acc.y) + (acc.z + acc.w));
                 wofs += nblk * 4;
             }
         }
@@ -632,27 +628,21 @@ int build_fast_tables(ssp_mfcc_plan* p) {
             }
         }
     }
-    // pack pass pairs: [step][A|B][lane][4], blocks of 4 steps, zero padded; every sweep must stay inside the P row +
+    // pack the passes: [step][lane][4], whole blocks of 4 steps, zero padded; every sweep must stay inside the P row +
     // the stale-but-finite Z data behind it (never reach the log-mel rows)
     std::vector<float> melw;
     int total = 0;
-    for (int pr = 0; pr < n_pass2 / 2; ++pr) {
-        const int nblk = (std::max(psteps[2 * pr], psteps[2 * pr + 1]) + 3) / 4;
-        f.mel_blocks[pr] = nblk;
-        melw.resize((size_t)(total + nblk * 4) * 128, 0.f);
-        for (int ab = 0; ab < 2; ++ab) {
-            const int ps = 2 * pr + ab;
-            for (int st = 0; st < psteps[ps]; ++st)
-                for (int l = 0; l < 16; ++l)
-                    for (int e = 0; e < 4; ++e)
-                        melw[(((size_t)(total + st) * 2 + ab) * 16 + l) * 4 + e] = wpass[ps][((size_t)st * 16 + l) * 4 + e];
-            for (int l = 0; l < 16; ++l)
-                if (mel_lo[ps * 16 + l] + 16 * nblk > PSWEEP)
-                    SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): filterbank sweep does not fit the P row");
-        }
+    for (int ps = 0; ps < n_pass; ++ps) {
+        const int nblk = (psteps[ps] + 3) / 4;
+        f.mel_blocks[ps] = nblk;
+        melw.resize((size_t)(total + nblk * 4) * 64, 0.f);
+        std::copy(wpass[ps].begin(), wpass[ps].end(), melw.begin() + (size_t)total * 64);
+        for (int l = 0; l < 16; ++l)
+            if (mel_lo[ps * 16 + l] + 16 * nblk > PSWEEP)
+                SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): filterbank sweep does not fit the P row");
         total += nblk * 4;
     }
-    for (int pr = n_pass2 / 2; pr < MAX_PASS / 2; ++pr) f.mel_blocks[pr] = 0;
+    for (int ps = n_pass; ps < MAX_PASS; ++ps) f.mel_blocks[ps] = 0;
     for (int ps = n_pass; ps < MAX_PASS; ++ps) f.mel_steps[ps] = 0;
     const int q_pass = (c.n_ceps + 15) / 16;
     const int n_filt4 = (((c.n_filt + 3) / 4) + 3) & ~3;  // 4-filter steps, padded to whole blocks of 4 steps
@@ -688,7 +678,7 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     f.mel_lo = p->f_mello.as<int32_t>();
     f.mel_id = p->f_melid.as<int32_t>();
     f.dctT = p->f_dct.as<float>();
-    f.n_pass = n_pass2;
+    f.n_pass = n_pass;
     f.lm_pad = n_filt4 * 4 - c.n_filt;
     f.q_pass = q_pass;
     f.n_filt4 = n_filt4;
@@ -717,7 +707,7 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     f.off_win = (int32_t)off;    off = al16(off + (mfcc_fast_waves() == 12 ? 512 * 4 : 0));
     f.off_tw16 = (int32_t)off;   off = al16(off + (mfcc_fast_waves() == 12 ? 240 * 8 : 0));
     f.off_wpost = (int32_t)off;  off = al16(off + (mfcc_fast_waves() == 12 ? 128 * 8 : 0));
-    f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 128 * 4);
+    f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 64 * 4);
     f.off_mello = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
     f.off_melid = f.off_mello;
     f.off_dct = (int32_t)off;    off = al16(off + (size_t)f.n_filt4 * 4 * f.q_pass * 16 * 4);
