@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsspgpu.so")
+LIB_PATH = os.environ.get("SSP_LIB_PATH") or os.path.join(HERE, "libsspgpu.so")  # override: diagnostic builds only
 
 SSP_OK, SSP_ERR_INVALID, SSP_ERR_UNSUPPORTED, SSP_ERR_HIP, SSP_ERR_NOMEM, SSP_ERR_NODEVICE = 0, -1, -2, -3, -4, -5
 HOST, DEVICE = 0, 1

@@ -55,6 +55,15 @@ struct FastArgs {
     int32_t off_win, off_tw16, off_wpost, off_melw, off_mello, off_melid, off_dct, off_ceps, off_stats, off_wave, wave_bytes;
     float pscale;           // 0.25 * spec_scale (power) or 0.5 * spec_scale (magnitude)
     float one_minus_a;
+    // register-resident "piece" filterbank (mfcc_fast.hip step 7, MELV > 0): every lane owns up to 4*MELV consecutive taps
+    // of ONE filter; a filter's pieces sit in consecutive lanes of one 16-lane row and are summed by a masked DPP scan
+    const float* pc_w;        // [64][melv][4] weights in the lane's read order
+    const int32_t* pc_ofs;    // [64][melv]    byte offset of each 16-byte read inside a frame's P row
+    const float* pc_mask;     // [64][4]       scan masks: 1 when lane + (1 << s) holds a piece of the same filter
+    const int32_t* pc_fid;    // [64]          filter id on the first lane of a filter's run, else -1
+    int32_t melv;             // 16-byte reads per lane and frame (0: the banded sweep is used instead)
+    int32_t mel_ns;           // scan steps = ceil(log2(longest run))
+    float log_add, log_max, log_k;  // log(max(v + log_add, log_max)) * log_k  (floor_mode / log_mode, branch free)
 };
 
 int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, hipStream_t stream);
@@ -80,7 +89,7 @@ struct ssp_mfcc_plan {
     bool fast_ready = false;
     int64_t fast_max_samples = 0;  // longest utterance of the cached work table (32-bit offsets in the fast kernel)
     ssp::FastArgs fast{};
-    ssp::DevBuf f_tw16, f_wpost, f_melw, f_mello, f_melid, f_dct;
+    ssp::DevBuf f_tw16, f_wpost, f_melw, f_mello, f_melid, f_dct, f_pcw, f_pcofs, f_pcmask, f_pcfid;
 };
 
 namespace ssp {

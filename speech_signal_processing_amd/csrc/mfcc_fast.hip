@@ -115,23 +115,24 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(ph)
 #endif
 
-struct __attribute__((packed, aligned(4))) f4u {
-    float x, y, z, w;
+struct __attribute__((packed, aligned(4))) f2u {
+    float x, y;
 };
 
-__device__ __forceinline__ float fast_log(const MfccArgs& a, float v) {
-    if (a.floor_mode == 1) v += a.eps;
-    else if (a.floor_mode == 2) v = fmaxf(v, a.eps);
-    // v_log_f32 (log2, ~1 ulp on the normal range) scaled: ln / log10 / 10 log10
-    const float l2 = __builtin_amdgcn_logf(v);
-    const float k = a.log_mode == 0 ? 0.6931471805599453f : (a.log_mode == 1 ? 0.30102999566398120f : 3.0102999566398120f);
-    return l2 * k;
+// log of a filterbank output, branch free: floor_mode 1 adds eps, 2 clamps at eps (FastArgs carries 0 / -inf for the unused
+// one); v_log_f32 (log2, ~1 ulp on the normal range) scaled to ln / log10 / 10 log10
+__device__ __forceinline__ float fast_log(const FastArgs& f, float v) {
+    return __builtin_amdgcn_logf(fmaxf(v + f.log_add, f.log_max)) * f.log_k;
 }
 
 
 // NZ: non-zero 32-sample rows of the window (13 for win <= 416, else 16); POWER: 1 magnitude | 2 power spectrum;
 // PRE: per-frame pre-emphasis on/off; FAST_WAVES: waves per workgroup
-template <int NZ, int POWER, int PRE, int FAST_WAVES>
+// MELV: 0 = banded filterbank sweep from LDS tables | 2..4 = register-resident piece filterbank with MELV 16-byte reads per lane
+// TUNED: the 13-cepstra / <= 32-filter / delta_N == 2 shape of every dialect of the reference as compile-time constants
+//        (n_ceps 13, one DCT pass of 8 four-filter steps, <= 2 scan steps, N = 2 regression): no loop or branch overhead in
+//        the filterbank / DCT stages, and a delta tail that emits 4 consecutive frames per thread
+template <int NZ, int POWER, int PRE, int FAST_WAVES, int MELV, bool TUNED>
 __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES == 6) ? 3 : 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * FAST_WAVES;
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-level control flow stays on the SALU
     const int g = lane >> 4, j = lane & 15;
-    const int nc = a.n_ceps;
+    const int nc = TUNED ? 13 : a.n_ceps;
+    const int q_pass = TUNED ? 1 : f.q_pass, n_filt4 = TUNED ? 8 : f.n_filt4, mel_ns = TUNED ? 2 : f.mel_ns;
 
     float* s_melw = reinterpret_cast<float*>(smem + f.off_melw);
     int* s_melpk = reinterpret_cast<int*>(smem + f.off_mello);  // storage start | (filter id + 1) << 16
@@ -173,9 +175,26 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
 #pragma unroll
         for (int i = 0; i < 8; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);  // W_512^(j + 16 i)
     }
-    for (int i = tid; i < f.total_steps * 64; i += NT) s_melw[i] = f.melw[i];
-    for (int i = tid; i < f.n_pass * 16; i += NT) s_melpk[i] = f.mel_lo[i] | ((f.mel_id[i] + 1) << 16);
-    for (int i = tid; i < f.n_filt4 * 4 * f.q_pass * 16; i += NT) s_dct[i] = f.dctT[i];
+    // piece filterbank: this lane's taps, read offsets, scan masks and (first lane of a run) filter id live in registers
+    constexpr int MV = MELV > 0 ? MELV : 1;
+    v4f mw[MV];
+    int mofs[MV];
+    v2f mk01 = v2f{0.f, 0.f}, mk23 = v2f{0.f, 0.f};
+    int mfid = -1;
+    if (MELV > 0) {
+#pragma unroll
+        for (int i = 0; i < MV; ++i) {
+            mw[i] = *reinterpret_cast<const v4f*>(f.pc_w + ((size_t)lane * MV + i) * 4);
+            mofs[i] = f.pc_ofs[lane * MV + i];
+        }
+        mk01 = *reinterpret_cast<const v2f*>(f.pc_mask + lane * 4);
+        mk23 = *reinterpret_cast<const v2f*>(f.pc_mask + lane * 4 + 2);
+        mfid = f.pc_fid[lane];
+    } else {
+        for (int i = tid; i < f.total_steps * 64; i += NT) s_melw[i] = f.melw[i];
+        for (int i = tid; i < f.n_pass * 16; i += NT) s_melpk[i] = f.mel_lo[i] | ((f.mel_id[i] + 1) << 16);
+    }
+    for (int i = tid; i < n_filt4 * 4 * q_pass * 16; i += NT) s_dct[i] = f.dctT[i];
     __syncthreads();
 
     const MfccChunk ch = a.chunks[blockIdx.x];
@@ -220,37 +239,37 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     for (int q = wave; q < nquads; q += FAST_WAVES) {
         const int t = ta + 4 * q + g;  // this lane group's frame
         // ---- 1+2. per-frame pre-emphasis (y[0] = x[0] - a x[0], y[n] = x[n] - a x[n-1]) and window, in registers.
-        //      x[e-1] is the neighbouring lane's second sample (DPP row_shr:1); lane 0 of a frame takes it from lane 15's
-        //      previous row (DPP row_ror:1), or from itself for the very first sample of the frame.
+        //      Both operand pairs (x[e], x[e+1]) and (x[e-1], x[e]) come from the LDS stage (the VALU, not the LDS, binds).
         v2f z[16];
+#ifndef SSP_NO_DMAWAIT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this quad's DMA has landed (issued one iteration ago)
+#endif
         STAMP(10)  // wait for the DMA
+        v2f pm[PRE ? NZ : 1];  // (x[e-1], x[e]): the pre-emphasis partner pair, read from the stage as well (no cross-lane traffic)
         {
             const float* sp = stage + g * hop + 2 * j;
 #pragma unroll
-            for (int n1 = 0; n1 < NZ; ++n1) pf[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1);
+            for (int n1 = 0; n1 < NZ; ++n1) {
+                pf[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1);
+                if (PRE) {
+                    const f2u t = *reinterpret_cast<const f2u*>(sp + 32 * n1 - 1);  // 4-byte aligned pair: ds_read2_b32
+                    pm[n1] = v2f{t.x, t.y};
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is in registers: the next quad may overwrite it
         STAMP(11)  // stage reads
+#ifndef SSP_NO_DMA
         prefetch(q + FAST_WAVES);  // flies under this whole iteration (past the end it stages zeros)
+#endif
         STAMP(12)  // DMA issue
+        // y[n] = x[n] - a x[n-1] as ONE packed FMA per row; the first sample of a frame pairs with itself (y[0] = x[0] - a x[0])
+        if (PRE) pm[0].x = (j == 0) ? pf[0].x : pm[0].x;
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NZ) {
                 v2f y = pf[n1 < NZ ? n1 : 0];
-                if (PRE) {
-                    // (scalar copies first: __builtin_bit_cast on a vector ELEMENT is mis-evaluated by this clang)
-                    const float cur_x = y.x, cur_y = y.y;
-                    float prev_row_last = cur_x;
-                    if (n1 > 0) {
-                        const float last_y = pf[n1 > 0 ? n1 - 1 : 0].y;
-                        prev_row_last = __builtin_amdgcn_update_dpp(0.f, last_y, 0x121 /*row_ror:1*/, 0xF, 0xF, false);
-                    }
-                    const float xm1 = __builtin_amdgcn_update_dpp(prev_row_last, cur_y, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
-                    const float y0 = __builtin_fmaf(npre, xm1, y.x);
-                    const float y1 = __builtin_fmaf(npre, y.x, y.y);
-                    y = v2f{y0, y1};
-                }
+                if (PRE) y = __builtin_elementwise_fma(v2f{npre, npre}, pm[n1 < NZ ? n1 : 0], y);
                 z[n1] = y * (TABREG ? wreg[n1 < NZ ? n1 : 0] : *reinterpret_cast<const v2f*>(s_win + 32 * n1 + 2 * j));
             } else {
                 z[n1] = v2f{0.f, 0.f};
@@ -290,17 +309,19 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         //         DPP row permutes per value (LDS is the binding unit of this kernel, the VALU is not), and every pair
         //         is formed exactly once.
         {
-            // partner exchange inside the 16-lane row, no LDS: dst[j] = src[(16 - j) & 15] = row_ror:1(row_mirror(src))
+            // partner exchange inside the 16-lane row, no LDS: dst[j] = src[(16 - j) & 15] = row_shr:1(row_mirror(src)) for
+            // j >= 1; lane 0 has no source in the shift and keeps `old` = its own partner Z[256 - 16 k2] (register 16 - k2)
             v2f zm[8];
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
                 const float sx = z[15 - k2].x, sy = z[15 - k2].y;
-                float mx = __builtin_amdgcn_update_dpp(0.f, sx, 0x140 /*row_mirror*/, 0xF, 0xF, false);
-                float my = __builtin_amdgcn_update_dpp(0.f, sy, 0x140 /*row_mirror*/, 0xF, 0xF, false);
-                mx = __builtin_amdgcn_update_dpp(0.f, mx, 0x121 /*row_ror:1*/, 0xF, 0xF, false);
-                my = __builtin_amdgcn_update_dpp(0.f, my, 0x121 /*row_ror:1*/, 0xF, 0xF, false);
-                const v2f own = z[(16 - k2) & 15];  // lane 0 pairs with itself: Z[256 - 16 k2] = its register 16 - k2
-                zm[k2] = v2f{j == 0 ? own.x : mx, j == 0 ? own.y : my};
+                const v2f own = z[(16 - k2) & 15];
+                const float ox = own.x, oy = own.y;
+                float mx = __builtin_amdgcn_update_dpp(sx, sx, 0x140 /*row_mirror*/, 0xF, 0xF, true);
+                float my = __builtin_amdgcn_update_dpp(sy, sy, 0x140 /*row_mirror*/, 0xF, 0xF, true);
+                mx = __builtin_amdgcn_update_dpp(ox, mx, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+                my = __builtin_amdgcn_update_dpp(oy, my, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+                zm[k2] = v2f{mx, my};
             }
             float* P = reinterpret_cast<float*>(zf);
             float pa[8], pb[8];
@@ -338,7 +359,47 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         //         4 fully unrolled steps (weights zero padded to whole blocks), so a pass is a
         //         few rounds of independent loads instead of a long chain of dependent round trips.
 #if (!defined(SSP_ABL) || SSP_ABL < 1) && !defined(SSP_NO_MEL)
-        {
+        if (MELV > 0) {
+            // piece filterbank: all 64 lanes work on ONE frame at a time.  Lane = up to 4*MELV consecutive taps of one
+            // filter (weights in registers, MELV 16-byte reads of the frame's P row); the pieces of a filter sit in
+            // consecutive lanes of a 16-lane row and are added by a masked DPP suffix scan, two frames per packed FMA;
+            // the first lane of every run takes the log and stores the frame's log-mel entry.
+            float* lm = reinterpret_cast<float*>(zf + LM_OFF - 64 * g);
+            if (j < f.lm_pad) lm[a.n_filt + j] = 0.f;  // padded filter slots must read as finite zeros
+            float sfr[4];
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) {
+                const char* pr = zbuf + fr * ZFRAME;
+                v4f acc = *reinterpret_cast<const v4f*>(pr + mofs[0]) * mw[0];
+#pragma unroll
+                for (int i = 1; i < MV; ++i) acc = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(pr + mofs[i]), mw[i], acc);
+                const v2f h = v2f{acc.x, acc.y} + v2f{acc.z, acc.w};
+                sfr[fr] = h.x + h.y;
+            }
+            v2f s01 = v2f{sfr[0], sfr[1]}, s23 = v2f{sfr[2], sfr[3]};
+#define SSP_SCAN_STEP(CTRL, MK)                                                                             \
+            {                                                                                                   \
+                const float a0 = s01.x, a1 = s01.y, a2 = s23.x, a3 = s23.y;                                     \
+                const float b0 = __builtin_amdgcn_update_dpp(a0, a0, CTRL, 0xF, 0xF, true);                   \
+                const float b1 = __builtin_amdgcn_update_dpp(a1, a1, CTRL, 0xF, 0xF, true);                   \
+                const float b2 = __builtin_amdgcn_update_dpp(a2, a2, CTRL, 0xF, 0xF, true);                   \
+                const float b3 = __builtin_amdgcn_update_dpp(a3, a3, CTRL, 0xF, 0xF, true);                   \
+                s01 = __builtin_elementwise_fma(v2f{b0, b1}, MK, s01);                                          \
+                s23 = __builtin_elementwise_fma(v2f{b2, b3}, MK, s23);                                          \
+            }
+            if (mel_ns > 0) SSP_SCAN_STEP(0x101 /*row_shl:1*/, xx(mk01))
+            if (mel_ns > 1) SSP_SCAN_STEP(0x102 /*row_shl:2*/, yy(mk01))
+            if (mel_ns > 2) SSP_SCAN_STEP(0x104 /*row_shl:4*/, xx(mk23))
+            if (mel_ns > 3) SSP_SCAN_STEP(0x108 /*row_shl:8*/, yy(mk23))
+#undef SSP_SCAN_STEP
+            if (mfid >= 0) {
+                float* lmf = reinterpret_cast<float*>(zbuf + LM_OFF) + mfid;
+                lmf[0 * (ZFRAME - 64) / 4] = fast_log(f, s01.x);
+                lmf[1 * (ZFRAME - 64) / 4] = fast_log(f, s01.y);
+                lmf[2 * (ZFRAME - 64) / 4] = fast_log(f, s23.x);
+                lmf[3 * (ZFRAME - 64) / 4] = fast_log(f, s23.y);
+            }
+        } else {
             const float* P = reinterpret_cast<const float*>(zf);
             float* lm = reinterpret_cast<float*>(zf + LM_OFF - 64 * g);
             if (j < f.lm_pad) lm[a.n_filt + j] = 0.f;  // padded filter slots must read as finite zeros
@@ -357,7 +418,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
                     }
                 }
                 const int id = (pk >> 16) - 1;
-                if (id >= 0) lm[id] = fast_log(a, (acc.x + acc.y) + (acc.z + acc.w));
+                if (id >= 0) lm[id] = fast_log(f, (acc.x + acc.y) + (acc.z + acc.w));
                 wofs += nblk * 4;
             }
         }
@@ -365,15 +426,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         // ---- 8. DCT rows: lane = cepstral index, 4 filters per step, blocks of 4 fully unrolled steps
         {
             const v4f* lm4 = reinterpret_cast<const v4f*>(zf + LM_OFF - 64 * g);
-            for (int qp = 0; qp < f.q_pass; ++qp) {
+#pragma unroll
+            for (int qp = 0; qp < q_pass; ++qp) {
                 const int qq = qp * 16 + j;
                 const v4f* dd = reinterpret_cast<const v4f*>(s_dct) + qq;
                 v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
-                for (int blk = 0; blk < f.n_filt4 / 4; ++blk) {
+#pragma unroll
+                for (int blk = 0; blk < n_filt4 / 4; ++blk) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int st = blk * 4 + u;
-                        acc = __builtin_elementwise_fma(lm4[st], dd[st * f.q_pass * 16], acc);
+                        acc = __builtin_elementwise_fma(lm4[st], dd[st * q_pass * 16], acc);
                     }
                 }
                 if (qq < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + qq] = (acc.x + acc.y) + (acc.z + acc.w);
@@ -394,7 +457,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     return;
 #endif
     // ---- delta / delta-delta from the cepstra in LDS (edge padding at utterance ends, GMM_UBM.py:64)
-    const int Nd = a.delta_N;
+    const int Nd = TUNED ? 2 : a.delta_N;
     const float inv = a.delta_inv_denom;
     const int D = a.d_out;
     auto cep = [&](int u, int qq) -> float { return s_ceps[(size_t)(u - ta) * nc + qq]; };
@@ -442,7 +505,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     // ---- output: blocks of rows are assembled as a contiguous (rows x D) image in the waves' transpose LDS (idle by
     //      now) and leave with 16-byte coalesced stores; thread -> (row, cepstral index) emits c, delta, delta-delta.
     float* obuf = reinterpret_cast<float*>(smem + f.off_wave);
-    const int rows_blk = max(1, (FAST_WAVES * f.wave_bytes) / (D * 4));
+    const int rows_blk = max(4, ((FAST_WAVES * f.wave_bytes - 16) / (D * 4)) & ~3);
     const int qsub = tid & 15, rsub = tid >> 4;
     if (a.cmvn) {
         // per-utterance CMVN: (x - mean) / std per output dimension, ddof = 0, std < 10 eps -> 1 (sklearn scale)
@@ -474,33 +537,66 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     }
     for (int r0 = 0; r0 < n; r0 += rows_blk) {
         const int nr = min(rows_blk, n - r0);
-        for (int qq = qsub; qq < nc; qq += 16)
-            for (int r = rsub; r < nr; r += NT / 16) {
-                float c0, c1, c2;
-                emit(t0 + r0 + r, qq, c0, c1, c2);
-                float* o = obuf + (size_t)r * D + qq;
-                if (a.cmvn) {
-                    c0 = (c0 - s_stats[qq]) * s_stats[D + qq];
-                    if (a.delta_order >= 1) c1 = (c1 - s_stats[nc + qq]) * s_stats[D + nc + qq];
-                    if (a.delta_order >= 2) c2 = (c2 - s_stats[2 * nc + qq]) * s_stats[D + 2 * nc + qq];
-                }
-                o[0] = c0;
-                if (a.delta_order >= 1) o[nc] = c1;
-                if (a.delta_order >= 2) o[2 * nc] = c2;
-            }
-        __syncthreads();
-        // coalesced copy of nr * D floats: scalar head up to a 16-byte boundary of the destination, float4 body, scalar tail
         float* dst = out + (size_t)r0 * D;
+        // the LDS image starts at the destination's offset inside its 16-byte line, so image and destination share their
+        // 16-byte phase: aligned 16-byte LDS reads feed aligned 16-byte global stores
+        float* img = obuf + ((reinterpret_cast<uintptr_t>(dst) & 15) >> 2);
+        auto put = [&](int r, int qq, float c0, float c1, float c2) {
+            float* o = img + (size_t)r * D + qq;
+            if (a.cmvn) {
+                c0 = (c0 - s_stats[qq]) * s_stats[D + qq];
+                if (a.delta_order >= 1) c1 = (c1 - s_stats[nc + qq]) * s_stats[D + nc + qq];
+                if (a.delta_order >= 2) c2 = (c2 - s_stats[2 * nc + qq]) * s_stats[D + 2 * nc + qq];
+            }
+            o[0] = c0;
+            if (a.delta_order >= 1) o[nc] = c1;
+            if (a.delta_order >= 2) o[2 * nc] = c2;
+        };
+        if (TUNED) {
+            // thread -> (group of 4 consecutive frames, cepstral index): 12 cepstra feed 4 x (c, delta, delta-delta)
+            const int ngrp = (nr + 3) >> 2;
+            for (int idx = tid; idx < ngrp * 13; idx += NT) {
+                const int rg = idx / 13, qq = idx - rg * 13;
+                const int u0 = t0 + r0 + 4 * rg;  // first frame of the group, utterance coordinates
+                if (a.delta_order > 0 && 4 * rg + 3 < nr && u0 >= 4 && u0 + 7 <= T - 1) {
+                    const float* cp = s_ceps + (size_t)(u0 - ta) * 13 + qq;
+                    float v[12];
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) v[k] = cp[(k - 4) * 13];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float c1 = ((v[5 + i] - v[3 + i]) + 2.f * (v[6 + i] - v[2 + i])) * inv;
+                        const float c2 = f.ddw[0] * (v[i] + v[8 + i]) + f.ddw[1] * (v[1 + i] + v[7 + i]) + f.ddw[2] * (v[2 + i] + v[6 + i]) +
+                                         f.ddw[3] * (v[3 + i] + v[5 + i]) + f.ddw[4] * v[4 + i];
+                        put(4 * rg + i, qq, v[4 + i], c1, c2);
+                    }
+                } else {
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * rg + i < nr) {
+                            float c0, c1, c2;
+                            emit(u0 + i, qq, c0, c1, c2);
+                            put(4 * rg + i, qq, c0, c1, c2);
+                        }
+                }
+            }
+        } else {
+            for (int qq = qsub; qq < nc; qq += 16)
+                for (int r = rsub; r < nr; r += NT / 16) {
+                    float c0, c1, c2;
+                    emit(t0 + r0 + r, qq, c0, c1, c2);
+                    put(r, qq, c0, c1, c2);
+                }
+        }
+        __syncthreads();
+        // coalesced copy of nr * D floats: scalar head up to a 16-byte boundary, 16-byte body, scalar tail
         const int tot = nr * D;
         const int head = min(tot, (int)(((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15) >> 2));
-        if (tid < head) dst[tid] = obuf[tid];
+        if (tid < head) dst[tid] = img[tid];
         const int nvec = (tot - head) >> 2;
-        for (int i = tid; i < nvec; i += NT) {
-            const float* sp = obuf + head + 4 * i;
-            *reinterpret_cast<v4f*>(dst + head + 4 * i) = v4f{sp[0], sp[1], sp[2], sp[3]};
-        }
+        for (int i = tid; i < nvec; i += NT)
+            *reinterpret_cast<v4f*>(dst + head + 4 * i) = *reinterpret_cast<const v4f*>(img + head + 4 * i);
         const int done = head + 4 * nvec;
-        if (tid < tot - done) dst[done + tid] = obuf[done + tid];
+        if (tid < tot - done) dst[done + tid] = img[done + tid];
         __syncthreads();
     }
     STAMP(9)  // delta / CMVN / output tail
@@ -661,6 +757,89 @@ int build_fast_tables(ssp_mfcc_plan* p) {
         for (int m = -Nd; m <= Nd; ++m)
             for (int nn = -Nd; nn <= Nd; ++nn) f.ddw[m + nn + 2 * Nd] += (float)((double)m * nn / (den * den));
     }
+    // ---- register-resident piece filterbank (kernel template MELV > 0).  A piece = up to PW = 4*MELV consecutive taps of
+    //      one filter starting on a 16-byte boundary of the P row; a filter's pieces occupy consecutive lanes of one
+    //      16-lane row (first-fit decreasing over the 4 rows).  The smallest MELV in 2..4 that fits 64 lanes wins;
+    //      filterbanks that fit none (e.g. 40 folded talkbox filters at 8 kHz) keep the banded sweep (MELV = 0).
+    f.melv = 0;
+    f.mel_ns = 0;
+    std::vector<float> pc_w;
+    std::vector<int32_t> pc_ofs, pc_fid(64, -1);
+    std::vector<float> pc_mask(64 * 4, 0.f);
+    if (!getenv("SSP_MFCC_NO_PIECES")) {
+        for (int mv = 2; mv <= 4 && f.melv == 0; ++mv) {
+            const int PW = 4 * mv;
+            std::vector<int> cnt(c.n_filt, 0), ord;
+            int maxc = 0;
+            for (int jf = 0; jf < c.n_filt; ++jf) {
+                if (len[jf] == 0) continue;
+                const int s4 = lo[jf] & ~3;
+                cnt[jf] = (lo[jf] + len[jf] - s4 + PW - 1) / PW;
+                maxc = std::max(maxc, cnt[jf]);
+                ord.push_back(jf);
+            }
+            if (maxc > 16) continue;
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return cnt[x] > cnt[y]; });
+            int used[4] = {0, 0, 0, 0};
+            std::vector<int> lane_of(c.n_filt, -1);
+            bool ok = true;
+            for (int jf : ord) {
+                int r = 0;
+                while (r < 4 && used[r] + cnt[jf] > 16) ++r;
+                if (r == 4) { ok = false; break; }
+                lane_of[jf] = r * 16 + used[r];
+                used[r] += cnt[jf];
+            }
+            if (!ok) continue;
+            // a P read may run past bin 256 into the stale (finite) Z data behind the row, never into the log-mel rows
+            for (int jf : ord)
+                if ((lo[jf] & ~3) + cnt[jf] * PW > PSWEEP) ok = false;
+            if (!ok) continue;
+            f.melv = mv;
+            int ns = 0;
+            while ((1 << ns) < maxc) ++ns;
+            f.mel_ns = ns;
+            pc_w.assign((size_t)64 * mv * 4, 0.f);
+            pc_ofs.assign((size_t)64 * mv, 0);
+            std::vector<int> pstart(64, 0), pfilt(64, -1);
+            for (int jf : ord)
+                for (int pcs = 0; pcs < cnt[jf]; ++pcs) {
+                    const int l = lane_of[jf] + pcs;
+                    pstart[l] = (lo[jf] & ~3) + pcs * PW;
+                    pfilt[l] = jf;
+                    if (pcs == 0) pc_fid[l] = jf;
+                }
+            for (int l = 0; l < 64; ++l)
+                for (int st = 0; st < 4; ++st)
+                    pc_mask[l * 4 + st] = (pfilt[l] >= 0 && (l & 15) + (1 << st) < 16 && pfilt[l + (1 << st)] == pfilt[l]) ? 1.f : 0.f;
+            // read order: lane l reads its 16-byte slots in the rotated order (i + rot[l]) % mv, chosen greedily so that the
+            // lanes of one ds_read_b128 conflict group hit different 16-byte bank slots of the 256-byte LDS row
+            static const int grp_of_lane32[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+            int load[4][4][16];  // [group][read][slot]
+            for (auto& x : load) for (auto& y : x) for (int& z : y) z = 0;
+            for (int l = 0; l < 64; ++l) {
+                const int grp = (l >> 5) * 2 + grp_of_lane32[l & 31];
+                int best = 0, best_cost = 1 << 30;
+                for (int rot = 0; rot < mv; ++rot) {
+                    int cost = 0;
+                    for (int i = 0; i < mv; ++i) cost += load[grp][i][(pstart[l] / 4 + (i + rot) % mv) & 15];
+                    if (cost < best_cost) { best_cost = cost; best = rot; }
+                }
+                if (pfilt[l] < 0) best = 0;
+                for (int i = 0; i < mv; ++i) {
+                    const int slot = (i + best) % mv;
+                    if (pfilt[l] >= 0) load[grp][i][(pstart[l] / 4 + slot) & 15]++;
+                    pc_ofs[(size_t)l * mv + i] = (pstart[l] + 4 * slot) * 4;
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = pstart[l] + 4 * slot + e;
+                        const int jf = pfilt[l];
+                        if (jf >= 0 && k >= lo[jf] && k < lo[jf] + len[jf] && k < nb)
+                            pc_w[((size_t)l * mv + i) * 4 + e] = pscale * dense[(size_t)jf * nb + k];
+                    }
+                }
+            }
+        }
+    }
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
         SSP_TRY(b.alloc(bytes));
         if (bytes) SSP_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
@@ -672,6 +851,16 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     SSP_TRY(up(p->f_mello, mel_lo.data(), mel_lo.size() * sizeof(int32_t)));
     SSP_TRY(up(p->f_melid, mel_id.data(), mel_id.size() * sizeof(int32_t)));
     SSP_TRY(up(p->f_dct, dctT.data(), dctT.size() * sizeof(float)));
+    if (f.melv > 0) {
+        SSP_TRY(up(p->f_pcw, pc_w.data(), pc_w.size() * sizeof(float)));
+        SSP_TRY(up(p->f_pcofs, pc_ofs.data(), pc_ofs.size() * sizeof(int32_t)));
+        SSP_TRY(up(p->f_pcmask, pc_mask.data(), pc_mask.size() * sizeof(float)));
+        SSP_TRY(up(p->f_pcfid, pc_fid.data(), pc_fid.size() * sizeof(int32_t)));
+        f.pc_w = p->f_pcw.as<float>();
+        f.pc_ofs = p->f_pcofs.as<int32_t>();
+        f.pc_mask = p->f_pcmask.as<float>();
+        f.pc_fid = p->f_pcfid.as<int32_t>();
+    }
     f.tw16 = p->f_tw16.as<float2>();
     f.wpost = p->f_wpost.as<float2>();
     f.melw = p->f_melw.as<float>();
@@ -688,6 +877,9 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     f.stage_floats = (f.slen + 255) & ~255;  // whole 256-float chunks are staged
     f.pscale = (c.spec_power == 2 ? 0.25f : 0.5f) * c.spec_scale;
     f.one_minus_a = 1.0f - c.preemph;
+    f.log_add = c.floor_mode == 1 ? c.eps : 0.f;
+    f.log_max = c.floor_mode == 2 ? c.eps : -INFINITY;
+    f.log_k = c.log_mode == 0 ? 0.6931471805599453f : (c.log_mode == 1 ? 0.30102999566398120f : 3.0102999566398120f);
     p->fast_ready = true;
     return SSP_OK;
 }
@@ -698,7 +890,12 @@ static size_t al16(size_t x) { return (x + 15) & ~size_t(15); }
 int mfcc_fast_waves() {
     const char* e = getenv("SSP_MFCC_WAVES");
     const int w = e ? atoi(e) : FAST_WAVES_DEFAULT;
-    return (w == 4 || w == 6 || w == 8 || w == 12) ? w : FAST_WAVES_DEFAULT;
+#ifdef SSP_FAST_WAVES8
+    return (w == 4 || w == 8) ? w : FAST_WAVES_DEFAULT;
+#else
+    (void)w;
+    return FAST_WAVES_DEFAULT;
+#endif
 }
 
 size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
@@ -707,7 +904,7 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     f.off_win = (int32_t)off;    off = al16(off + (mfcc_fast_waves() == 12 ? 512 * 4 : 0));
     f.off_tw16 = (int32_t)off;   off = al16(off + (mfcc_fast_waves() == 12 ? 240 * 8 : 0));
     f.off_wpost = (int32_t)off;  off = al16(off + (mfcc_fast_waves() == 12 ? 128 * 8 : 0));
-    f.off_melw = (int32_t)off;   off = al16(off + (size_t)f.total_steps * 64 * 4);
+    f.off_melw = (int32_t)off;   off = al16(off + (f.melv > 0 ? 0 : (size_t)f.total_steps * 64 * 4));  // piece filterbank: weights in registers
     f.off_mello = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
     f.off_melid = f.off_mello;
     f.off_dct = (int32_t)off;    off = al16(off + (size_t)f.n_filt4 * 4 * f.q_pass * 16 * 4);
@@ -726,22 +923,35 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
     const size_t lds = mfcc_fast_lds(p->cfg, f, chunk_frames);
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
     if (getenv("SSP_DEBUG"))
-        fprintf(stderr, "[ssp] mfcc fast: chunks=%d chunk_frames=%d lds=%zu B (waves %d x %d B, tables+ceps %d B) mel steps %d/%d/%d/%d\n",
+        fprintf(stderr, "[ssp] mfcc fast: chunks=%d chunk_frames=%d lds=%zu B (waves %d x %d B, tables+ceps %d B) mel steps %d/%d/%d/%d melv %d ns %d\n",
                 n_chunks, chunk_frames, lds, mfcc_fast_waves(), f.wave_bytes, f.off_wave, f.mel_blocks[0] * 4, f.mel_blocks[1] * 4,
-                f.mel_steps[0], f.mel_steps[1]);
+                f.mel_steps[0], f.mel_steps[1], f.melv, f.mel_ns);
     const int nz = p->cfg.win_len <= 416 ? 13 : 16, pw = p->cfg.spec_power, pr = p->cfg.preemph_mode ? 1 : 0;
     const int nw = mfcc_fast_waves();
     if ((int64_t)p->fast_max_samples * 4 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): utterance too long for 32-bit offsets");
     bool launched = false;
-#define SSP_FAST_CASE(NZ_, PW_, PR_, NW_)                                                                              \
-    if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && nw == NW_) {                                              \
-        auto* kfn = mfcc_fused512_kernel<NZ_, PW_, PR_, NW_>;                                                          \
+    const ssp_mfcc_cfg& c = p->cfg;
+    const bool tuned = f.melv > 0 && f.mel_ns <= 2 && c.n_ceps == 13 && f.n_filt4 == 8 && f.q_pass == 1 &&
+                       (c.delta_order == 0 || c.delta_N == 2) && !getenv("SSP_MFCC_NO_TUNED");
+#define SSP_FAST_CASE(NZ_, PW_, PR_, NW_, MV_, TU_)                                                                    \
+    if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && nw == NW_ && f.melv == MV_ && tuned == TU_) {             \
+        auto* kfn = mfcc_fused512_kernel<NZ_, PW_, PR_, NW_, MV_, TU_>;                                                \
         if (lds > 64 * 1024)                                                                                           \
             SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kfn, dim3(n_chunks), dim3(64 * NW_), lds, stream, args, f);                                 \
         launched = true;                                                                                               \
     }
-#define SSP_FAST_NW(NZ_, PW_, PR_) SSP_FAST_CASE(NZ_, PW_, PR_, 4) SSP_FAST_CASE(NZ_, PW_, PR_, 6) SSP_FAST_CASE(NZ_, PW_, PR_, 8) SSP_FAST_CASE(NZ_, PW_, PR_, 12)
+#define SSP_FAST_MV(NZ_, PW_, PR_, NW_)                                                                                \
+    SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 0, false) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 2, false) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 3, false) \
+    SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 4, false) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 3, true) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 4, true)
+#ifdef SSP_FAST_WAVES8  // experiment: 8-wave workgroups (one per CU)
+#define SSP_FAST_NW(NZ_, PW_, PR_) SSP_FAST_MV(NZ_, PW_, PR_, 4) SSP_FAST_MV(NZ_, PW_, PR_, 8)
+#else
+#define SSP_FAST_NW(NZ_, PW_, PR_) SSP_FAST_MV(NZ_, PW_, PR_, 4)
+#endif
+#ifdef SSP_FAST_MINIMAL  // diagnostic builds: only the benchmark instance
+    SSP_FAST_CASE(13, 2, 1, 4, 3, true)
+#else
     SSP_FAST_NW(13, 2, 1)
     SSP_FAST_NW(13, 2, 0)
     SSP_FAST_NW(13, 1, 1)
@@ -750,7 +960,9 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
     SSP_FAST_NW(16, 2, 0)
     SSP_FAST_NW(16, 1, 1)
     SSP_FAST_NW(16, 1, 0)
+#endif
 #undef SSP_FAST_NW
+#undef SSP_FAST_MV
 #undef SSP_FAST_CASE
     if (!launched) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): no kernel instance for this cfg");
     SSP_HIP(hipGetLastError());
