@@ -57,10 +57,22 @@ __device__ __forceinline__ v2f sub_neg_i(v2f t, v2f u) { return __builtin_elemen
 __device__ __forceinline__ v2f cmulc(v2f z, float c, float s) {
     return __builtin_elementwise_fma(yy(z), v2f{-s, c}, xx(z) * v2f{c, s});
 }
-// z * w, w from a table: wi = (-w.y, w.x) is formed once per twiddle
+// z * w in TWO packed instructions with no second copy of w: the (-w.y, w.x) operand of the second FMA is formed by the
+// instruction's own half selects and neg_lo modifier (the compiler otherwise keeps swap(w) * (-1, 1) in extra VGPRs)
 __device__ __forceinline__ v2f cmul(v2f z, v2f w) {
-    const v2f wi = swap(w) * v2f{-1.f, 1.f};
-    return __builtin_elementwise_fma(yy(z), wi, xx(z) * w);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(z), "v"(w));                       // (z.x w.x, z.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"              // + (-z.y w.y, z.y w.x)
+        : "=v"(r) : "v"(z), "v"(w), "v"(t));
+    return r;
+}
+// (-i z) * w = (z.y w.x + z.x w.y, z.y w.y - z.x w.x), same two-instruction form
+__device__ __forceinline__ v2f cmul_negi(v2f z, v2f w) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(z), "v"(w));         // (z.y w.x, z.y w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]"              // + (z.x w.y, -z.x w.x)
+        : "=v"(r) : "v"(z), "v"(w), "v"(t));
+    return r;
 }
 // z * w with both w = (wr, wi) and iw = (-wi, wr) at hand (registers): two packed instructions
 __device__ __forceinline__ v2f cmul2(v2f z, v2f w, v2f iw) { return __builtin_elementwise_fma(yy(z), iw, xx(z) * w); }
@@ -197,6 +209,10 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     for (int i = tid; i < n_filt4 * 4 * q_pass * 16; i += NT) s_dct[i] = f.dctT[i];
     __syncthreads();
 
+#ifdef SSP_SETUP_ONLY  // ablation: cost of workgroup launch + table setup alone
+    if (mw[0].x == 12345.f) a.out[tid] = wreg[0].x + twr[3].y + wpr[2].x + mk01.x + mk23.y + (float)mofs[0] + (float)mfid + s_dct[tid];
+    return;
+#endif
     const MfccChunk ch = a.chunks[blockIdx.x];
     const int64_t s0 = a.sample_off[ch.utt];
     const int64_t N = a.sample_off[ch.utt + 1] - s0;
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
                 const v2f w = TABREG ? wpr[k2] : s_wpost[k2 * 16 + j];                  // W_512^(j + 16 k2)
                 const v2f e = __builtin_elementwise_fma(zm[k2], v2f{1.f, -1.f}, zk);   // 2E = Z[k] + conj Z[256-k]
                 const v2f d = __builtin_elementwise_fma(zm[k2], v2f{-1.f, 1.f}, zk);   // 2D = Z[k] - conj Z[256-k]
-                const v2f o = cmul(swap(d) * v2f{1.f, -1.f}, w);                       // 2 (-i D) W^k
+                const v2f o = cmul_negi(d, w);                                         // 2 (-i D) W^k
                 const v2f xa = e + o, xb = e - o;                                      // 2 X[k], conj(2 X[256-k])
                 const v2f sa = xa * xa, sb = xb * xb;
                 pa[k2] = sa.x + sa.y;
@@ -920,7 +936,8 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
 int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int chunk_frames, hipStream_t stream) {
     if (n_chunks <= 0) return SSP_OK;
     FastArgs f = p->fast;
-    const size_t lds = mfcc_fast_lds(p->cfg, f, chunk_frames);
+    size_t lds = mfcc_fast_lds(p->cfg, f, chunk_frames);
+    if (const char* e = getenv("SSP_MFCC_LDS_PAD")) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(e));  // diagnostic: caps the workgroups per CU
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
     if (getenv("SSP_DEBUG"))
         fprintf(stderr, "[ssp] mfcc fast: chunks=%d chunk_frames=%d lds=%zu B (waves %d x %d B, tables+ceps %d B) mel steps %d/%d/%d/%d melv %d ns %d\n",
