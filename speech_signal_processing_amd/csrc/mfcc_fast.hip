@@ -11,7 +11,7 @@
 //      between neighbouring frames is served by L1/L2, HBM sees every sample once)
 //   2. pre-emphasis + window in registers: z[n1] = (y[32 n1 + 2 n2], y[32 n1 + 2 n2 + 1]) * w     (n1 = 0..NZ-1, rest zero)
 //   3. radix-16 FFT over n1 in registers, twiddle W_256^(n2 k1)
-//   4. 16x16 transpose through LDS (144-B padded rows: conflict-free ds_write_b64 / ds_read_b128)
+//   4. 16x16 transpose through LDS (unpadded 128-B rows, 16-byte chunks XOR-swizzled: conflict-free ds_write_b64 / ds_read_b128)
 //   5. radix-16 FFT over n2 in registers -> Z[k1 + 16 k2]
 //   6. split step of the real FFT: lane k1 owns the bin pairs k = k1 + 16 k2 <-> 256 - k (k2 < 8); the partners sit in the
 //      upper half of lane 16 - k1's registers, so only that half is exchanged through LDS; power / magnitude go to a
@@ -33,12 +33,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int ZROW = 144;             // bytes per 16-complex row of the transpose / Z image (128 + 16 pad)
-constexpr int ZFRAME = 16 * ZROW;     // 2304 B per frame (multiple of 256 B: keeps the 4 frames bank-aligned)
-constexpr int PSTR = 260;             // floats per frame of the P (power spectrum) row: 257 bins + pad
+constexpr int ZROW = 128;             // bytes per 16-complex row of the transpose / Z image: no padding, the 16-byte chunks of
+                                      // row r are XOR-swizzled by (r >> 1) & 7 instead (conflict-free writes and 16-byte reads)
+constexpr int ZFRAME = 16 * ZROW;     // 2048 B per frame
 constexpr int MAX_PASS = MFCC_FAST_MAX_PASS;
 constexpr int FAST_WAVES_DEFAULT = 4;  // waves per workgroup; two ~60 KiB workgroups per CU = 2 waves per SIMD, 256-VGPR budget
-constexpr int LM_OFF = 2048;          // byte offset of frame 0's log-mel row (64 floats) at the END of its Z image; frame g
+constexpr int LM_OFF = 1792;          // byte offset of frame 0's log-mel row (<= 48 floats) near the END of its Z image; frame g
                                       // sits 64 g bytes lower so the 4 frames' broadcast reads use different banks
 constexpr int PSWEEP = (LM_OFF - 192) / 4;    // filterbank sweeps may run past the P row into stale (finite) Z data, never into log-mel
 
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     float* s_dct = reinterpret_cast<float*>(smem + f.off_dct);
     float* s_ceps = reinterpret_cast<float*>(smem + f.off_ceps);
     float* s_stats = reinterpret_cast<float*>(smem + f.off_stats);
-    // wave-private LDS: ONE region of 4 frame images (2304 B each) that is, in program order, the transpose image, the
+    // wave-private LDS: ONE region of 4 frame images (2048 B each) that is, in program order, the transpose image, the
     // Z image, the P rows and the log-mel rows of the quad
     char* zbuf = smem + f.off_wave + wave * f.wave_bytes;
 
@@ -302,13 +302,25 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         // ---- 4. transpose through LDS
         char* zf = zbuf + g * ZFRAME;
 #if (!defined(SSP_ABL) || SSP_ABL < 3) && !defined(SSP_NO_T2)
+        {
+            // lane j (= n2) stores z[k1] into row k1, 8-byte slot j of the row: 16-byte chunk (j >> 1) ^ m, m = (k1 >> 1) & 7
+            int wb0 = ((j >> 1) << 4) | ((j & 1) << 3);
+            asm volatile("" : "+v"(wb0));  // keeps the 7 swizzled bases out of loop-invariant registers (one v_xor each instead)
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) *reinterpret_cast<v2f*>(zf + k1 * ZROW + j * 8) = z[k1];
+            for (int m = 0; m < 8; ++m) {
+                char* wp = zf + (wb0 ^ (m << 4));
+                *reinterpret_cast<v2f*>(wp + (2 * m) * ZROW) = z[2 * m];
+                *reinterpret_cast<v2f*>(wp + (2 * m + 1) * ZROW) = z[2 * m + 1];
+            }
+            // lane j (= k1) reads row j: logical chunk c (columns 2c, 2c+1) sits at chunk c ^ ((j >> 1) & 7)
+            int rb0 = j * ZROW + (((j >> 1) & 7) << 4);
+            asm volatile("" : "+v"(rb0));
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const v4f r = *reinterpret_cast<const v4f*>(zf + j * ZROW + c * 16);
-            z[2 * c] = v2f{r.x, r.y};
-            z[2 * c + 1] = v2f{r.z, r.w};
+            for (int c = 0; c < 8; ++c) {
+                const v4f r = *reinterpret_cast<const v4f*>(zf + (rb0 ^ (c << 4)));
+                z[2 * c] = v2f{r.x, r.y};
+                z[2 * c + 1] = v2f{r.z, r.w};
+            }
         }
         STAMP(2)  // transpose write + read
         // ---- 5. FFT16 over n2: lane j = k1, register = k2
