@@ -62,6 +62,7 @@ struct DevBuf {
         bytes = n;
         return SSP_OK;
     }
+    int reserve(size_t n) { return (p && bytes >= n) ? SSP_OK : alloc(n); }  // grow-only scratch
     template <class T>
     T* as() const {
         return static_cast<T*>(p);

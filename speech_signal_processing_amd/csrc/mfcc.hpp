@@ -63,7 +63,12 @@ struct FastArgs {
     const int32_t* pc_fid;    // [64]          filter id on the first lane of a filter's run, else -1
     int32_t melv;             // 16-byte reads per lane and frame (0: the banded sweep is used instead)
     int32_t mel_ns;           // scan steps = ceil(log2(longest run))
-    float log_add, log_max, log_k;  // log(max(v + log_add, log_max)) * log_k  (floor_mode / log_mode, branch free)
+    float log_add, log_max, log_k;
+    // persistent workgroups
+    float* ceps_scratch;      // [grid][ceps_stride] cepstra of the chunk each workgroup has in flight
+    int32_t* work_counter;    // next chunk to claim (zeroed before every launch)
+    int32_t ceps_stride;      // floats per workgroup slot (multiple of 4)
+    int32_t n_chunks;  // log(max(v + log_add, log_max)) * log_k  (floor_mode / log_mode, branch free)
 };
 
 int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, hipStream_t stream);
@@ -89,12 +94,13 @@ struct ssp_mfcc_plan {
     bool fast_ready = false;
     int64_t fast_max_samples = 0;  // longest utterance of the cached work table (32-bit offsets in the fast kernel)
     ssp::FastArgs fast{};
-    ssp::DevBuf f_tw16, f_wpost, f_melw, f_mello, f_melid, f_dct, f_pcw, f_pcofs, f_pcmask, f_pcfid;
+    ssp::DevBuf f_tw16, f_wpost, f_melw, f_mello, f_melid, f_dct, f_pcw, f_pcofs, f_pcmask, f_pcfid, f_scratch, f_counter;
 };
 
 namespace ssp {
 bool mfcc_fast_supported(const ssp_mfcc_cfg& cfg);
 int build_fast_tables(ssp_mfcc_plan* plan);
 size_t mfcc_fast_lds(const ssp_mfcc_cfg& cfg, FastArgs& f, int chunk_frames);
+int mfcc_fast_max_chunk(const ssp_mfcc_cfg& cfg, const FastArgs& f);  // most frames one workgroup can take at once
 int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, int chunk_frames, hipStream_t stream);
 }  // namespace ssp

@@ -145,7 +145,10 @@ __device__ __forceinline__ float fast_log(const FastArgs& f, float v) {
 //        (n_ceps 13, one DCT pass of 8 four-filter steps, <= 2 scan steps, N = 2 regression): no loop or branch overhead in
 //        the filterbank / DCT stages, and a delta tail that emits 4 consecutive frames per thread
 template <int NZ, int POWER, int PRE, int FAST_WAVES, int MELV, bool TUNED>
-__global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES == 6) ? 3 : 2) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
+#ifndef SSP_FAST_OCC
+#define SSP_FAST_OCC 3  // waves per SIMD the register budget is cut for (168 VGPRs)
+#endif
+__global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * FAST_WAVES;
     constexpr bool TABREG = FAST_WAVES != 12;  // 3 waves/SIMD (12-wave workgroup) has no registers to spare: tables in LDS
@@ -158,7 +161,6 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     float* s_melw = reinterpret_cast<float*>(smem + f.off_melw);
     int* s_melpk = reinterpret_cast<int*>(smem + f.off_mello);  // storage start | (filter id + 1) << 16
     float* s_dct = reinterpret_cast<float*>(smem + f.off_dct);
-    float* s_ceps = reinterpret_cast<float*>(smem + f.off_ceps);
     float* s_stats = reinterpret_cast<float*>(smem + f.off_stats);
     // wave-private LDS: ONE region of 4 frame images (2048 B each) that is, in program order, the transpose image, the
     // Z image, the P rows and the log-mel rows of the quad
@@ -213,7 +215,20 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     if (mw[0].x == 12345.f) a.out[tid] = wreg[0].x + twr[3].y + wpr[2].x + mk01.x + mk23.y + (float)mofs[0] + (float)mfid + s_dct[tid];
     return;
 #endif
-    const MfccChunk ch = a.chunks[blockIdx.x];
+    // ---- persistent workgroup: chunks are claimed from a global counter (ragged batches balance themselves); the tables
+    //      above are loaded once per workgroup.  Cepstra of the chunk in flight go to this workgroup's slot of a small global
+    //      scratch (L2 / Infinity-Cache resident: grid x 16 KiB) instead of LDS, which is what lets 3 workgroups share a CU.
+    __shared__ int s_next;
+    float* __restrict__ scr = f.ceps_scratch + (size_t)blockIdx.x * f.ceps_stride;
+#ifdef SSP_STAMP
+    unsigned long long st_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+#endif
+  for (;;) {
+    if (tid == 0) s_next = atomicAdd(f.work_counter, 1);
+    __syncthreads();
+    const int cidx = __builtin_amdgcn_readfirstlane(s_next);
+    if (cidx >= f.n_chunks) break;
+    const MfccChunk ch = a.chunks[cidx];
     const int64_t s0 = a.sample_off[ch.utt];
     const int64_t N = a.sample_off[ch.utt + 1] - s0;
     const int64_t f0 = a.frame_off[ch.utt];
@@ -230,27 +245,36 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     //      buffer loads that write the wave-private stage directly: no VGPRs, 4 instructions per quad, every sample
     //      crosses L2 ~1.4x instead of the 2.1x of per-lane gathers), one quad ahead.  Bounds-checked: anything
     //      outside the utterance [0, N) lands as 0 = the zero padding the dialects need.
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(N * 4), 0x00020000);
+    // (the descriptor is assembled from readfirstlane'd words: the compiler must see it as wave-uniform, or every DMA
+    //  instruction is wrapped in a waterfall loop of readfirstlane / compare / branch)
+    const uint64_t xaddr = reinterpret_cast<uint64_t>(x);
+    const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xaddr), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xaddr >> 32));
+    const int xbytes = __builtin_amdgcn_readfirstlane((int)(N * 4));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<float*>(((uint64_t)xhi << 32) | xlo), 0, xbytes, 0x00020000);
     float* stage = reinterpret_cast<float*>(zbuf + 4 * ZFRAME);
-    const bool dma16 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((hop & 3) == 0);  // wave-uniform
-    const int n_piece = (f.slen + 255) >> 8;  // 1 KiB pieces
+    const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)stage);
+    const bool dma16 = ((xlo & 15) == 0) && ((hop & 3) == 0);  // wave-uniform
+    const int n_piece = (f.slen + 255) >> 8;  // 1 KiB pieces (<= 5: slen <= 3 * 256 + 512 floats)
     auto prefetch = [&](int q) {
         const int sq4 = (ta + 4 * q) * hop * 4;  // byte offset of the quad's first sample inside the utterance
         if (dma16) {
-            for (int c = 0; c < n_piece; ++c)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage + c * 256), 16, sq4 + c * 1024 + lane * 16, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+                if (c < n_piece)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(stage_lds + c * 1024), 16, sq4 + c * 1024 + lane * 16, 0, 0, 0);
         } else {  // ragged batches whose utterances do not start on 16-byte boundaries: 4-byte DMA pieces
             for (int c = 0; c < 4 * n_piece; ++c)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(stage + c * 64), 4, sq4 + c * 256 + lane * 4, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(stage_lds + c * 256), 4, sq4 + c * 256 + lane * 4, 0, 0, 0);
         }
     };
     v2f pf[NZ];   // (x[e], x[e+1]),  e = g*hop + 32 n1 + 2 j inside the staged quad
 #ifdef SSP_STAMP
-    unsigned long long st_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     prefetch(wave);
+    float cdef = 0.f;   // the cepstrum of the previous quad: stored one iteration late so that the store (like the DMA) has a whole
+    int cdef_off = -1;  // iteration to complete before the next s_waitcnt vmcnt(0)
     const float npre = -pre;
     for (int q = wave; q < nquads; q += FAST_WAVES) {
         const int t = ta + 4 * q + g;  // this lane group's frame
@@ -261,16 +285,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this quad's DMA has landed (issued one iteration ago)
 #endif
         STAMP(10)  // wait for the DMA
-        v2f pm[PRE ? NZ : 1];  // (x[e-1], x[e]): the pre-emphasis partner pair, read from the stage as well (no cross-lane traffic)
+        v2f pm[PRE ? NZ : 1];  // (x[e-2], x[e-1]): the pre-emphasis partner comes from the stage too (aligned 8-byte reads: the
+                               // 4-byte-aligned pair (x[e-1], x[e]) would be a ds_read2_b32 with 2-way bank conflicts between frames)
         {
             const float* sp = stage + g * hop + 2 * j;
 #pragma unroll
             for (int n1 = 0; n1 < NZ; ++n1) {
                 pf[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1);
-                if (PRE) {
-                    const f2u t = *reinterpret_cast<const f2u*>(sp + 32 * n1 - 1);  // 4-byte aligned pair: ds_read2_b32
-                    pm[n1] = v2f{t.x, t.y};
-                }
+                if (PRE) pm[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1 - 2);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is in registers: the next quad may overwrite it
@@ -278,14 +300,18 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
 #ifndef SSP_NO_DMA
         prefetch(q + FAST_WAVES);  // flies under this whole iteration (past the end it stages zeros)
 #endif
+        if (cdef_off >= 0) scr[cdef_off] = cdef;
         STAMP(12)  // DMA issue
-        // y[n] = x[n] - a x[n-1] as ONE packed FMA per row; the first sample of a frame pairs with itself (y[0] = x[0] - a x[0])
-        if (PRE) pm[0].x = (j == 0) ? pf[0].x : pm[0].x;
+        // y[n] = x[n] - a x[n-1]; the first sample of a frame pairs with itself (y[0] = x[0] - a x[0])
+        if (PRE) pm[0].y = (j == 0) ? pf[0].x : pm[0].y;
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NZ) {
                 v2f y = pf[n1 < NZ ? n1 : 0];
-                if (PRE) y = __builtin_elementwise_fma(v2f{npre, npre}, pm[n1 < NZ ? n1 : 0], y);
+                if (PRE) {
+                    const float xm1 = pm[n1 < NZ ? n1 : 0].y, x0 = y.x, x1 = y.y;
+                    y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
+                }
                 z[n1] = y * (TABREG ? wreg[n1 < NZ ? n1 : 0] : *reinterpret_cast<const v2f*>(s_win + 32 * n1 + 2 * j));
             } else {
                 z[n1] = v2f{0.f, 0.f};
@@ -467,23 +493,38 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
                         acc = __builtin_elementwise_fma(lm4[st], dd[st * q_pass * 16], acc);
                     }
                 }
-                if (qq < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + qq] = (acc.x + acc.y) + (acc.z + acc.w);
+                const float cv = (acc.x + acc.y) + (acc.z + acc.w);
+                const int coff = (qq < nc && t < tb) ? (t - ta) * nc + qq : -1;
+                if (qp == 0) {
+                    cdef = cv;
+                    cdef_off = coff;
+                } else if (coff >= 0) {
+                    scr[coff] = cv;
+                }
             }
         }
 #else
-        if (j < nc && t < tb) s_ceps[(size_t)(t - ta) * nc + j] = reinterpret_cast<const float*>(zf)[j + 7];  // ablation: no filterbank / DCT
+        cdef = reinterpret_cast<const float*>(zf)[j + 7];  // ablation: no filterbank / DCT
+        cdef_off = (j < nc && t < tb) ? (t - ta) * nc + j : -1;
 #endif
         STAMP(6)  // DCT + cepstra
     }
     STAMP(7)  // loop exit
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may still be landing when the stage is reused below
+    if (cdef_off >= 0) scr[cdef_off] = cdef;
+    // no LDS-DMA may still be landing when the wave regions are reused below, and every cepstrum store must have completed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     STAMP(8)  // barrier wait
-
 #if (defined(SSP_ABL) && SSP_ABL >= 4) || defined(SSP_NO_TAIL)
-    if (tid == 0) a.out[(size_t)(f0 + t0) * a.d_out] = s_ceps[0];
-    return;
+    if (tid == 0) a.out[(size_t)(f0 + t0) * a.d_out] = scr[0];
+    __syncthreads();
+    continue;
 #endif
+    // ---- the chunk's cepstra come back from the scratch into the (now idle) wave regions: coalesced 16-byte copies
+    float* s_ceps = reinterpret_cast<float*>(smem + f.off_wave);
+    const int ceps_floats = ((tb - ta) * nc + 3) & ~3;
+    for (int i = tid; i < ceps_floats / 4; i += NT) reinterpret_cast<v4f*>(s_ceps)[i] = reinterpret_cast<const v4f*>(scr)[i];
+    __syncthreads();
     // ---- delta / delta-delta from the cepstra in LDS (edge padding at utterance ends, GMM_UBM.py:64)
     const int Nd = TUNED ? 2 : a.delta_N;
     const float inv = a.delta_inv_denom;
@@ -532,8 +573,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
     float* __restrict__ out = a.out + (size_t)(f0 + t0) * D;
     // ---- output: blocks of rows are assembled as a contiguous (rows x D) image in the waves' transpose LDS (idle by
     //      now) and leave with 16-byte coalesced stores; thread -> (row, cepstral index) emits c, delta, delta-delta.
-    float* obuf = reinterpret_cast<float*>(smem + f.off_wave);
-    const int rows_blk = max(4, ((FAST_WAVES * f.wave_bytes - 16) / (D * 4)) & ~3);
+    float* obuf = s_ceps + ceps_floats;
+    const int rows_blk = max(4, ((FAST_WAVES * f.wave_bytes - ceps_floats * 4 - 16) / (D * 4)) & ~3);
     const int qsub = tid & 15, rsub = tid >> 4;
     if (a.cmvn) {
         // per-utterance CMVN: (x - mean) / std per output dimension, ddof = 0, std < 10 eps -> 1 (sklearn scale)
@@ -628,6 +669,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
         __syncthreads();
     }
     STAMP(9)  // delta / CMVN / output tail
+  }  // persistent chunk loop
 #ifdef SSP_STAMP
     if (lane == 0)
         for (int i = 0; i < 13; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
@@ -637,7 +679,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, (FAST_WAVES == 12 || FAST_WAVES ==
 
 // ------------------------------------------------------------------------------------------------ host side
 bool mfcc_fast_supported(const ssp_mfcc_cfg& c) {
-    return c.n_fft == 512 && c.hop >= 2 && (c.hop & 1) == 0 && c.n_filt <= 64 && c.n_ceps <= 64 &&
+    return c.n_fft == 512 && c.hop >= 2 && c.hop <= 256 && (c.hop & 1) == 0 && c.n_filt <= 64 && c.n_ceps <= 64 &&
            c.frame_mode != 2 && c.top_db < 0.f && (c.delta_order == 0 || c.delta_N <= 4);
 }
 
@@ -843,20 +885,44 @@ int build_fast_tables(ssp_mfcc_plan* p) {
             // read order: lane l reads its 16-byte slots in the rotated order (i + rot[l]) % mv, chosen greedily so that the
             // lanes of one ds_read_b128 conflict group hit different 16-byte bank slots of the 256-byte LDS row
             static const int grp_of_lane32[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
-            int load[4][4][16];  // [group][read][slot]
-            for (auto& x : load) for (auto& y : x) for (int& z : y) z = 0;
+            auto grp = [&](int l) { return (l >> 5) * 2 + grp_of_lane32[l & 31]; };
+            std::vector<int> rot(64, 0);
+            // LDS cycles of the mv reads of one frame: per conflict group and read, the most distinct addresses on one slot
+            auto cycles = [&]() {
+                int tot = 0;
+                for (int gq = 0; gq < 4; ++gq)
+                    for (int i = 0; i < mv; ++i) {
+                        int cntslot[16] = {0}, seen_addr[16][16], worst = 0;
+                        for (int l = 0; l < 64; ++l) {
+                            if (grp(l) != gq) continue;
+                            const int a = pfilt[l] < 0 ? 0 : pstart[l] + 4 * ((i + rot[l]) % mv);
+                            const int sl = (a / 4) & 15;
+                            bool dup = false;
+                            for (int k = 0; k < cntslot[sl]; ++k) dup = dup || seen_addr[sl][k] == a;
+                            if (!dup) seen_addr[sl][cntslot[sl]++] = a;
+                            worst = std::max(worst, cntslot[sl]);
+                        }
+                        tot += worst;
+                    }
+                return tot;
+            };
+            int best = cycles();
+            uint32_t rng = 12345u;
+            for (int it = 0; it < 20000 && best > 4 * mv; ++it) {
+                rng = rng * 1664525u + 1013904223u;
+                const int l = (rng >> 8) & 63;
+                if (pfilt[l] < 0) continue;
+                rng = rng * 1664525u + 1013904223u;
+                const int old_rot = rot[l];
+                rot[l] = (int)((rng >> 8) % (uint32_t)mv);
+                const int cst = cycles();
+                if (cst <= best) best = cst;
+                else rot[l] = old_rot;
+            }
+            if (getenv("SSP_DEBUG")) fprintf(stderr, "[ssp] mfcc fast: piece filterbank melv %d, %d LDS cycles per frame (ideal %d)\n", mv, best, 4 * mv);
             for (int l = 0; l < 64; ++l) {
-                const int grp = (l >> 5) * 2 + grp_of_lane32[l & 31];
-                int best = 0, best_cost = 1 << 30;
-                for (int rot = 0; rot < mv; ++rot) {
-                    int cost = 0;
-                    for (int i = 0; i < mv; ++i) cost += load[grp][i][(pstart[l] / 4 + (i + rot) % mv) & 15];
-                    if (cost < best_cost) { best_cost = cost; best = rot; }
-                }
-                if (pfilt[l] < 0) best = 0;
                 for (int i = 0; i < mv; ++i) {
-                    const int slot = (i + best) % mv;
-                    if (pfilt[l] >= 0) load[grp][i][(pstart[l] / 4 + slot) & 15]++;
+                    const int slot = (i + rot[l]) % mv;
                     pc_ofs[(size_t)l * mv + i] = (pstart[l] + 4 * slot) * 4;
                     for (int e = 0; e < 4; ++e) {
                         const int k = pstart[l] + 4 * slot + e;
@@ -926,23 +992,32 @@ int mfcc_fast_waves() {
 #endif
 }
 
+// LDS carve; returns total bytes.  The chunk's cepstra live in a global scratch, so the footprint does not depend on the
+// chunk length: tables + FAST_WAVES wave regions (4 frame images + the sample stage each).
 size_t mfcc_fast_lds(const ssp_mfcc_cfg& c, FastArgs& f, int ch) {
     const int H = c.delta_order * c.delta_N;
     size_t off = 0;
-    f.off_win = (int32_t)off;    off = al16(off + (mfcc_fast_waves() == 12 ? 512 * 4 : 0));
-    f.off_tw16 = (int32_t)off;   off = al16(off + (mfcc_fast_waves() == 12 ? 240 * 8 : 0));
-    f.off_wpost = (int32_t)off;  off = al16(off + (mfcc_fast_waves() == 12 ? 128 * 8 : 0));
+    f.off_win = f.off_tw16 = f.off_wpost = 0;
     f.off_melw = (int32_t)off;   off = al16(off + (f.melv > 0 ? 0 : (size_t)f.total_steps * 64 * 4));  // piece filterbank: weights in registers
-    f.off_mello = (int32_t)off;  off = al16(off + (size_t)f.n_pass * 16 * 4);
+    f.off_mello = (int32_t)off;  off = al16(off + (f.melv > 0 ? 0 : (size_t)f.n_pass * 16 * 4));
     f.off_melid = f.off_mello;
     f.off_dct = (int32_t)off;    off = al16(off + (size_t)f.n_filt4 * 4 * f.q_pass * 16 * 4);
     f.ceps_rows = ch + 2 * H;
-    f.off_ceps = (int32_t)off;   off = al16(off + (size_t)f.ceps_rows * c.n_ceps * 4);
+    f.off_ceps = 0;
     f.off_stats = (int32_t)off;  off = al16(off + (size_t)2 * c.n_ceps * (1 + c.delta_order) * 4);
     off = (off + 255) & ~size_t(255);
     f.off_wave = (int32_t)off;
     f.wave_bytes = 4 * ZFRAME + (((f.slen + 255) >> 8) << 10);  // transpose images + the LDS-DMA sample stage
     return off + mfcc_fast_waves() * (size_t)f.wave_bytes + 256;  // + pad: lane 0 reads (and discards) one row past the last image
+}
+
+// the delta tail holds the chunk's cepstra AND at least 16 output rows in the wave regions
+int mfcc_fast_max_chunk(const ssp_mfcc_cfg& c, const FastArgs& f) {
+    const int H = c.delta_order * c.delta_N;
+    const int d_out = c.n_ceps * (1 + c.delta_order);
+    const int wave_bytes = 4 * ZFRAME + (((f.slen + 255) >> 8) << 10);
+    const long avail = (long)mfcc_fast_waves() * wave_bytes - 16 - 16L * d_out * 4 - 16;
+    return (int)std::max<long>(0, avail / (c.n_ceps * 4) - 2 * H);
 }
 
 int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int chunk_frames, hipStream_t stream) {
@@ -951,10 +1026,9 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
     size_t lds = mfcc_fast_lds(p->cfg, f, chunk_frames);
     if (const char* e = getenv("SSP_MFCC_LDS_PAD")) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(e));  // diagnostic: caps the workgroups per CU
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
-    if (getenv("SSP_DEBUG"))
-        fprintf(stderr, "[ssp] mfcc fast: chunks=%d chunk_frames=%d lds=%zu B (waves %d x %d B, tables+ceps %d B) mel steps %d/%d/%d/%d melv %d ns %d\n",
-                n_chunks, chunk_frames, lds, mfcc_fast_waves(), f.wave_bytes, f.off_wave, f.mel_blocks[0] * 4, f.mel_blocks[1] * 4,
-                f.mel_steps[0], f.mel_steps[1], f.melv, f.mel_ns);
+    if (chunk_frames > mfcc_fast_max_chunk(p->cfg, f)) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): chunk of %d frames exceeds the delta tail's LDS", chunk_frames);
+    f.ceps_stride = (f.ceps_rows * p->cfg.n_ceps + 3) & ~3;
+    f.n_chunks = n_chunks;
     const int nz = p->cfg.win_len <= 416 ? 13 : 16, pw = p->cfg.spec_power, pr = p->cfg.preemph_mode ? 1 : 0;
     const int nw = mfcc_fast_waves();
     if ((int64_t)p->fast_max_samples * 4 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): utterance too long for 32-bit offsets");
@@ -967,7 +1041,16 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
         auto* kfn = mfcc_fused512_kernel<NZ_, PW_, PR_, NW_, MV_, TU_>;                                                \
         if (lds > 64 * 1024)                                                                                           \
             SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kfn, dim3(n_chunks), dim3(64 * NW_), lds, stream, args, f);                                 \
+        int per_cu = 0;                                                                                                \
+        SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * NW_, lds));                            \
+        const int grid = std::min(n_chunks, std::max(1, per_cu) * p->ctx->num_cu);                                       \
+        SSP_TRY(p->f_scratch.reserve((size_t)grid * f.ceps_stride * sizeof(float)));                                   \
+        SSP_TRY(p->f_counter.reserve(sizeof(int32_t)));                                                                \
+        f.ceps_scratch = p->f_scratch.as<float>();                                                                     \
+        f.work_counter = p->f_counter.as<int32_t>();                                                                   \
+        SSP_HIP(hipMemsetAsync(f.work_counter, 0, sizeof(int32_t), stream));                                           \
+        if (getenv("SSP_DEBUG")) fprintf(stderr, "[ssp] mfcc fast: grid %d (%d per CU), lds %zu\n", grid, per_cu, lds); \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * NW_), lds, stream, args, f);                                     \
         launched = true;                                                                                               \
     }
 #define SSP_FAST_MV(NZ_, PW_, PR_, NW_)                                                                                \

@@ -70,15 +70,14 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     int ch;
     size_t lds = 0;
     if (variant == 2) {
-        // whole utterance per workgroup while 2 workgroups still fit a CU's 160 KiB LDS; longer ones are chunked
+        // persistent workgroups with a fixed LDS footprint; a chunk's cepstra (+ delta halo) and a block of output rows
+        // share the wave regions in the delta tail, which bounds the chunk: whole utterances up to 512 frames, else chunks
         FastArgs tmp = p->fast;
-        ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 4096);
-        // two workgroups per CU (80 KiB each) when a whole utterance fits; else one; else chunk the utterance
-        if (mfcc_fast_lds(c, tmp, ch) > lds_cap / 2)
-            while (ch > 64 && mfcc_fast_lds(c, tmp, ch) > lds_cap && !whole) ch = (ch * 3) / 4;
+        const int cap = mfcc_fast_max_chunk(c, tmp);
+        ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), std::min(512, cap));
         if (whole) {
             ch = (int)std::max<int64_t>(max_T, 1);
-            if (mfcc_fast_lds(c, tmp, ch) > lds_cap)
+            if (ch > cap)
                 SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): cmvn needs a whole utterance per workgroup; %lld frames exceed the LDS",
                          (long long)max_T);
         }
@@ -279,8 +278,14 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     if (v == 0) v = (mfcc_fast_supported(plan->cfg) && plan->fast_ready) ? 2 : 1;
     if (v == 2 && !(mfcc_fast_supported(plan->cfg) && plan->fast_ready))
         SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the fused fast kernel does not cover this cfg");
-    if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_variant != v)
-        SSP_TRY(build_work(plan, sample_seg, frame_seg, v));
+    if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_variant != v) {
+        int brc = build_work(plan, sample_seg, frame_seg, v);
+        if (brc == SSP_ERR_UNSUPPORTED && variant == 0 && v == 2) {  // auto: a batch the fused kernel cannot lay out goes to the generic one
+            v = 1;
+            brc = build_work(plan, sample_seg, frame_seg, v);
+        }
+        SSP_TRY(brc);
+    }
 
     hipStream_t s = plan->ctx->stream;
     Staged sin, sout;
