@@ -138,6 +138,17 @@ int ssp_gmm_destroy(ssp_gmm* gmm);
 int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_seg, float* loglik_out,
                   float* scores_out, int32_t* argmax_out, int where, int precision, float* kernel_ms);
 
+/* ---- GMM training (EM): the O(frames x K x D) part of one iteration of sklearn GaussianMixture(covariance_type='diag').fit as
+ *      the reference trains its speaker models and UBM (GMM_UBM.py:158-170; sklearn mixture/_base.py:_e_step,
+ *      mixture/_gaussian_mixture.py:_estimate_gaussian_parameters) ---- */
+/* Current parameters: HOST double weights[K], means[K x D], covars[K x D].  feats: float[n_frames x D].
+ * Outputs (HOST double): nk_out[K] = sum_t resp[t,k];  sx_out[K x D] = sum_t resp[t,k] x[t,d];  sxx_out[K x D] = sum_t resp[t,k] x[t,d]^2;
+ * loglik_sum_out = sum_t logsumexp_k(log w_k + log N(x_t | k))  (n_frames x sklearn's lower bound of the E step).
+ * The O(K x D) closing arithmetic of the M step and the convergence test stay with the caller (float64). */
+int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double* weights, const double* means, const double* covars,
+                     const float* feats, int64_t n_frames, double* nk_out, double* sx_out, double* sxx_out,
+                     double* loglik_sum_out, int where, float* kernel_ms);
+
 /* ---- d-vector cosine scoring: replaces the scipy cosine double loop + argmin
  *      (d_vector.py:315-319, 346-361) ---- */
 /* X: float[N x d]; C: float[S x d]; dist_out (nullable): float[N x S] = clip(1 - cos, 0, 2);

@@ -3,7 +3,8 @@
 * ``delta``            GMM_UBM.py:53-69
 * ``extract_feature``  GMM_UBM.py:72-118  (sidekit mfcc -> [c, delta c] -> per-utterance scale; one fused kernel)
 * ``score_matrix``     the scoring loops GMM_UBM.py:181-197 as a function that returns what the reference prints
-* ``GMM``              GMM_UBM.py:134 with pre-trained models (EM training is out of scope)
+* ``GMM``              GMM_UBM.py:134-199: trains one GMM per speaker + the UBM (EM on the GPU, gmm_train.GaussianMixture)
+                       or takes pre-trained models, then scores
 """
 from __future__ import annotations
 
@@ -12,6 +13,7 @@ import functools
 import numpy as np
 
 from . import api, frontend
+from .gmm_train import GaussianMixture
 
 
 def delta(feat, N=2):
@@ -67,14 +69,21 @@ def score_matrix(models, ubm, feats):
     return sc[:, 1:] - sc[:, :1], np.asarray(r["argmax"]).astype(np.int64)
 
 
-def GMM(train, x_train, y_train, x_test, y_test, n_components=16, model=None):
-    """GMM_UBM.py:134-199 with pre-trained models: ``model`` = (list_of_speaker_GMMs, UBM) — what the reference
-    un-pickles from Model/GMM_MFCC_model.pkl / UBM_MFCC_model.pkl when model=True.  Prints and returns the
-    train/test accuracies the reference prints."""
+def GMM(train, x_train, y_train, x_test, y_test, n_components=16, model=None, random_state=None):
+    """GMM_UBM.py:134-199.  ``model`` falsy (the reference's default): one ``GaussianMixture(n_components, 'diag')`` per
+    speaker is fitted on ``train[speaker]`` (speakers in ascending label order, like label_encoder.values()) and the UBM
+    on the stacked training data (GMM_UBM.py:154-170), EM on the GPU.  ``model`` = (list_of_speaker_GMMs, UBM): what the
+    reference un-pickles from Model/GMM_MFCC_model.pkl / UBM_MFCC_model.pkl when model=True.
+    Prints and returns the train/test accuracies the reference prints; the trained models are left in ``GMM.last_model``."""
     if not model:
-        raise NotImplementedError("EM training of the GMMs is out of scope of the GPU hot path (SURVEY.md 8(f)); "
-                                  "fit sklearn GaussianMixture(n_components, 'diag') models and pass model=(GMMs, UBM)")
+        speakers = sorted(train.keys())
+        gmms = [GaussianMixture(n_components=n_components, covariance_type='diag', random_state=random_state).fit(train[s])
+                for s in speakers]
+        ubm_train = np.vstack([train[s] for s in speakers])
+        ubm = GaussianMixture(n_components=n_components, covariance_type='diag', random_state=random_state).fit(ubm_train)
+        model = (gmms, ubm)
     gmms, ubm = model
+    GMM.last_model = model
     valid = score_matrix(gmms, ubm, x_train)[1]
     acc_train = (valid == np.array(y_train)).sum() / len(x_train)
     pred = score_matrix(gmms, ubm, x_test)[1]

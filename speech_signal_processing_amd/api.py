@@ -251,6 +251,33 @@ def cmvn_features(ctx: Context, feats, frame_seg: Segments, timing: bool = False
     return (out, ms.value) if timing else out
 
 
+def gmm_em_stats(ctx: "Context", weights, means, covars, feats, timing: bool = False) -> dict:
+    """E step + M-step sums of ONE EM iteration of a diagonal GMM on the GPU (ssp_gmm_em_stats).
+    weights (K,), means (K,D), covars (K,D) float64; feats (n, D) float32 (numpy or device tensor).
+    Returns nk (K,), sx (K,D), sxx (K,D), loglik_sum (float) as float64."""
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    mu = np.ascontiguousarray(means, dtype=np.float64)
+    cv = np.ascontiguousarray(covars, dtype=np.float64)
+    if w.ndim != 1 or mu.ndim != 2 or mu.shape != cv.shape or mu.shape[0] != w.shape[0]:
+        raise ValueError("expected weights (K,), means (K,D), covars (K,D)")
+    K, D = mu.shape
+    keep, ptr, where = _as_f32(feats, "feats")
+    if keep.ndim != 2 or keep.shape[1] != D:
+        raise ValueError("feats must be (frames, %d)" % D)
+    nk = np.empty(K, dtype=np.float64)
+    sx = np.empty((K, D), dtype=np.float64)
+    sxx = np.empty((K, D), dtype=np.float64)
+    ll = C.c_double(0.0)
+    ms = C.c_float(0.0)
+    _lib.check(ctx._lib.ssp_gmm_em_stats(ctx._h, K, D, w.ctypes.data, mu.ctypes.data, cv.ctypes.data, ptr, int(keep.shape[0]),
+                                          nk.ctypes.data, sx.ctypes.data, sxx.ctypes.data, C.byref(ll), where,
+                                          C.byref(ms) if timing else None))
+    res = {"nk": nk, "sx": sx, "sxx": sxx, "loglik_sum": ll.value}
+    if timing:
+        res["kernel_ms"] = ms.value
+    return res
+
+
 class GmmScorer:
     """Packed diagonal GMMs (ssp_gmm).  weights (M,K), means (M,K,D), covars (M,K,D) float64.
     has_ubm: model 0 is the UBM (GMM_UBM.py:169-170); scores/argmax are then taken against it."""

@@ -1,0 +1,246 @@
+// EM sufficient statistics of a diagonal-covariance GMM on gfx950 — the O(frames x K x D) part of one iteration of
+// sklearn's GaussianMixture.fit as the reference runs it (GMM_UBM.py:158-170: GaussianMixture(n_components, 'diag').fit):
+//   E step   log_resp[t,k] = log w_k + log N(x_t; mu_k, diag cov_k) - logsumexp_k(...)      sk:mixture/_base.py:_e_step
+//   M sums   nk[k] = sum_t resp[t,k],  sx[k,d] = sum_t resp[t,k] x[t,d],  sxx[k,d] = sum_t resp[t,k] x[t,d]^2
+//            (the resp.T @ X and resp.T @ X*X products of _estimate_gaussian_parameters / _estimate_gaussian_covariances_diag)
+// The O(K x D) closing arithmetic of the M step (means, covariances + reg_covar, weights, convergence test) stays on the
+// host in float64 exactly as sklearn writes it (speech_signal_processing_amd/gmm_train.py).
+//
+// Three kernels per call:
+//   gmm_em_lse_kernel    workgroup = 64 frames: lp[t,k] for every mixture in 64-mixture chunks staged in LDS, online
+//                        log-sum-exp -> lse[t] and one partial of sum_t lse[t] per workgroup
+//   gmm_em_acc_kernel    grid (G, K/64): the workgroup keeps ONE 64-mixture chunk of parameters in LDS and walks its frame
+//                        tiles; per tile  resp = exp(lp - lse)  (64 x 64, LDS)  then  thread (k, dim group) accumulates
+//                        nk / sx / sxx in registers over all its tiles; one fp32 partial per (workgroup, mixture, column)
+//   gmm_em_reduce_kernel partials -> float64 sums in a fixed order (bit-reproducible)
+// Parameters enter as A = mu P, B = -P/2, c = ln w + 1/2 sum ln P - 1/2 sum mu^2 P - D/2 ln 2pi (float64 on the host, fp32
+// on the device): lp = c + sum_d x_d (A_d + x_d B_d).
+#include <cmath>
+
+#include "common.hpp"
+
+namespace ssp {
+
+constexpr int EM_TF = 64;   // frames per tile
+constexpr int EM_KC = 64;   // mixtures per chunk
+constexpr int EM_DG = 16;   // max dims per accumulation group (4 groups: D <= 64)
+
+struct EmArgs {
+    const float* x;       // [n x D]
+    const float* par;     // [Kp][2D+1]  (A[0..D), B[0..D), c), Kp = K rounded up to a multiple of 64, padded c = -1e30
+    float* lse;           // [n]
+    float* lse_part;      // [ceil(n / 64)]
+    float* part;          // [G][Kp][2D+1]
+    int64_t n;
+    int32_t D, K, Kp, G, n_tiles;
+};
+
+// lp of frame `xs` (LDS row, D floats) under mixture row `w` (LDS, 2D+1 floats; wave-uniform address: broadcast reads)
+__device__ __forceinline__ float em_lp(const float* __restrict__ xs, const float* __restrict__ w, int D) {
+    float acc = w[2 * D];
+    for (int d = 0; d < D; ++d) {
+        const float xv = xs[d];
+        acc = fmaf(xv, fmaf(xv, w[D + d], w[d]), acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void gmm_em_lse_kernel(EmArgs a) {
+    extern __shared__ float sm[];
+    const int D = a.D, W = 2 * D + 1, XS = D | 1;  // odd row stride: the 64 frames of a wave read distinct banks
+    float* xs = sm;                   // [64][XS]
+    float* ws = xs + EM_TF * XS;      // [64][W]
+    float* red = ws + EM_KC * W;      // [4][64] x 2
+    const int tid = threadIdx.x, t = tid & 63, kg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t base = (int64_t)blockIdx.x * EM_TF;
+    const int nt = (int)min<int64_t>(EM_TF, a.n - base);
+    for (int i = tid; i < EM_TF * D; i += 256) {
+        const int r = i / D, c = i - r * D;
+        xs[r * XS + c] = r < nt ? a.x[(base + r) * D + c] : 0.f;
+    }
+    float m = -INFINITY, s = 0.f;
+    for (int kc = 0; kc < a.Kp; kc += EM_KC) {
+        __syncthreads();
+        for (int i = tid; i < EM_KC * W; i += 256) ws[i] = a.par[(size_t)kc * W + i];
+        __syncthreads();
+        for (int kk = 0; kk < 16; ++kk) {
+            const float lp = em_lp(xs + t * XS, ws + (kg * 16 + kk) * W, D);
+            const float mn = fmaxf(m, lp);
+            s = s * __expf(m - mn) + __expf(lp - mn);
+            m = mn;
+        }
+    }
+    red[kg * 64 + t] = m;
+    red[256 + kg * 64 + t] = s;
+    __syncthreads();
+    if (tid < 64) {
+        float mm = red[t], ss = red[256 + t];
+        for (int g = 1; g < 4; ++g) {
+            const float m2 = red[g * 64 + t], s2 = red[256 + g * 64 + t];
+            const float mn = fmaxf(mm, m2);
+            ss = ss * __expf(mm - mn) + s2 * __expf(m2 - mn);
+            mm = mn;
+        }
+        float l = t < nt ? mm + __logf(ss) : 0.f;
+        if (t < nt) a.lse[base + t] = l;
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        if (t == 0) a.lse_part[blockIdx.x] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void gmm_em_acc_kernel(EmArgs a) {
+    extern __shared__ float sm[];
+    const int D = a.D, W = 2 * D + 1, XS = D | 1;
+    float* xs = sm;                   // [64][XS]
+    float* ws = xs + EM_TF * XS;      // [64][W]    this workgroup's chunk of mixtures, loaded once
+    float* rs = ws + EM_KC * W;       // [64 frames][65]  responsibilities of the tile
+    const int tid = threadIdx.x, t = tid & 63, kg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kc = blockIdx.y * EM_KC;
+    for (int i = tid; i < EM_KC * W; i += 256) ws[i] = a.par[(size_t)kc * W + i];
+    // accumulation role: mixture k = tid & 63 of the chunk, dims [dg * dper, dg * dper + dper)
+    const int dper = (D + 3) / 4, d0 = kg * dper;
+    float ax[EM_DG], axx[EM_DG], an = 0.f;
+#pragma unroll
+    for (int i = 0; i < EM_DG; ++i) ax[i] = axx[i] = 0.f;
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.G) {
+        const int64_t base = (int64_t)tile * EM_TF;
+        const int nt = (int)min<int64_t>(EM_TF, a.n - base);
+        __syncthreads();
+        for (int i = tid; i < EM_TF * D; i += 256) {
+            const int r = i / D, c = i - r * D;
+            xs[r * XS + c] = r < nt ? a.x[(base + r) * D + c] : 0.f;
+        }
+        __syncthreads();
+        const float l = t < nt ? a.lse[base + t] : INFINITY;  // frames beyond the end get resp = exp(-inf) = 0
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = kg * 16 + kk;
+            rs[t * 65 + k] = __expf(em_lp(xs + t * XS, ws + k * W, D) - l);
+        }
+        __syncthreads();
+        for (int r = 0; r < EM_TF; ++r) {
+            const float rv = rs[r * 65 + t];  // mixture t of the chunk, frame r
+            if (kg == 0) an += rv;
+            const float* xr = xs + r * XS + d0;  // wave-uniform: broadcast
+#pragma unroll
+            for (int i = 0; i < EM_DG; ++i)
+                if (i < dper && d0 + i < D) {
+                    const float xv = xr[i], rx = rv * xv;
+                    ax[i] += rx;
+                    axx[i] = fmaf(rx, xv, axx[i]);
+                }
+        }
+    }
+    float* out = a.part + ((size_t)blockIdx.x * a.Kp + kc + t) * W;
+#pragma unroll
+    for (int i = 0; i < EM_DG; ++i)
+        if (i < dper && d0 + i < D) {
+            out[d0 + i] = ax[i];
+            out[D + d0 + i] = axx[i];
+        }
+    if (kg == 0) out[2 * D] = an;
+}
+
+// out[j] = sum_g part[g][j] (float64, fixed order);  j over Kp * W columns, then the lse partials
+__global__ void gmm_em_reduce_kernel(const float* part, int G, int64_t cols, const float* lse_part, int64_t n_lse, double* out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < cols) {
+        double s = 0.0;
+        for (int g = 0; g < G; ++g) s += (double)part[(size_t)g * cols + j];
+        out[j] = s;
+    }
+    if (blockIdx.x == 0) {  // sum_t lse[t]: one workgroup, fixed strided order + tree
+        __shared__ double sh[256];
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < n_lse; i += blockDim.x) s += (double)lse_part[i];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[cols] = sh[0];
+    }
+}
+
+}  // namespace ssp
+
+using namespace ssp;
+
+extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double* weights, const double* means,
+                                const double* covars, const float* feats, int64_t n_frames, double* nk_out, double* sx_out,
+                                double* sxx_out, double* loglik_sum_out, int where, float* kernel_ms) {
+    SSP_TRY(use_ctx(ctx));
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (K < 1 || D < 1 || !weights || !means || !covars || !nk_out || !sx_out || !sxx_out || !loglik_sum_out)
+        SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_em_stats: bad shape or null array");
+    if (D > 4 * EM_DG) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_em_stats: D=%d exceeds the supported feature dimension (%d)", D, 4 * EM_DG);
+    if (n_frames < 1 || !feats) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_em_stats: no frames");
+    if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_em_stats: where");
+    const int W = 2 * D + 1, Kp = (K + EM_KC - 1) / EM_KC * EM_KC;
+    std::vector<float> par((size_t)Kp * W, 0.f);
+    const double ln2pi = std::log(2.0 * M_PI);
+    for (int k = 0; k < Kp; ++k) {
+        float* w = par.data() + (size_t)k * W;
+        if (k >= K) {
+            w[2 * D] = -1.0e30f;  // padded mixture: resp = exp(-1e30 - lse) = 0
+            continue;
+        }
+        if (!(weights[k] > 0.0)) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_em_stats: non-positive weight (mix %d)", k);
+        double c = std::log(weights[k]) - 0.5 * D * ln2pi;
+        for (int d = 0; d < D; ++d) {
+            const double cv = covars[(size_t)k * D + d], mu = means[(size_t)k * D + d];
+            if (!(cv > 0.0)) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_em_stats: non-positive covariance (mix %d)", k);
+            const double P = 1.0 / cv;
+            w[d] = (float)(mu * P);
+            w[D + d] = (float)(-0.5 * P);
+            c += 0.5 * std::log(P) - 0.5 * mu * mu * P;
+        }
+        w[2 * D] = (float)c;
+    }
+    hipStream_t s = ctx->stream;
+    const int64_t n_tiles = (n_frames + EM_TF - 1) / EM_TF;
+    if (n_tiles > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_em_stats: too many frames");
+    const int G = (int)std::min<int64_t>(n_tiles, 2 * (int64_t)ctx->num_cu);
+    const int64_t cols = (int64_t)Kp * W;
+    DevBuf d_par, d_lse, d_lsep, d_part, d_out;
+    Staged sx;
+    int rc;
+    const float* d_x = (const float*)sx.in(ctx, feats, (size_t)n_frames * D * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    SSP_TRY(d_par.alloc(par.size() * sizeof(float)));
+    SSP_TRY(d_lse.alloc((size_t)n_frames * sizeof(float)));
+    SSP_TRY(d_lsep.alloc((size_t)n_tiles * sizeof(float)));
+    SSP_TRY(d_part.alloc((size_t)G * cols * sizeof(float)));
+    SSP_TRY(d_out.alloc((size_t)(cols + 1) * sizeof(double)));
+    SSP_HIP(hipMemcpyAsync(d_par.p, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    SSP_HIP(hipMemsetAsync(d_part.p, 0, (size_t)G * cols * sizeof(float), s));
+    EmArgs a{d_x, d_par.as<float>(), d_lse.as<float>(), d_lsep.as<float>(), d_part.as<float>(), n_frames, D, K, Kp, G, (int32_t)n_tiles};
+    const int XS = D | 1;
+    const size_t lds1 = ((size_t)EM_TF * XS + (size_t)EM_KC * W + 512) * sizeof(float);
+    const size_t lds2 = ((size_t)EM_TF * XS + (size_t)EM_KC * W + (size_t)EM_TF * 65) * sizeof(float);
+    if (lds1 > 64 * 1024)
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_lse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    if (lds2 > 64 * 1024)
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_acc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, s));
+    hipLaunchKernelGGL(gmm_em_lse_kernel, dim3((unsigned)n_tiles), dim3(256), lds1, s, a);
+    hipLaunchKernelGGL(gmm_em_acc_kernel, dim3(G, Kp / EM_KC), dim3(256), lds2, s, a);
+    hipLaunchKernelGGL(gmm_em_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, d_part.as<float>(), G, cols,
+                       d_lsep.as<float>(), n_tiles, d_out.as<double>());
+    SSP_HIP(hipGetLastError());
+    SSP_TRY(tm.stop(s, kernel_ms));
+    std::vector<double> host((size_t)cols + 1);
+    SSP_HIP(hipMemcpyAsync(host.data(), d_out.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    SSP_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < K; ++k) {
+        const double* r = host.data() + (size_t)k * W;
+        for (int d = 0; d < D; ++d) {
+            sx_out[(size_t)k * D + d] = r[d];
+            sxx_out[(size_t)k * D + d] = r[D + d];
+        }
+        nk_out[k] = r[2 * D];
+    }
+    *loglik_sum_out = host[(size_t)cols];
+    return SSP_OK;
+}

@@ -302,7 +302,7 @@ def test_gmm_score_matrix_vs_reference_loop(golden, ssp):
     y = list(g["sm_argmax"])
     acc_tr, acc_te = GMM_UBM.GMM(None, feats[:50], y[:50], feats[50:], y[50:], model=(spk, ubm))
     assert acc_tr == 1.0 and acc_te == 1.0
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AttributeError):  # training needs the reference's train dict (GMM_UBM.py:158: train[speaker])
         GMM_UBM.GMM(None, feats, y, feats, y, model=False)
 
 
@@ -395,6 +395,83 @@ def test_gmm_batch_permutation_property(ssp):
     r2 = sc.score(np.vstack([feats[i] for i in perm]), api.Segments.from_lengths(ctx, lens[perm]))
     assert np.array_equal(np.asarray(r1["scores"])[perm], np.asarray(r2["scores"]))
     assert np.array_equal(np.asarray(r1["argmax"])[perm], np.asarray(r2["argmax"]))
+
+
+# ----------------------------------------------------------------------------------------- GMM training (EM)
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_gmm_em_stats_vs_oracle(golden, ssp, tag):
+    """one E step + M-step sums on the GPU vs the float64 oracle, from the golden initial parameters"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    g = golden("gmm_em")
+    X, w0, mu0, cov0 = g[tag + "_X"], g[tag + "_w0"], g[tag + "_mu0"], g[tag + "_cov0"]
+    st = api.gmm_em_stats(api.default_context(), w0, mu0, cov0, X)
+    nk, sx, sxx, ll = O.gmm_em_stats(w0, mu0, cov0, X)
+    assert abs(st["loglik_sum"] - ll) <= 1e-5 * abs(ll)
+    assert np.allclose(st["nk"], nk, rtol=1e-4, atol=1e-4 * nk.max())
+    assert np.allclose(st["sx"], sx, rtol=1e-4, atol=1e-4 * np.abs(sx).max())
+    assert np.allclose(st["sxx"], sxx, rtol=1e-4, atol=1e-4 * np.abs(sxx).max())
+    assert abs(st["nk"].sum() - X.shape[0]) < 1e-3 * X.shape[0] * 1e-2  # responsibilities sum to one per frame
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_gmm_fit_vs_sklearn_golden(golden, ssp, tag):
+    """GaussianMixture.fit (EM on the GPU) vs sklearn's fit from the same start: same iteration count and convergence
+    flag, parameters and lower bound within 1e-4"""
+    pkg, api = ssp
+    from speech_signal_processing_amd.gmm_train import GaussianMixture
+    g = golden("gmm_em")
+    K, D, n, max_iter, tol = g[tag + "_cfg"]
+    gm = GaussianMixture(n_components=int(K), tol=float(tol), max_iter=int(max_iter), weights_init=g[tag + "_w0"],
+                         means_init=g[tag + "_mu0"], precisions_init=1.0 / g[tag + "_cov0"]).fit(g[tag + "_X"])
+    assert gm.n_iter_ == int(g[tag + "_niter"]) and gm.converged_ == bool(g[tag + "_conv"])
+    assert abs(gm.lower_bound_ - float(g[tag + "_lb"])) <= 1e-4 * abs(float(g[tag + "_lb"]))
+    assert np.allclose(gm.weights_, g[tag + "_w"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(gm.means_, g[tag + "_mu"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(gm.covariances_, g[tag + "_cov"], rtol=1e-3, atol=1e-5)
+    # the trained object scores like sklearn's (duck type of the fitted model)
+    from oracle import ref_cpu as O
+    x = g[tag + "_X"][:200]
+    ref = O.gmm_score(g[tag + "_w"], g[tag + "_mu"], g[tag + "_cov"], x)
+    assert abs(gm.score(x) - ref) <= 1e-4 * abs(ref)
+
+
+def test_gmm_train_end_to_end_speaker_id(ssp):
+    """GMM_UBM.GMM(train, ...) with model=None: per-speaker GMMs + UBM trained on the GPU from random starts identify
+    well separated synthetic speakers (the reference's train-then-score path, GMM_UBM.py:134-199)"""
+    pkg, api = ssp
+    from speech_signal_processing_amd import GMM_UBM
+    rng = np.random.default_rng(5)
+    S, D = 6, 13
+    centres = 3.0 * rng.standard_normal((S, 4, D))
+
+    def utt(s, T):
+        c = centres[s][rng.integers(0, 4, T)]
+        return (c + 0.7 * rng.standard_normal((T, D))).astype(np.float32)
+    x_train = [utt(s, 150) for s in range(S) for _ in range(4)]
+    y_train = [s for s in range(S) for _ in range(4)]
+    x_test = [utt(s, 120) for s in range(S) for _ in range(2)]
+    y_test = [s for s in range(S) for _ in range(2)]
+    train = {s: np.vstack([x for x, y in zip(x_train, y_train) if y == s]) for s in range(S)}
+    acc_train, acc = GMM_UBM.GMM(train, x_train, y_train, x_test, y_test, n_components=4, random_state=0)
+    assert acc_train == 1.0 and acc == 1.0
+    gmms, ubm = GMM_UBM.GMM.last_model
+    assert len(gmms) == S and ubm.means_.shape == (4, D) and abs(ubm.weights_.sum() - 1) < 1e-12
+
+
+def test_gmm_em_stats_device_tensor_and_errors(ssp):
+    import torch
+    pkg, api = ssp
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((1000, 20)).astype(np.float32)
+    w, mu, cov = np.full(3, 1 / 3), rng.standard_normal((3, 20)), np.ones((3, 20))
+    a = api.gmm_em_stats(api.default_context(), w, mu, cov, X)
+    b = api.gmm_em_stats(api.default_context(), w, mu, cov, torch.from_numpy(X).cuda())
+    assert np.array_equal(a["nk"], b["nk"]) and a["loglik_sum"] == b["loglik_sum"]  # fixed reduction order: bit-reproducible
+    with pytest.raises(ValueError):
+        api.gmm_em_stats(api.default_context(), w, mu, -cov, X)
+    with pytest.raises(NotImplementedError):
+        api.gmm_em_stats(api.default_context(), w, np.zeros((3, 80)), np.ones((3, 80)), np.zeros((10, 80), np.float32))
 
 
 # ----------------------------------------------------------------------------------------- cosine

@@ -119,3 +119,16 @@ def test_unpinned_presets_shapes():
     assert fb.shape == (24, 257) and int((fb != 0).sum()) == 454
     assert O.librosa_mfcc_flat(np.random.default_rng(2).standard_normal(48000)).shape == (94 * 13,)
     assert O.extract_feature_one(x).shape == (98, 26)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_gmm_em_matches_sklearn_fit(golden, tag):
+    """oracle EM loop vs sklearn GaussianMixture(...).fit from the same initial parameters (tests/golden/make_golden_em.py)."""
+    g = golden("gmm_em")
+    K, D, n, max_iter, tol = g[tag + "_cfg"]
+    w, mu, cov, n_iter, lb, conv = O.gmm_fit(g[tag + "_X"], g[tag + "_w0"], g[tag + "_mu0"], g[tag + "_cov0"],
+                                             max_iter=int(max_iter), tol=float(tol))
+    assert n_iter == int(g[tag + "_niter"]) and conv == bool(g[tag + "_conv"])
+    assert abs(lb - float(g[tag + "_lb"])) < 1e-11
+    for got, ref in ((w, g[tag + "_w"]), (mu, g[tag + "_mu"]), (cov, g[tag + "_cov"])):
+        assert np.abs(got - ref).max() < 1e-11
