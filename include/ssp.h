@@ -149,6 +149,13 @@ int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double* weights, 
                      const float* feats, int64_t n_frames, double* nk_out, double* sx_out, double* sxx_out,
                      double* loglik_sum_out, int where, float* kernel_ms);
 
+/* ---- d-vector network forward: one Dense layer Y = act(X W + b) of the speaker network the reference runs with
+ *      spkModel.predict (d_vector.py:171-189 builds Dense(256) x 4 with ReLU between; predict at d_vector.py:298-299,327,348) ---- */
+/* X: float[N x d_in]; Wt: float[units x d_in] = the Keras kernel (d_in x units) TRANSPOSED; bias: float[units] (nullable);
+ * relu != 0 applies max(0, .); Y: float[N x units].  All four arrays live on the side `where` names. */
+int ssp_dense_forward(ssp_ctx* ctx, const float* X, int64_t N, int32_t d_in, const float* Wt, const float* bias,
+                      int32_t units, int32_t relu, float* Y, int where, float* kernel_ms);
+
 /* ---- d-vector cosine scoring: replaces the scipy cosine double loop + argmin
  *      (d_vector.py:315-319, 346-361) ---- */
 /* X: float[N x d]; C: float[S x d]; dist_out (nullable): float[N x S] = clip(1 - cos, 0, 2);

@@ -373,6 +373,29 @@ def centroids(ctx: Context, X, labels, num: int):
     return out
 
 
+def dense_forward(ctx: Context, X, Wt, bias=None, relu: bool = False, timing: bool = False):
+    """Y = act(X @ Wt.T + bias) — one Keras Dense layer (ssp_dense_forward).  X (N, d_in); Wt (units, d_in) is the Keras
+    kernel transposed; all arrays numpy (host) or all torch CUDA tensors.  Returns Y (N, units) of the same kind."""
+    xk, xp, where = _as_f32(X, "X")
+    wk, wp, wwhere = _as_f32(Wt, "Wt")
+    if wwhere != where:
+        raise ValueError("X and Wt must both be numpy arrays or both be torch CUDA tensors")
+    if xk.ndim != 2 or wk.ndim != 2 or xk.shape[1] != wk.shape[1]:
+        raise ValueError("X (N,d_in) and Wt (units,d_in) must share d_in")
+    N, d_in, units = int(xk.shape[0]), int(xk.shape[1]), int(wk.shape[0])
+    bk, bp = None, None
+    if bias is not None:
+        bk, bp, bwhere = _as_f32(bias, "bias")
+        if bwhere != where or int(np.prod(bk.shape)) != units:
+            raise ValueError("bias must have `units` entries and live where X lives")
+    Y = ctx._empty((N, units), where)
+    yp = Y.data_ptr() if where == _lib.DEVICE else Y.ctypes.data
+    ms = C.c_float(0.0)
+    _lib.check(ctx._lib.ssp_dense_forward(ctx._h, xp, N, d_in, wp, bp, units, 1 if relu else 0, yp, where,
+                                           C.byref(ms) if timing else None))
+    return (Y, ms.value) if timing else Y
+
+
 def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True, minval: bool = True,
                     timing: bool = False) -> dict:
     """dist[i,j] = clip(1 - cos(X[i], C[j]), 0, 2); argmin over j (first index on ties) — d_vector.py:315-319."""

@@ -1,6 +1,7 @@
-"""GPU-backed mirror of the scoring half of the reference's ``d_vector.py`` (nn_model.test / enroll / eval,
-d_vector.py:296-361) and of Data_gen's feature front end (d_vector.py:80-98).  The Keras networks are out of scope:
-embeddings are inputs here (BASELINE.json config 5: "precomputed 256-d embeddings")."""
+"""GPU-backed mirror of the inference half of the reference's ``d_vector.py``: Data_gen's feature front end
+(d_vector.py:80-98), the forward pass of the fully connected speaker network (``DenseNet.predict`` = spkModel.predict of
+the Sequential built at d_vector.py:171-189) and nn_model.test / enroll / eval (d_vector.py:296-361).  Training the
+Keras networks (and the GRU / LSTM variants) is out of scope: weights are inputs."""
 from __future__ import annotations
 
 import functools
@@ -21,6 +22,42 @@ def identify(X, centroids):
     """argmin_j cosine(X[i], centroids[j]) (first index on ties) — d_vector.py:319."""
     r = api.cosine_identify(api.default_context(), X, np.asarray(centroids, dtype=np.float32), dist=False, argmin=True, minval=False)
     return np.asarray(r["argmin"]).astype(np.int64)
+
+
+class DenseNet:
+    """Forward pass of the reference's fully connected d-vector network (d_vector.py:171-189): Dense(256)+ReLU x 3, then
+    Dense(256) — what ``load_model('feature/d_vector/d_vector_nn.h5').predict`` computes (dropout is the identity at
+    inference).  ``layers``: list of (kernel (d_in, units), bias (units,) or None, activation in {'relu', 'linear', None}) in
+    Keras' own layout, e.g. ``[(l.get_weights()[0], l.get_weights()[1], 'relu') ...]``.  Weights go to the GPU once."""
+
+    def __init__(self, layers, device: int = 0):
+        import torch
+        self._ctx = api.default_context(device, torch_stream=True)
+        self.layers = []
+        d_prev = None
+        for W, b, act in layers:
+            W = np.asarray(W, dtype=np.float32)
+            if W.ndim != 2 or (d_prev is not None and W.shape[0] != d_prev):
+                raise ValueError("layer kernels must be (d_in, units) and chain")
+            if act not in ('relu', 'linear', None):
+                raise ValueError("activation must be 'relu' or 'linear'")
+            d_prev = W.shape[1]
+            Wt = torch.from_numpy(np.ascontiguousarray(W.T)).cuda(device)
+            bt = None if b is None else torch.from_numpy(np.asarray(b, dtype=np.float32).reshape(-1)).cuda(device)
+            self.layers.append((Wt, bt, act == 'relu'))
+        self.input_dim = int(self.layers[0][0].shape[1])
+        self.output_dim = int(d_prev)
+
+    def predict(self, X, batch_size=None):
+        """X (N, input_dim) numpy or torch CUDA tensor -> (N, output_dim) of the same kind (numpy in: float32 out)."""
+        import torch
+        is_t = api._is_torch(X)
+        h = X if is_t else torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).cuda(self.layers[0][0].device)
+        if h.ndim != 2 or h.shape[1] != self.input_dim:
+            raise ValueError("X must be (N, %d)" % self.input_dim)
+        for Wt, bt, relu in self.layers:
+            h = api.dense_forward(self._ctx, h, Wt, bt, relu=relu)
+        return h if is_t else h.cpu().numpy()
 
 
 class Data_gen:
@@ -72,9 +109,11 @@ class nn_model:
     def __init__(self):
         self.d_vector = {}  # name -> mean embedding, the dict the reference pickles (d_vector.py:333-344)
 
-    def test(self, X_train, Y_train, X_val, Y_val):
-        """d_vector.py:296-320: per-speaker centroids of X_train (one-hot Y_train), cosine distance of every
-        X_val row to every centroid, accuracy of the arg-min."""
+    def test(self, X_train, Y_train, X_val, Y_val, spk_model=None):
+        """d_vector.py:296-320: (with ``spk_model``: X = spk_model.predict(X), d_vector.py:298-299) per-speaker centroids
+        of X_train (one-hot Y_train), cosine distance of every X_val row to every centroid, accuracy of the arg-min."""
+        if spk_model is not None:
+            X_train, X_val = spk_model.predict(X_train), spk_model.predict(X_val)
         num = Y_train.shape[1]
         lab = np.argmax(Y_train, axis=1)  # decoding the one-hot labels is index bookkeeping, not arithmetic
         avg = np.asarray(api.centroids(api.default_context(), np.asarray(X_train, dtype=np.float32), lab, num))

@@ -548,6 +548,54 @@ def test_dvector_front_end_shapes(ssp):
 
 
 # ----------------------------------------------------------------------------------------- error behaviour
+# ----------------------------------------------------------------------------------------- d-vector network forward
+@pytest.mark.parametrize("N,d_in,units,relu", [(1000, 1274, 256, True), (77, 50, 10, False), (129, 256, 256, True), (1, 3, 1, True)])
+def test_dense_forward_vs_oracle(ssp, N, d_in, units, relu):
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(N + d_in)
+    X = rng.standard_normal((N, d_in)).astype(np.float32)
+    W = (rng.standard_normal((d_in, units)) / np.sqrt(d_in)).astype(np.float32)
+    b = rng.standard_normal(units).astype(np.float32)
+    got = api.dense_forward(api.default_context(), X, np.ascontiguousarray(W.T), b, relu=relu)
+    ref = O.dense_net_forward(X, [(W, b, 'relu' if relu else 'linear')])
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    nob = api.dense_forward(api.default_context(), X, np.ascontiguousarray(W.T), None, relu=False)
+    assert np.abs(nob - X.astype(np.float64) @ W.astype(np.float64)).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_dvector_network_predict_and_test(ssp):
+    """DenseNet.predict = the reference's spkModel.predict (Dense(256)+ReLU x 3, Dense(256)) and nn_model.test on its output"""
+    import torch
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd import d_vector
+    rng = np.random.default_rng(3)
+    dims = [1274, 256, 256, 256, 256]
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i])).astype(np.float32),
+               (0.1 * rng.standard_normal(dims[i + 1])).astype(np.float32), 'relu' if i < 3 else 'linear') for i in range(4)]
+    net = d_vector.DenseNet(layers)
+    S, per = 5, 30
+    proto = rng.standard_normal((S, 1274)).astype(np.float32)
+    lab = np.repeat(np.arange(S), per)
+    X = (proto[lab] + 0.3 * rng.standard_normal((S * per, 1274))).astype(np.float32)
+    emb = net.predict(X)
+    ref = O.dense_net_forward(X, layers)
+    assert emb.shape == (S * per, 256) and emb.dtype == np.float32
+    assert np.abs(emb - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    emb_t = net.predict(torch.from_numpy(X).cuda())
+    assert np.array_equal(emb_t.cpu().numpy(), emb)
+    Y = np.eye(S)[lab]
+    acc = d_vector.nn_model().test(X[::2], Y[::2], X[1::2], Y[1::2], spk_model=net)
+    ref_emb_tr, ref_emb_va = ref[::2], ref[1::2]
+    cent = np.stack([ref_emb_tr[lab[::2] == s].mean(0) for s in range(S)])
+    ref_acc = (O.cosine_matrix(ref_emb_va, cent).argmin(1) == lab[1::2]).mean()
+    assert acc == ref_acc
+    with pytest.raises(ValueError):
+        net.predict(np.zeros((3, 10), np.float32))
+
+
 def test_error_codes(ssp):
     pkg, api = ssp
     ctx = api.default_context()
