@@ -149,6 +149,13 @@ int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double* weights, 
                      const float* feats, int64_t n_frames, double* nk_out, double* sx_out, double* sxx_out,
                      double* loglik_sum_out, int where, float* kernel_ms);
 
+/* ---- DTW template matching: replaces the distance_dtw double loop of MFCC_DTW.py:57-108,187-217
+ *      (dtw.accelerated_dtw(x, y, dist='euclidean'), warp 1) for every (query, template) pair ---- */
+/* xq: float[total query rows x dim] with q_seg row offsets; xt, t_seg likewise for the templates (dim = 1: the reference's
+ * flattened _MFCC sequences).  dist_out: float[n_q x n_t] = D1[r-1][c-1]; normalize != 0 divides by (r + c) (dtw <= 1.3.3). */
+int ssp_dtw_distances(ssp_ctx* ctx, const float* xq, const ssp_segments* q_seg, const float* xt, const ssp_segments* t_seg,
+                      int32_t dim, int32_t normalize, float* dist_out, int where, float* kernel_ms);
+
 /* ---- d-vector network forward: one Dense layer Y = act(X W + b) of the speaker network the reference runs with
  *      spkModel.predict (d_vector.py:171-189 builds Dense(256) x 4 with ReLU between; predict at d_vector.py:298-299,327,348) ---- */
 /* X: float[N x d_in]; Wt: float[units x d_in] = the Keras kernel (d_in x units) TRANSPOSED; bias: float[units] (nullable);

@@ -1,7 +1,8 @@
 """GPU-backed mirror of the MFCC wrappers of the reference's ``MFCC_DTW.py`` (lines 28-54).
 
 ``load_train`` / ``load_test`` of the reference take ``mfcc_extract=`` (MFCC_DTW.py:122,155): pass ``_MFCC`` or
-``MFCC_lib`` from this module there.  DTW matching itself is out of scope."""
+``MFCC_lib`` from this module there.  The matcher (distance_dtw / distance_train / distance_test, MFCC_DTW.py:57-108, and the
+arg-min classification of test(), MFCC_DTW.py:187-217) runs as one all-pairs DTW kernel (api.dtw_distances)."""
 from __future__ import annotations
 
 import functools
@@ -28,3 +29,31 @@ def MFCC_lib(raw_signal, n_mfcc=13):
 def _MFCC(raw_signal):
     """MFCC_DTW.py:33-54 — MFCC(raw_signal, fs=8000, frameSize=512, step=256).flatten()."""
     return MFCC(raw_signal, fs=8000, frameSize=512, step=256).flatten()
+
+
+def distance_dtw(sample_x, sample_y, show=False, dtw_method=1, dist=None, normalize=False):
+    """MFCC_DTW.py:57-76 — d of dtw.accelerated_dtw(sample_x, sample_y, dist='euclidean') (dtw_method=1; fastdtw's
+    approximation, dtw_method=2, is not reproduced).  ``normalize=True`` divides by len(x) + len(y) (dtw <= 1.3.3)."""
+    if dtw_method != 1:
+        raise NotImplementedError("only dtw_method=1 (accelerated_dtw) is implemented")
+    return float(api.dtw_distances(api.default_context(), [sample_x], [sample_y], normalize=normalize)[0, 0])
+
+
+def distance_train(data, normalize=False):
+    """MFCC_DTW.py:79-95 — symmetric matrix of pairwise DTW distances with a zero diagonal."""
+    d = np.asarray(api.dtw_distances(api.default_context(), data, data, normalize=normalize), dtype=np.float64)
+    d = np.triu(d, 1)
+    return d + d.T
+
+
+def distance_test(x_test, x_train, show=False, normalize=False):
+    """MFCC_DTW.py:98-108 — (1, len(x_train)) distances of one test sample to every training sample:
+    distance[0, k] = distance_dtw(x_train[k], x_test)."""
+    return np.asarray(api.dtw_distances(api.default_context(), x_train, [x_test], normalize=normalize), dtype=np.float64).T.copy()
+
+
+def classify(x_test, x_train, y_train, normalize=False):
+    """The matching loop of test() (MFCC_DTW.py:196-203) for a whole test set in ONE launch: distances (n_test, n_train)
+    with distances[i, k] = distance_dtw(x_train[k], x_test[i]) and y_pred[i] = y_train[argmin_k]."""
+    d = np.asarray(api.dtw_distances(api.default_context(), x_train, x_test, normalize=normalize), dtype=np.float64).T
+    return d, [y_train[k] for k in d.argmin(axis=1)]

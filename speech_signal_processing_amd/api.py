@@ -373,6 +373,29 @@ def centroids(ctx: Context, X, labels, num: int):
     return out
 
 
+def dtw_distances(ctx: Context, queries, templates, normalize: bool = False, timing: bool = False):
+    """All-pairs DTW distances (ssp_dtw_distances).  queries / templates: lists of arrays, each (L,) (the reference's
+    flattened MFCCs) or (L, dim).  Returns the (n_q, n_t) float32 matrix (numpy)."""
+    def pack(seqs):
+        arrs = [np.asarray(s, dtype=np.float32) for s in seqs]
+        arrs = [a.reshape(-1, 1) if a.ndim == 1 else a for a in arrs]
+        dims = {a.shape[1] for a in arrs if a.shape[0] > 0}
+        if len(dims) > 1:
+            raise ValueError("all sequences must share the feature dimension")
+        dim = dims.pop() if dims else 1
+        flat = np.concatenate([a.reshape(-1, dim) for a in arrs]) if arrs else np.zeros((0, dim), np.float32)
+        return np.ascontiguousarray(flat), Segments.from_lengths(ctx, [a.shape[0] for a in arrs]), dim
+    q, qs, dq = pack(queries)
+    t, ts, dt = pack(templates)
+    if dq != dt:
+        raise ValueError("queries and templates must share the feature dimension")
+    out = np.empty((qs.n, ts.n), dtype=np.float32)
+    ms = C.c_float(0.0)
+    _lib.check(ctx._lib.ssp_dtw_distances(ctx._h, q.ctypes.data, qs._h, t.ctypes.data, ts._h, dq, 1 if normalize else 0,
+                                           out.ctypes.data, _lib.HOST, C.byref(ms) if timing else None))
+    return (out, ms.value) if timing else out
+
+
 def dense_forward(ctx: Context, X, Wt, bias=None, relu: bool = False, timing: bool = False):
     """Y = act(X @ Wt.T + bias) — one Keras Dense layer (ssp_dense_forward).  X (N, d_in); Wt (units, d_in) is the Keras
     kernel transposed; all arrays numpy (host) or all torch CUDA tensors.  Returns Y (N, units) of the same kind."""

@@ -1,0 +1,171 @@
+// DTW distances of the reference's template matcher on gfx950 (MFCC_DTW.py:57-108, 187-217):
+//   d, C, D1, path = dtw.accelerated_dtw(x, y, dist='euclidean')        (dtw package, warp = 1)
+//   D1[i][j] = ||x_i - y_j||_2 + min(D1[i-1][j-1], D1[i-1][j], D1[i][j-1]),  borders +inf, D0[0][0] = 0;  d = D1[r-1][c-1]
+// for every (test sequence, template) pair of distance_test / test().  The reference feeds FLATTENED MFCCs (_MFCC,
+// MFCC_DTW.py:54: 1-D sequences of frames x 13 scalars, reshaped to (-1, 1) by the dtw package), so dim = 1 with sequences of
+// ~1.2k elements is the common case; dim > 1 (2-D MFCC rows) is supported by the same kernel.
+//
+// One wave per pair, skewed wavefront: lane l owns W consecutive template columns and walks the rows one step behind
+// lane l - 1 (row i = step - l), so the left and diagonal neighbours of its first column are the values lane l - 1
+// produced one and two steps ago (one cross-lane shift per step); its own previous row stays in W registers.  Templates
+// longer than 64 W columns are swept in super-blocks of 64 W columns with the boundary column parked in a per-wave scratch.
+#include <cmath>
+
+#include "common.hpp"
+
+namespace ssp {
+
+struct DtwArgs {
+    const float* xq;          // [rows_q x dim]
+    const float* xt;          // [rows_t x dim]
+    const int64_t* q_off;     // [n_q + 1]
+    const int64_t* t_off;     // [n_t + 1]
+    float* out;               // [n_q x n_t]
+    float* bnd;               // [n_waves x max_r] boundary columns
+    int64_t n_pairs;
+    int32_t n_q, n_t, dim, normalize, max_r;
+};
+
+template <int W>
+__global__ __launch_bounds__(256) void dtw_kernel(DtwArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave_id >= a.n_pairs) return;
+    const int q = (int)(wave_id / a.n_t), p = (int)(wave_id - (int64_t)q * a.n_t);
+    const int r = (int)(a.q_off[q + 1] - a.q_off[q]), c = (int)(a.t_off[p + 1] - a.t_off[p]);
+    const int dim = a.dim;
+    const float* __restrict__ x = a.xq + a.q_off[q] * dim;
+    const float* __restrict__ y = a.xt + a.t_off[p] * dim;
+    float* __restrict__ bnd = a.bnd + wave_id * a.max_r;
+    float result = INFINITY;  // empty sequences: the package would fail; report +inf
+    if (r > 0 && c > 0) {
+        for (int cb0 = 0; cb0 < c; cb0 += 64 * W) {
+            const int cb = min(64 * W, c - cb0);        // columns of this super-block
+            const int lanes = (cb + W - 1) / W;         // lanes that own at least one column
+            const int j0 = cb0 + lane * W;              // this lane's first column
+            const bool more = cb0 + 64 * W < c;         // another super-block follows: park the last column
+            float yreg[W];
+            if (dim == 1) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) yreg[k] = j0 + k < c ? y[j0 + k] : 0.f;
+            }
+            float prev[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) prev[k] = INFINITY;  // row -1
+            float last = INFINITY;    // this lane's value in its LAST column at its previous step (row i - 1)
+            float diagl = INFINITY;   // D[i-1][j0-1]
+            for (int s = 0; s < r + lanes - 1; ++s) {
+                const int i = s - lane;
+                // lane l - 1's last-column value for row i (it finished that row in the previous step)
+                float left = __shfl_up(last, 1);
+                const bool act = i >= 0 && i < r && lane < lanes;
+                if (lane == 0) {
+                    if (cb0 == 0) {
+                        left = INFINITY;
+                        diagl = i == 0 ? 0.f : INFINITY;
+                    } else if (act) {
+                        // agent-scope loads: the values were stored by another lane of this wave in the previous super-block
+                        left = __hip_atomic_load(&bnd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        diagl = i > 0 ? __hip_atomic_load(&bnd[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
+                    }
+                }
+                if (act) {
+                    float cur[W];
+                    float xi = 0.f;
+                    if (dim == 1) xi = x[i];
+#pragma unroll
+                    for (int k = 0; k < W; ++k) {
+                        const int j = j0 + k;
+                        float cost;
+                        if (dim == 1) {
+                            cost = fabsf(xi - yreg[k]);
+                        } else {
+                            float ss = 0.f;
+                            if (j < c)
+                                for (int e = 0; e < dim; ++e) {
+                                    const float df = x[(size_t)i * dim + e] - y[(size_t)j * dim + e];
+                                    ss = fmaf(df, df, ss);
+                                }
+                            cost = sqrtf(ss);
+                        }
+                        const float up = prev[k];
+                        const float dg = k == 0 ? diagl : prev[k - 1];
+                        const float lf = k == 0 ? left : cur[k - 1];
+                        cur[k] = j < c ? cost + fminf(dg, fminf(up, lf)) : INFINITY;
+                    }
+                    diagl = left;  // D[i][j0-1] is the diagonal neighbour of row i + 1
+                    const int kl = min(W, cb - lane * W) - 1;  // this lane's last valid column
+                    float lv = cur[0];
+#pragma unroll
+                    for (int k = 1; k < W; ++k) lv = k == kl ? cur[k] : lv;
+#pragma unroll
+                    for (int k = 0; k < W; ++k) prev[k] = cur[k];
+                    last = lv;
+                    if (lane == lanes - 1) {
+                        if (more) __hip_atomic_store(&bnd[i], lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (i == r - 1 && !more) result = lv;
+                    }
+                }
+            }
+            if (more) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the parked column is read back by lane 0 of this wave
+        }
+    }
+    // the value sits in the lane that owned the last column
+    float v = result;
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    if (lane == 0) a.out[wave_id] = (a.normalize && r + c > 0) ? v / (float)(r + c) : v;
+}
+
+}  // namespace ssp
+
+using namespace ssp;
+
+extern "C" int ssp_dtw_distances(ssp_ctx* ctx, const float* xq, const ssp_segments* q_seg, const float* xt,
+                                 const ssp_segments* t_seg, int32_t dim, int32_t normalize, float* dist_out, int where,
+                                 float* kernel_ms) {
+    SSP_TRY(use_ctx(ctx));
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (!q_seg || !t_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_dtw_distances: null segments");
+    if (dim < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_dtw_distances: dim");
+    if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_dtw_distances: where");
+    const int64_t n_q = q_seg->n, n_t = t_seg->n, n_pairs = n_q * n_t;
+    if (n_pairs == 0) return SSP_OK;
+    if (!dist_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_dtw_distances: null output");
+    const int64_t rows_q = q_seg->host.back(), rows_t = t_seg->host.back();
+    if ((rows_q > 0 && !xq) || (rows_t > 0 && !xt)) SSP_FAIL(SSP_ERR_INVALID, "ssp_dtw_distances: null data");
+    const int64_t max_r = std::max<int64_t>(q_seg->max_len(), 1), max_c = t_seg->max_len();
+    if (max_r > INT32_MAX / 2 || max_c > INT32_MAX / 2 || n_q > INT32_MAX || n_t > INT32_MAX)
+        SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_dtw_distances: sequence too long");
+    hipStream_t s = ctx->stream;
+    Staged sq, st, so;
+    int rc;
+    const float* dq = (const float*)sq.in(ctx, xq, (size_t)rows_q * dim * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    const float* dt = (const float*)st.in(ctx, xt, (size_t)rows_t * dim * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    float* dout = (float*)so.out(dist_out, (size_t)n_pairs * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    // column block per lane: the smallest of {4, 8, 16, 32} that covers the longest template in one super-block, else 32
+    const int need = (int)((max_c + 63) / 64);
+    const int W = need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 32;
+    const bool multi = max_c > 64 * (int64_t)W;
+    DevBuf bnd;
+    SSP_TRY(bnd.alloc(multi ? (size_t)n_pairs * max_r * sizeof(float) : 16));
+    DtwArgs a{dq, dt, q_seg->dev.as<int64_t>(), t_seg->dev.as<int64_t>(), dout, bnd.as<float>(), n_pairs,
+              (int32_t)n_q, (int32_t)n_t, dim, normalize ? 1 : 0, (int32_t)max_r};
+    const int64_t grid = (n_pairs + 3) / 4;
+    if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_dtw_distances: too many pairs");
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, s));
+    switch (W) {
+        case 4: hipLaunchKernelGGL(dtw_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL(dtw_kernel<8>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL(dtw_kernel<16>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(dtw_kernel<32>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+    }
+    SSP_HIP(hipGetLastError());
+    SSP_TRY(tm.stop(s, kernel_ms));
+    SSP_TRY(so.back(ctx, dist_out, (size_t)n_pairs * sizeof(float), where));
+    SSP_HIP(hipStreamSynchronize(s));  // `bnd` and the staging buffers are freed at return
+    return SSP_OK;
+}

@@ -548,6 +548,44 @@ def test_dvector_front_end_shapes(ssp):
 
 
 # ----------------------------------------------------------------------------------------- error behaviour
+# ----------------------------------------------------------------------------------------- DTW template matching
+def test_dtw_vs_oracle_flattened_mfcc(ssp):
+    """the reference's own configuration: flattened in-repo MFCCs (1-D sequences of frames x 13 scalars), all pairs"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd import MFCC_DTW
+    seqs = [O.MFCC(synth_audio(u, n, 8000), 8000, 512, 256).flatten() for u, n in ((0, 6000), (1, 9000), (2, 7000), (3, 24000))]
+    train, test = seqs[:3], seqs[2:]
+    got = api.dtw_distances(api.default_context(), train, test)
+    ref, _ = O.dtw_distance_matrix(train, test)   # ref[k_train, k_test]
+    assert got.shape == ref.shape == (3, 2)
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-4)
+    assert got[2, 0] == 0.0  # identical sequences
+    d, pred = MFCC_DTW.classify(test, train, ["a", "b", "c"])
+    assert pred[0] == "c" and np.allclose(d, ref.T, rtol=1e-4, atol=1e-4)
+    assert abs(MFCC_DTW.distance_dtw(train[0], test[1]) - O.dtw_distance(train[0], test[1])) <= 1e-4 * O.dtw_distance(train[0], test[1])
+    assert abs(MFCC_DTW.distance_dtw(train[0], test[1], normalize=True) - O.dtw_distance(train[0], test[1], True)) <= 1e-6
+    dm = MFCC_DTW.distance_train(train)
+    assert np.allclose(dm, dm.T) and np.all(np.diag(dm) == 0) and abs(dm[0, 1] - O.dtw_distance(train[0], train[1])) <= 1e-4 * dm[0, 1]
+    assert MFCC_DTW.distance_test(test[0], train).shape == (1, 3)
+
+
+@pytest.mark.parametrize("dim,lens_q,lens_t", [(1, [1, 2, 65, 300], [1, 64, 257]), (13, [5, 94], [94, 30, 1]), (1, [70], [2100, 4500]), (3, [40], [2050])])
+def test_dtw_shapes_vs_oracle(ssp, dim, lens_q, lens_t):
+    """ragged lengths: single elements, lane-block boundaries, multi-dimensional rows, templates longer than one super-block"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(dim + len(lens_q))
+    mk = lambda L: (rng.standard_normal((L, dim)) if dim > 1 else rng.standard_normal(L)).astype(np.float32)
+    Q, T = [mk(L) for L in lens_q], [mk(L) for L in lens_t]
+    got = api.dtw_distances(api.default_context(), Q, T)
+    ref = np.array([[O.dtw_distance(q, t) for t in T] for q in Q])
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-5), np.abs(got - ref).max()
+    gotn = api.dtw_distances(api.default_context(), Q, T, normalize=True)
+    refn = np.array([[O.dtw_distance(q, t, True) for t in T] for q in Q])
+    assert np.allclose(gotn, refn, rtol=1e-4, atol=1e-6)
+
+
 # ----------------------------------------------------------------------------------------- d-vector network forward
 @pytest.mark.parametrize("N,d_in,units,relu", [(1000, 1274, 256, True), (77, 50, 10, False), (129, 256, 256, True), (1, 3, 1, True)])
 def test_dense_forward_vs_oracle(ssp, N, d_in, units, relu):

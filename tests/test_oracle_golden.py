@@ -132,3 +132,26 @@ def test_gmm_em_matches_sklearn_fit(golden, tag):
     assert abs(lb - float(g[tag + "_lb"])) < 1e-11
     for got, ref in ((w, g[tag + "_w"]), (mu, g[tag + "_mu"]), (cov, g[tag + "_cov"])):
         assert np.abs(got - ref).max() < 1e-11
+
+
+def test_dtw_oracle_matches_plain_recurrence():
+    """the vectorised anti-diagonal oracle against the package's plain double loop (accelerated_dtw, warp = 1) and its
+    elementary properties: d(x, x) = 0, symmetry, a known hand value"""
+    rng = np.random.default_rng(0)
+    for dim in (1, 4):
+        x = rng.standard_normal((17, dim))
+        y = rng.standard_normal((23, dim))
+        r, c = len(x), len(y)
+        D0 = np.zeros((r + 1, c + 1))
+        D0[0, 1:] = np.inf
+        D0[1:, 0] = np.inf
+        D1 = D0[1:, 1:]
+        D0[1:, 1:] = np.sqrt(((x[:, None] - y[None]) ** 2).sum(-1))
+        for i in range(r):
+            for j in range(c):
+                D1[i, j] += min(D0[i, j], D0[i + 1, j], D0[i, j + 1])
+        assert abs(O.dtw_distance(x, y) - D1[-1, -1]) < 1e-12
+        assert abs(O.dtw_distance(x, y, True) - D1[-1, -1] / (r + c)) < 1e-12
+        assert O.dtw_distance(x, x) == 0.0
+        assert abs(O.dtw_distance(x, y) - O.dtw_distance(y, x)) < 1e-12
+    assert O.dtw_distance([0.0, 1.0, 2.0], [0.0, 2.0]) == 1.0
