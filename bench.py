@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused fast kernel")
-    ap.add_argument("--stages", default="mfcc,gmm,cosine")
+    ap.add_argument("--stages", default="mfcc,gmm,cosine,em,dnn,dtw")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
     args = ap.parse_args()
@@ -296,6 +296,54 @@ def main():
                          "frac": flop / (c_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "cosine_kernel",
                          "kernel_ms": c_ms, "algorithmic_flop_per_launch": flop},
         }
+
+    # ------------------------------------------------------------------ widened stages; reported, not part of `value`
+    if "em" in stages:
+        K, D = 64, plan.d_out
+        rng = np.random.default_rng(9)
+        n_em = min(n_frames, 3000000)
+        sub = feats[:n_em]
+        mean, std = sub.mean(0).double().cpu().numpy(), sub.std(0).double().cpu().numpy()
+        w0 = rng.dirichlet(5 * np.ones(K))
+        mu0 = mean + std * rng.standard_normal((K, D))
+        cov0 = (std ** 2) * rng.uniform(0.5, 2.0, (K, D))
+        api.gmm_em_stats(ctx, w0, mu0, cov0, sub)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = api.gmm_em_stats(ctx, w0, mu0, cov0, sub, timing=True)
+        dt = time.perf_counter() - t0
+        result["gmm_em"] = {"metric": "GMM EM iteration (E step + M sums), frames/s (K=%d, D=%d)" % (K, D), "value": n_em / dt,
+                            "unit": "frames/s", "kernel_ms": r["kernel_ms"], "frames": n_em,
+                            "tflops": 12.0 * D * K * n_em / r["kernel_ms"] / 1e9, "dtype": "f32"}
+    if "dnn" in stages:
+        Nd = 200000
+        gen = torch.Generator(device=device)
+        gen.manual_seed(5 + rank)
+        dims = [1274, 256, 256, 256, 256]
+        Xd = torch.randn((Nd, dims[0]), generator=gen, device=device)
+        Wd = [torch.randn((dims[i + 1], dims[i]), generator=gen, device=device) / dims[i] ** 0.5 for i in range(4)]
+        bd = [torch.zeros(dims[i + 1], device=device) for i in range(4)]
+        tot = 0.0
+        for rep in range(2):
+            h, tot = Xd, 0.0
+            for i in range(4):
+                h, ms = api.dense_forward(ctx, h, Wd[i], bd[i], relu=i < 3, timing=True)
+                tot += ms
+        flop = 2.0 * Nd * sum(dims[i] * dims[i + 1] for i in range(4))
+        result["dvector_dnn"] = {"metric": "d-vector network forward 1274->256x4, embeddings/s", "value": Nd / tot * 1e3,
+                                 "unit": "embeddings/s", "kernel_ms": tot, "dtype": "f32",
+                                 "roofline": {"bound": "mfma", "achieved": flop / tot / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                              "frac": flop / tot / 1e9 / MFMA_F32_PEAK_TF, "traffic": None}}
+        del Xd, h
+    if "dtw" in stages:
+        rng = np.random.default_rng(13)
+        nq, nt, L = 128, 64, 1222
+        Q = [rng.standard_normal(L).astype(np.float32) for _ in range(nq)]
+        T = [rng.standard_normal(L).astype(np.float32) for _ in range(nt)]
+        api.dtw_distances(ctx, Q[:4], T[:4])
+        _, ms = api.dtw_distances(ctx, Q, T, timing=True)
+        result["dtw"] = {"metric": "DTW matcher, pairs/s (1222-element flattened MFCC sequences)", "value": nq * nt / ms * 1e3,
+                         "unit": "pairs/s", "kernel_ms": ms, "cell_updates_per_s": nq * nt * L * L / ms * 1e3, "dtype": "f32"}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
