@@ -118,7 +118,8 @@ def main():
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused fast kernel")
-    ap.add_argument("--stages", default="mfcc,gmm,cosine,em,dnn,dtw")
+    ap.add_argument("--stages", default="mfcc,gmm,gmm4,cosine,em,dnn,dtw")
+    ap.add_argument("--gmm4-utts", type=int, default=2000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
     args = ap.parse_args()
@@ -265,6 +266,44 @@ def main():
         r = r1
         del scorer, r, r0, r1
 
+    # ------------------------------------------------------------------ configs[3] shape: 512-mix UBM + 1251 speaker models, a measured sample
+    if "gmm4" in stages:
+        K, S, D = 512, 1251, plan.d_out
+        u4 = min(args.gmm4_utts, n_utt)
+        f4 = int(fseg.offsets[u4])
+        rng = np.random.default_rng(17)
+        sub = feats[:: max(1, n_frames // 200000)]
+        mean, std = sub.mean(0).double().cpu().numpy(), sub.std(0).double().cpu().numpy()
+        wts = rng.dirichlet(5 * np.ones(K))
+        mu = mean + std * rng.standard_normal((K, D))
+        cov = (std ** 2) * rng.uniform(0.5, 2.0, (K, D))
+        mus = np.empty((S + 1, K, D))
+        mus[0] = mu
+        for i in range(S):
+            mus[i + 1] = mu + 0.3 * std * rng.standard_normal((K, D))
+        scorer4 = api.GmmScorer(ctx, np.broadcast_to(wts, (S + 1, K)), mus, np.broadcast_to(cov, (S + 1, K, D)), has_ubm=True)
+        del mus
+        seg4 = api.Segments.from_lengths(ctx, np.diff(fseg.offsets[:u4 + 1]))
+        out4 = {}
+        for prec, tag in ((0, "f32"), (1, "bf16x3")):
+            scorer4.score(feats[:f4], seg4, precision=prec)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r4 = scorer4.score(feats[:f4], seg4, precision=prec, timing=True)
+            gathered = all_gather_rows(torch.stack([r4["argmax"].to(torch.float32), r4["scores"][:, 0]], dim=1))
+            torch.cuda.synchronize()
+            barrier()
+            dt4 = max_over_ranks(time.perf_counter() - t0, device)
+            flop4 = 4.0 * D * K * f4 * (S + 1)
+            out4[tag] = {"value": f4 * (S + 1) * world / dt4, "unit": "frame-scores/s", "kernel_ms": r4["kernel_ms"],
+                         "tflops": flop4 / (r4["kernel_ms"] * 1e-3) / 1e12, "gathered_rows": int(gathered.shape[0])}
+        result["gmm_cfg3_shape"] = {
+            "metric": "GMM frame-scores/s at the configs[3] shape (K=512, 1251 speakers + UBM, D=%d), sample of %d utterances per GPU" % (D, u4),
+            "frames_per_gpu": f4, "full_config_utterances_per_gpu": 150000,
+            "extrapolated_full_config_s_per_gpu": {t: 150000.0 / u4 * out4[t]["kernel_ms"] * 1e-3 for t in out4}, **out4}
+        del scorer4, r4
+
     # ------------------------------------------------------------------ cosine stage (configs[4])
     if "cosine" in stages:
         N, S, d = 1000000, 1251, 256
@@ -348,6 +387,13 @@ def main():
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_mfcc(20000, n_samp, fs)
+        try:  # best-effort CPU figure: the same oracle in 16 worker processes (a child process: no fork from this GPU process)
+            import subprocess
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_parallel_baseline.py"), "16", "8"],
+                                 capture_output=True, text=True, timeout=120)
+            result["cpu_baseline_parallel"] = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:  # pragma: no cover
+            result["cpu_baseline_parallel"] = {"error": repr(e)}
         if "gmm" in result:
             result["gmm"]["cpu_baseline"] = cpu_baseline_gmm(plan.d_out, 64, 51)
         if "cosine" in result:
