@@ -256,12 +256,13 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
     const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)stage);
     const bool dma16 = ((xlo & 15) == 0) && ((hop & 3) == 0);  // wave-uniform
     const int n_piece = (f.slen + 255) >> 8;  // 1 KiB pieces (<= 5: slen <= 3 * 256 + 512 floats)
+    const bool last_half = (f.slen & 255) != 0 && (f.slen & 255) <= 128;
     auto prefetch = [&](int q) {
         const int sq4 = (ta + 4 * q) * hop * 4;  // byte offset of the quad's first sample inside the utterance
         if (dma16) {
 #pragma unroll
             for (int c = 0; c < 5; ++c)
-                if (c < n_piece)
+                if (c < n_piece && (c + 1 < n_piece || !last_half || lane < 32))  // a trailing half piece: lanes 0..31 only
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(stage_lds + c * 1024), 16, sq4 + c * 1024 + lane * 16, 0, 0, 0);
         } else {  // ragged batches whose utterances do not start on 16-byte boundaries: 4-byte DMA pieces
             for (int c = 0; c < 4 * n_piece; ++c)
@@ -520,6 +521,57 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
     __syncthreads();
     continue;
 #endif
+    if (TUNED && !a.cmvn && a.delta_order > 0) {
+        // ---- direct tail (no CMVN): thread -> (4 consecutive frames, cepstral index); 12 cepstra straight from the scratch
+        //      (L2 resident, written by this workgroup before the barrier), 4 x (c, delta, delta-delta) straight to the output
+        //      with 4-byte buffer stores (the workgroup fills contiguous 4 x d_out blocks; L2 merges the lines).  No LDS
+        //      image, no further barrier: the next chunk's claim barrier separates these reads from the next cepstrum stores.
+        const int Dd = a.d_out;
+        const float invd = a.delta_inv_denom;
+        const uint64_t oaddr = reinterpret_cast<uint64_t>(a.out + (size_t)f0 * Dd);
+        // (uint32_t temporaries: readfirstlane returns int, and a low word with bit 31 set would sign-extend into the high word)
+        const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t)oaddr), ohi = __builtin_amdgcn_readfirstlane((uint32_t)(oaddr >> 32));
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<float*>(((uint64_t)ohi << 32) | olo), 0, __builtin_amdgcn_readfirstlane(T * Dd * 4), 0x00020000);
+        auto put = [&](int idx, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, idx * 4, 0, 0); };
+        auto cepg = [&](int u, int qq) -> float { return scr[(u - ta) * 13 + qq]; };
+        auto dlg = [&](int u, int qq) -> float {
+            return ((cepg(min(u + 1, T - 1), qq) - cepg(max(u - 1, 0), qq)) + 2.f * (cepg(min(u + 2, T - 1), qq) - cepg(max(u - 2, 0), qq))) * invd;
+        };
+        const int ngrp = (n + 3) >> 2;
+        for (int idx = tid; idx < ngrp * 13; idx += NT) {
+            const int rg = idx / 13, qq = idx - rg * 13;
+            const int u0 = t0 + 4 * rg;  // first frame of the group, utterance coordinates
+            if (4 * rg + 3 < n && u0 >= 4 && u0 + 7 <= T - 1) {
+                const float* cp = scr + (u0 - ta) * 13 + qq;
+                float v[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) v[k] = cp[(k - 4) * 13];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float c1 = ((v[5 + i] - v[3 + i]) + 2.f * (v[6 + i] - v[2 + i])) * invd;
+                    const float c2 = f.ddw[0] * (v[i] + v[8 + i]) + f.ddw[1] * (v[1 + i] + v[7 + i]) + f.ddw[2] * (v[2 + i] + v[6 + i]) +
+                                     f.ddw[3] * (v[3 + i] + v[5 + i]) + f.ddw[4] * v[4 + i];
+                    const int oi = (u0 + i) * Dd + qq;
+                    put(oi, v[4 + i]);
+                    put(oi + 13, c1);
+                    if (a.delta_order >= 2) put(oi + 26, c2);
+                }
+            } else {
+                for (int i = 0; i < 4; ++i)
+                    if (4 * rg + i < n) {  // utterance / chunk edges: the nested edge-padded form
+                        const int u = u0 + i, oi = u * Dd + qq;
+                        put(oi, cepg(u, qq));
+                        put(oi + 13, dlg(u, qq));
+                        if (a.delta_order >= 2)
+                            put(oi + 26, ((dlg(min(u + 1, T - 1), qq) - dlg(max(u - 1, 0), qq)) +
+                                          2.f * (dlg(min(u + 2, T - 1), qq) - dlg(max(u - 2, 0), qq))) * invd);
+                    }
+            }
+        }
+        STAMP(9)
+        continue;
+    }
     // ---- the chunk's cepstra come back from the scratch into the (now idle) wave regions: coalesced 16-byte copies
     float* s_ceps = reinterpret_cast<float*>(smem + f.off_wave);
     const int ceps_floats = ((tb - ta) * nc + 3) & ~3;

@@ -145,6 +145,40 @@ def test_mfcc_edge_cases(ssp, variant):
                 assert_feat_close(got[u], ref, what=f"edge utt {u}")
 
 
+def test_mfcc_device_pointers_with_high_low_word(ssp):
+    """device input / output placed at addresses whose low 32-bit word has bit 31 set (buffer descriptors are assembled from
+    32-bit halves: a sign-extended low word once corrupted the base)"""
+    import torch
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    ctx = api.Context.for_torch(0)
+    tables = pkg.preset_sidekit(delta_order=2)
+    plan = api.MfccPlan(ctx, tables)
+    sigs = [synth_audio(u, 16000, 16000) for u in range(6)]
+    flat = np.concatenate(sigs)
+    seg = api.Segments.from_lengths(ctx, [len(s) for s in sigs])
+    fseg = plan.frame_segments(seg)
+    big = torch.empty((1 << 31) // 4 + (1 << 26), dtype=torch.float32, device="cuda")  # > 2 GiB: some offset has bit 31 set
+    base = big.data_ptr()
+    need_in, need_out = flat.size, fseg.total * plan.d_out
+    def view_with_bit31(n, after=0):
+        off = after
+        while not ((base + 4 * off) & 0x80000000) or (base + 4 * off) % 16:
+            off += 4
+            if 4 * off + 4 * n >= big.numel() * 4:
+                pytest.skip("no offset with bit 31 set inside the buffer")
+        return big[off:off + n], off + n
+    x, nxt = view_with_bit31(need_in)
+    out, _ = view_with_bit31(need_out, nxt + 1024)
+    assert (x.data_ptr() & 0x80000000) and (out.data_ptr() & 0x80000000)
+    x.copy_(torch.from_numpy(flat))
+    plan.run(x, seg, fseg, out=out.view(fseg.total, plan.d_out), variant=2)
+    torch.cuda.synchronize()
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=2)
+    ref = np.vstack([O.mfcc_pipeline(sg, cfg, w, fb, dct) for sg in sigs])
+    assert_feat_close(out.view(fseg.total, plan.d_out).cpu().numpy(), ref, what="bit-31 pointers")
+
+
 def test_librosa_preset_vs_oracle(ssp):
     pkg, api = ssp
     from oracle import ref_cpu as O
