@@ -1,26 +1,27 @@
 // mfcc_fused512_kernel — the throughput kernel of the fused MFCC pass for n_fft == 512 (sidekit and in-repo dialects).
 //
 // Work decomposition (CDNA4, 64-wide waves):
-//   workgroup (256 threads = 4 waves)  = one chunk of frames of ONE utterance (normally the whole utterance)
-//   wave                               = 4 frames at a time ("quad"), 16 lanes per frame
+//   workgroup (256 threads = 4 waves)  = PERSISTENT (3 per CU = 3 waves per SIMD, 168 VGPRs): claims chunks of frames of one
+//                                        utterance (normally the whole utterance) from a global counter
+//   wave                               = 4 frames at a time ("quad"), 16 lanes per frame; quads q = wave, wave + 4, ...
 //   lane                               = 16 complex points of the 256-point complex FFT that carries the 512-point real FFT
 //
 // Per quad, per wave (no workgroup barrier inside the loop; every LDS region below is wave-private):
-//   1. lane n2 of a frame loads ITS OWN FFT inputs (x[e-1], x[e], x[e+1]), e = t*hop + 32 n1 + 2 n2, straight from
-//      global memory one quad ahead (bounds-checked buffer loads; 128 contiguous bytes per frame and n1; the overlap
-//      between neighbouring frames is served by L1/L2, HBM sees every sample once)
+//   1. the quad's 3 hop + 32 NZ samples arrive by LDS-DMA one quad ahead (coalesced 16-byte buffer loads straight into the
+//      wave's stage, bounds-checked: anything outside the utterance is the zero padding the dialects need); lanes read
+//      (x[e], x[e+1]) and (x[e-2], x[e-1]), e = g*hop + 32 n1 + 2 n2, from the stage with aligned 8-byte reads
 //   2. pre-emphasis + window in registers: z[n1] = (y[32 n1 + 2 n2], y[32 n1 + 2 n2 + 1]) * w     (n1 = 0..NZ-1, rest zero)
 //   3. radix-16 FFT over n1 in registers, twiddle W_256^(n2 k1)
 //   4. 16x16 transpose through LDS (unpadded 128-B rows, 16-byte chunks XOR-swizzled: conflict-free ds_write_b64 / ds_read_b128)
 //   5. radix-16 FFT over n2 in registers -> Z[k1 + 16 k2]
-//   6. split step of the real FFT: lane k1 owns the bin pairs k = k1 + 16 k2 <-> 256 - k (k2 < 8); the partners sit in the
-//      upper half of lane 16 - k1's registers, so only that half is exchanged through LDS; power / magnitude go to a
-//      per-frame P row in natural bin order
-//   7. banded filterbank: lane = filter (slots sorted by band length), log
-//   8. DCT rows: lane = cepstral index; cepstra go to the workgroup's LDS buffer
-// After the loop one barrier, then delta / delta-delta (recomputed on the fly from the cepstra in LDS), optional
-// per-utterance CMVN and ONE coalesced write of the (frames x d_out) block.  HBM sees every sample once and every
-// output feature once.
+//   6. split step of the real FFT: lane k1 owns the bin pairs k = k1 + 16 k2 <-> 256 - k (k2 < 8); the partners come from
+//      lane 16 - k1 by two DPP row permutes; power / magnitude go to a per-frame P row in natural bin order
+//   7. filterbank + log: register-resident pieces (MELV > 0: lane = up to 4 MELV taps of one filter, masked DPP scan over the
+//      pieces of a filter) or the banded sweep from LDS tables (MELV = 0)
+//   8. DCT rows: lane = cepstral index; the quad's cepstra go to the workgroup's slot of a global scratch (L2 resident)
+// After the loop one barrier, then delta / delta-delta: without CMVN straight from the scratch to the output (4 frames per
+// thread, buffer stores); with CMVN through an LDS copy of the cepstra, two-pass statistics and a coalesced block write.
+// HBM sees every sample once and every output feature once (+ the scratch round trip at the L2's fabric side).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -151,7 +152,6 @@ template <int NZ, int POWER, int PRE, int FAST_WAVES, int MELV, bool TUNED>
 __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_kernel(MfccArgs a, FastArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 64 * FAST_WAVES;
-    constexpr bool TABREG = FAST_WAVES != 12;  // 3 waves/SIMD (12-wave workgroup) has no registers to spare: tables in LDS
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-level control flow stays on the SALU
     const int g = lane >> 4, j = lane & 15;
@@ -169,26 +169,15 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
     // ---- shared tables -> LDS
     // this lane's window taps stay in registers for the whole kernel: w[32 n1 + 2 j], w[32 n1 + 2 j + 1]
     v2f wreg[NZ];
-    float* s_win = reinterpret_cast<float*>(smem + f.off_win);
-    v2f* s_tw16 = reinterpret_cast<v2f*>(smem + f.off_tw16);
-    v2f* s_wpost = reinterpret_cast<v2f*>(smem + f.off_wpost);
-    if (TABREG) {
 #pragma unroll
-        for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
-    } else {
-        for (int i = tid; i < 512; i += NT) s_win[i] = a.window[i];
-        for (int i = tid; i < 240; i += NT) s_tw16[i] = *reinterpret_cast<const v2f*>(&f.tw16[16 + i]);
-        for (int i = tid; i < 128; i += NT) s_wpost[i] = *reinterpret_cast<const v2f*>(&f.wpost[i]);
-    }
+    for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
     // this lane's twiddles stay in registers: W_256^(k1 j) for the step between the two radix-16 passes and
     // W_512^(8j+1+i) for the split step (LDS is the busiest unit of this kernel; registers are not)
     v2f twr[15], wpr[8];
-    if (TABREG) {
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
+    for (int k1 = 1; k1 < 16; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);  // W_512^(j + 16 i)
-    }
+    for (int i = 0; i < 8; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);  // W_512^(j + 16 i)
     // piece filterbank: this lane's taps, read offsets, scan masks and (first lane of a run) filter id live in registers
     constexpr int MV = MELV > 0 ? MELV : 1;
     v4f mw[MV];
@@ -313,7 +302,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                     const float xm1 = pm[n1 < NZ ? n1 : 0].y, x0 = y.x, x1 = y.y;
                     y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
                 }
-                z[n1] = y * (TABREG ? wreg[n1 < NZ ? n1 : 0] : *reinterpret_cast<const v2f*>(s_win + 32 * n1 + 2 * j));
+                z[n1] = y * wreg[n1 < NZ ? n1 : 0];
             } else {
                 z[n1] = v2f{0.f, 0.f};
             }
@@ -324,11 +313,11 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
         fft16(z);
 #endif
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], TABREG ? twr[k1 - 1] : s_tw16[(k1 - 1) * 16 + j]);
+        for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], twr[k1 - 1]);
         STAMP(1)  // FFT1 + twiddle
         // ---- 4. transpose through LDS
         char* zf = zbuf + g * ZFRAME;
-#if (!defined(SSP_ABL) || SSP_ABL < 3) && !defined(SSP_NO_T2)
+#ifndef SSP_NO_T2
         {
             // lane j (= n2) stores z[k1] into row k1, 8-byte slot j of the row: 16-byte chunk (j >> 1) ^ m, m = (k1 >> 1) & 7
             int wb0 = ((j >> 1) << 4) | ((j & 1) << 3);
@@ -354,7 +343,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
         fft16(z);
 #endif
         STAMP(3)  // FFT2
-#if (defined(SSP_ABL) && SSP_ABL >= 2) || defined(SSP_NO_SPLIT)
+#ifdef SSP_NO_SPLIT
         { float* P = reinterpret_cast<float*>(zf);
 #pragma unroll
           for (int k2 = 0; k2 < 16; ++k2) P[j + 16 * k2] = z[k2].x * z[k2].x + z[k2].y * z[k2].y; }
@@ -383,7 +372,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
                 const v2f zk = z[k2];
-                const v2f w = TABREG ? wpr[k2] : s_wpost[k2 * 16 + j];                  // W_512^(j + 16 k2)
+                const v2f w = wpr[k2];                                                 // W_512^(j + 16 k2)
                 const v2f e = __builtin_elementwise_fma(zm[k2], v2f{1.f, -1.f}, zk);   // 2E = Z[k] + conj Z[256-k]
                 const v2f d = __builtin_elementwise_fma(zm[k2], v2f{-1.f, 1.f}, zk);   // 2D = Z[k] - conj Z[256-k]
                 const v2f o = cmul_negi(d, w);                                         // 2 (-i D) W^k
@@ -413,7 +402,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
         // ---- 7. banded filterbank + log: lane = filter slot, 4 taps per step (16-byte LDS reads), swept in blocks of
         //         4 fully unrolled steps (weights zero padded to whole blocks), so a pass is a
         //         few rounds of independent loads instead of a long chain of dependent round trips.
-#if (!defined(SSP_ABL) || SSP_ABL < 1) && !defined(SSP_NO_MEL)
+#ifndef SSP_NO_MEL
         if (MELV > 0) {
             // piece filterbank: all 64 lanes work on ONE frame at a time.  Lane = up to 4*MELV consecutive taps of one
             // filter (weights in registers, MELV 16-byte reads of the frame's P row); the pieces of a filter sit in
@@ -516,7 +505,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     STAMP(8)  // barrier wait
-#if (defined(SSP_ABL) && SSP_ABL >= 4) || defined(SSP_NO_TAIL)
+#ifdef SSP_NO_TAIL
     if (tid == 0) a.out[(size_t)(f0 + t0) * a.d_out] = scr[0];
     __syncthreads();
     continue;
