@@ -680,3 +680,80 @@ def test_error_codes(ssp):
         api.MfccPlan(ctx, t)
     with pytest.raises(ValueError):
         api.GmmScorer(ctx, np.ones((1, 2)) / 2, np.zeros((1, 2, 3)), np.zeros((1, 2, 3)), has_ubm=False)  # covariance 0
+
+
+# ----------------------------------------------------------------------------------------- BASELINE.json full sizes
+# Parity at full size through replication: the batch is R distinct utterances tiled to the configured count.  Every
+# utterance is processed independently, so (a) all copies must be bit-identical and (b) the R distinct ones must match
+# the oracle — together that pins all outputs of the full-size launch.
+def test_full_size_cfg1_mfcc_replication(ssp):
+    import torch
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    R, n_utt, n = 8, 100000, 48000
+    base = np.stack([synth_audio(u, n, 16000) for u in range(R)])
+    ctx = api.Context.for_torch(0)
+    audio = torch.from_numpy(base).cuda().repeat(n_utt // R, 1)          # (100000, 48000): 19.2 GB, utterance u = base[u % R]
+    plan = api.MfccPlan(ctx, pkg.preset_sidekit(delta_order=2))
+    seg = api.Segments.from_lengths(ctx, np.full(n_utt, n, dtype=np.int64))
+    fseg = plan.frame_segments(seg)
+    out = plan.run(audio.view(-1), seg, fseg)
+    torch.cuda.synchronize()
+    T = fseg.total // n_utt
+    assert T == 298 and out.shape == (n_utt * T, 39)
+    blocks = out.view(n_utt // R, R * T * 39)
+    assert bool((blocks == blocks[0]).all()), "copies of the same utterance differ inside one launch"
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=2)
+    got = out[: R * T].cpu().numpy()
+    for u in range(R):
+        assert_feat_close(got[u * T:(u + 1) * T], O.mfcc_pipeline(base[u], cfg, w, fb, dct), what="full-size utt %d" % u)
+    out2 = plan.run(audio.view(-1), seg, fseg)
+    assert bool((out2 == out).all()), "two launches on the same input differ"
+
+
+def test_full_size_cfg2_gmm_replication(ssp):
+    import torch
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    R, n_utt, T, D, K, S = 10, 100000, 298, 39, 64, 50
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal((R, T, D)).astype(np.float32)
+    wts = rng.dirichlet(5 * np.ones(K))
+    mu = rng.standard_normal((K, D))
+    cov = rng.uniform(0.5, 2.0, (K, D))
+    mus = np.stack([mu] + [mu + 0.3 * rng.standard_normal((K, D)) for _ in range(S)])
+    ctx = api.Context.for_torch(0)
+    feats = torch.from_numpy(base.reshape(R * T, D)).cuda().repeat(n_utt // R, 1)   # 2.98e7 x 39
+    fseg = api.Segments.from_lengths(ctx, np.full(n_utt, T, dtype=np.int64))
+    scorer = api.GmmScorer(ctx, np.stack([wts] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
+    for precision in (0, 1):
+        r = scorer.score(feats, fseg, precision=precision)
+        torch.cuda.synchronize()
+        sc, am = r["scores"], r["argmax"]
+        assert sc.shape == (n_utt, S + 1)
+        assert bool((sc.view(n_utt // R, R * (S + 1)) == sc.view(n_utt // R, R * (S + 1))[0]).all())
+        assert bool((am.view(n_utt // R, R) == am.view(n_utt // R, R)[0]).all())
+        ref = np.array([[O.gmm_score(wts, m, cov, base[u]) for m in mus] for u in range(R)])
+        got = sc[:R].cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+        assert (am[:R].cpu().numpy() == (ref[:, 1:] - ref[:, :1]).argmax(1)).all()
+
+
+def test_full_size_cfg4_cosine_replication(ssp):
+    import torch
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    R, N, S, d = 1000, 1000000, 1251, 256
+    rng = np.random.default_rng(22)
+    Cn = rng.standard_normal((S, d)).astype(np.float32)
+    lab = rng.integers(0, S, R)
+    base = (Cn[lab] + 0.7 * rng.standard_normal((R, d))).astype(np.float32)
+    ctx = api.Context.for_torch(0)
+    X = torch.from_numpy(base).cuda().repeat(N // R, 1)
+    r = api.cosine_identify(ctx, X, torch.from_numpy(Cn).cuda())
+    torch.cuda.synchronize()
+    am, mn = r["argmin"], r["min"]
+    assert bool((am.view(N // R, R) == am.view(N // R, R)[0]).all()) and bool((mn.view(N // R, R) == mn.view(N // R, R)[0]).all())
+    refd = O.cosine_matrix(base, Cn)
+    assert (am[:R].cpu().numpy() == refd.argmin(1)).all()
+    assert np.abs(mn[:R].cpu().numpy() - refd.min(1)).max() < 5e-6
