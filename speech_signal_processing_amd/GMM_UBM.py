@@ -9,6 +9,8 @@
 from __future__ import annotations
 
 import functools
+import os
+import pickle as pkl
 
 import numpy as np
 
@@ -69,19 +71,45 @@ def score_matrix(models, ubm, feats):
     return sc[:, 1:] - sc[:, :1], np.asarray(r["argmax"]).astype(np.int64)
 
 
-def GMM(train, x_train, y_train, x_test, y_test, n_components=16, model=None, random_state=None):
+def save_models(gmms, ubm, model_dir="Model"):
+    """The two pickles the reference writes after training (GMM_UBM.py:173-179): Model/GMM_MFCC_model.pkl (list of the
+    per-speaker models) and Model/UBM_MFCC_model.pkl."""
+    if not os.path.exists(model_dir):
+        os.mkdir(model_dir)
+    with open(os.path.join(model_dir, "GMM_MFCC_model.pkl"), "wb") as f:
+        pkl.dump(gmms, f)
+    with open(os.path.join(model_dir, "UBM_MFCC_model.pkl"), "wb") as f:
+        pkl.dump(ubm, f)
+
+
+def load_models(model_dir="Model"):
+    """GMM_UBM.py:141-146: the pickled speaker models and UBM (sklearn GaussianMixture objects written by the reference,
+    or gmm_train.GaussianMixture objects written by save_models)."""
+    with open(os.path.join(model_dir, "GMM_MFCC_model.pkl"), "rb") as f:
+        gmms = pkl.load(f)
+    with open(os.path.join(model_dir, "UBM_MFCC_model.pkl"), "rb") as f:
+        ubm = pkl.load(f)
+    return gmms, ubm
+
+
+def GMM(train, x_train, y_train, x_test, y_test, n_components=16, model=None, random_state=None, model_dir=None):
     """GMM_UBM.py:134-199.  ``model`` falsy (the reference's default): one ``GaussianMixture(n_components, 'diag')`` per
     speaker is fitted on ``train[speaker]`` (speakers in ascending label order, like label_encoder.values()) and the UBM
-    on the stacked training data (GMM_UBM.py:154-170), EM on the GPU.  ``model`` = (list_of_speaker_GMMs, UBM): what the
-    reference un-pickles from Model/GMM_MFCC_model.pkl / UBM_MFCC_model.pkl when model=True.
-    Prints and returns the train/test accuracies the reference prints; the trained models are left in ``GMM.last_model``."""
-    if not model:
+    on the stacked training data (GMM_UBM.py:154-170), EM on the GPU; with ``model_dir`` (the reference always uses
+    "Model") the two pickles of GMM_UBM.py:173-179 are written.  ``model=True``: load those pickles from ``model_dir``
+    (default "Model", GMM_UBM.py:141-146).  ``model`` = (list_of_speaker_GMMs, UBM): use them as given.
+    Prints and returns the train/test accuracies the reference prints; the models are left in ``GMM.last_model``."""
+    if model is True:
+        model = load_models(model_dir or "Model")
+    elif not model:
         speakers = sorted(train.keys())
         gmms = [GaussianMixture(n_components=n_components, covariance_type='diag', random_state=random_state).fit(train[s])
                 for s in speakers]
         ubm_train = np.vstack([train[s] for s in speakers])
         ubm = GaussianMixture(n_components=n_components, covariance_type='diag', random_state=random_state).fit(ubm_train)
         model = (gmms, ubm)
+        if model_dir:
+            save_models(gmms, ubm, model_dir)
     gmms, ubm = model
     GMM.last_model = model
     valid = score_matrix(gmms, ubm, x_train)[1]

@@ -5,6 +5,8 @@ Keras networks (and the GRU / LSTM variants) is out of scope: weights are inputs
 from __future__ import annotations
 
 import functools
+import os
+import pickle as pkl
 
 import numpy as np
 
@@ -104,10 +106,29 @@ class Data_gen:
 
 
 class nn_model:
-    """Scoring half of d_vector.nn_model.  ``X_*`` are embeddings (outputs of the speaker network)."""
+    """Inference half of d_vector.nn_model.  ``X_*`` are embeddings, or network inputs when ``spk_model`` (a DenseNet, the
+    stand-in for load_model('feature/d_vector/d_vector_{}.h5')) is given.  ``store``: path of the enrolment dictionary pickle
+    (the reference always uses 'feature/d_vector/d_vector.pkl', d_vector.py:333-344,350-351); None keeps it in memory."""
 
-    def __init__(self):
+    def __init__(self, store=None):
+        self.store = store
         self.d_vector = {}  # name -> mean embedding, the dict the reference pickles (d_vector.py:333-344)
+
+    def _load(self):
+        if self.store is not None:
+            try:
+                with open(self.store, 'rb') as f:
+                    self.d_vector = pkl.load(f)
+            except Exception:  # d_vector.py:336-337: a missing / unreadable file starts an empty dictionary
+                self.d_vector = {}
+
+    def _save(self):
+        if self.store is not None:
+            d = os.path.dirname(self.store)
+            if d and not os.path.exists(d):
+                os.makedirs(d)
+            with open(self.store, 'wb') as f:
+                pkl.dump(self.d_vector, f)
 
     def test(self, X_train, Y_train, X_val, Y_val, spk_model=None):
         """d_vector.py:296-320: (with ``spk_model``: X = spk_model.predict(X), d_vector.py:298-299) per-speaker centroids
@@ -120,15 +141,22 @@ class nn_model:
         pred = identify(np.asarray(X_val, dtype=np.float32), avg)
         return (np.argmax(Y_val, axis=1) == pred).sum() / X_val.shape[0]
 
-    def enroll(self, X_train, name):
+    def enroll(self, X_train, name, spk_model=None):
         """d_vector.py:322-344: store the mean embedding under ``name`` (overwrites, like the reference)."""
+        if spk_model is not None:
+            X_train = spk_model.predict(X_train)
+        self._load()
         if name in self.d_vector:
             print("sample already exists")
         X = np.asarray(X_train, dtype=np.float32)
         self.d_vector[name] = np.asarray(api.centroids(api.default_context(), X, np.zeros(len(X), np.int32), 1))[0]
+        self._save()
 
-    def eval(self, target):
+    def eval(self, target, spk_model=None):
         """d_vector.py:346-361: linear scan in dict order; the minimum is kept only while < 1; returns the name or None."""
+        if spk_model is not None:
+            target = spk_model.predict(np.asarray(target, dtype=np.float32).reshape(1, -1))
+        self._load()
         if not self.d_vector:
             return None
         names = list(self.d_vector.keys())

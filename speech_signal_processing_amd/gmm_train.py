@@ -33,6 +33,11 @@ class GaussianMixture:
         self.random_state = random_state
         self._ctx = ctx
 
+    def __getstate__(self):  # picklable like the sklearn object it stands in for (GMM_UBM.py:173-179): no device handles
+        st = dict(self.__dict__)
+        st["_ctx"] = None
+        return st
+
     # ---- sklearn's M step (mixture/_gaussian_mixture.py:_estimate_gaussian_parameters, _m_step), float64
     def _m_step(self, st, n):
         nk = st["nk"] + 10 * np.finfo(np.float64).eps

@@ -668,6 +668,32 @@ def test_dvector_network_predict_and_test(ssp):
         net.predict(np.zeros((3, 10), np.float32))
 
 
+def test_enrolment_store_and_model_dir(ssp, tmp_path):
+    """file formats of the reference: the enrolment dictionary pickle (d_vector.py:333-344) and Model/*.pkl (GMM_UBM.py:173-179)"""
+    import pickle
+    pkg, api = ssp
+    from speech_signal_processing_amd import d_vector, GMM_UBM
+    rng = np.random.default_rng(8)
+    store = str(tmp_path / "feature" / "d_vector" / "d_vector.pkl")
+    a, b = rng.standard_normal((5, 64)).astype(np.float32) + 3, rng.standard_normal((5, 64)).astype(np.float32) - 3
+    d_vector.nn_model(store).enroll(a, "alice")
+    d_vector.nn_model(store).enroll(b, "bob")            # a fresh object reloads the dictionary, like every call of the reference
+    with open(store, "rb") as f:
+        dv = pickle.load(f)
+    assert list(dv.keys()) == ["alice", "bob"] and np.allclose(dv["alice"], a.mean(0), atol=1e-5)
+    assert d_vector.nn_model(store).eval(a[0]) == "alice" and d_vector.nn_model(store).eval(-a[0] - b[0] * 0) in ("bob", None)
+    S, D = 3, 8
+    cent = 4.0 * rng.standard_normal((S, D))
+    mk = lambda s_, T: (cent[s_] + rng.standard_normal((T, D))).astype(np.float32)
+    x_tr, y_tr = [mk(s_, 200) for s_ in range(S)], list(range(S))
+    x_te, y_te = [mk(s_, 100) for s_ in range(S)], list(range(S))
+    train = {s_: x_tr[s_] for s_ in range(S)}
+    md = str(tmp_path / "Model")
+    acc1 = GMM_UBM.GMM(train, x_tr, y_tr, x_te, y_te, n_components=2, random_state=1, model_dir=md)
+    acc2 = GMM_UBM.GMM(None, x_tr, y_tr, x_te, y_te, model=True, model_dir=md)   # GMM_UBM.py:141-146
+    assert acc1 == acc2 == (1.0, 1.0)
+
+
 def test_error_codes(ssp):
     pkg, api = ssp
     ctx = api.default_context()

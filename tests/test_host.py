@@ -100,3 +100,24 @@ def test_frame_count_and_dim_helpers_need_no_gpu():
     assert lib.ssp_mfcc_out_dim(ctypes.byref(cs), ctypes.byref(d)) == 0 and d.value == 39
     assert lib.ssp_mfcc_num_frames(None, 10, ctypes.byref(n)) == _lib.SSP_ERR_INVALID
     assert b"bad argument" in lib.ssp_last_error()
+
+
+def test_model_pickles_round_trip(tmp_path):
+    """the reference's persistence formats (GMM_UBM.py:173-179 model pickles) need no GPU: a fitted-looking
+    gmm_train.GaussianMixture survives pickle and save_models / load_models write the reference's two file names"""
+    import pickle
+    from speech_signal_processing_amd import GMM_UBM
+    from speech_signal_processing_amd.gmm_train import GaussianMixture
+    rng = np.random.default_rng(0)
+    def fake(K=3, D=5):
+        g = GaussianMixture(n_components=K)
+        g.weights_, g.means_, g.covariances_ = np.full(K, 1 / K), rng.standard_normal((K, D)), rng.uniform(1, 2, (K, D))
+        g.precisions_cholesky_ = 1 / np.sqrt(g.covariances_)
+        return g
+    g2 = pickle.loads(pickle.dumps(fake()))
+    assert g2.means_.shape == (3, 5) and g2._ctx is None
+    gm, ubm = [fake(), fake()], fake()
+    GMM_UBM.save_models(gm, ubm, str(tmp_path / "Model"))
+    assert sorted(p.name for p in (tmp_path / "Model").iterdir()) == ["GMM_MFCC_model.pkl", "UBM_MFCC_model.pkl"]
+    gm2, ubm2 = GMM_UBM.load_models(str(tmp_path / "Model"))
+    assert len(gm2) == 2 and np.array_equal(ubm2.means_, ubm.means_)
