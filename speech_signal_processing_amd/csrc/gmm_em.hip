@@ -6,7 +6,7 @@
 // The O(K x D) closing arithmetic of the M step (means, covariances + reg_covar, weights, convergence test) stays on the
 // host in float64 exactly as sklearn writes it (speech_signal_processing_amd/gmm_train.py).
 //
-// Three kernels per call:
+// Kernels per call (D > 47; the MFMA path for D <= 47 is described at gmm_em_acc_mfma_kernel):
 //   gmm_em_lse_kernel    workgroup = 64 frames: lp[t,k] for every mixture in 64-mixture chunks staged in LDS, online
 //                        log-sum-exp -> lse[t] and one partial of sum_t lse[t] per workgroup
 //   gmm_em_acc_kernel    grid (G, K/64): the workgroup keeps ONE 64-mixture chunk of parameters in LDS and walks its frame
@@ -140,6 +140,109 @@ __global__ __launch_bounds__(256) void gmm_em_acc_kernel(EmArgs a) {
     if (kg == 0) out[2 * D] = an;
 }
 
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// sum of lse over 64-frame tiles (one partial per tile, like gmm_em_lse_kernel writes)
+__global__ __launch_bounds__(64) void gmm_em_lsesum_kernel(const float* __restrict__ lse, int64_t n, float* __restrict__ part) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    float v = i < n ? lse[i] : 0.f;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (threadIdx.x == 0) part[blockIdx.x] = v;
+}
+
+// MFMA form of gmm_em_acc_kernel (D <= 47: at most 3 column tiles of [x, x^2, 1]).  Grid (G, K/64), 4 waves; per 64-frame tile
+//   GEMM1  lp[64 mix x 64 frames] = W[64 x (2D+1)] . aug^T        wave (r, c) owns one 32 x 32 tile; mixtures = MFMA rows, frames =
+//                                                                  columns, so a lane's 16 accumulators belong to ONE frame
+//   resp   = exp(lp - lse[frame])  -> LDS tile rs[frame][mix]
+//   GEMM2  S[64 mix x (2D+1)] += resp[64 mix x 64 frames] . aug    split over the waves by frames (wave w: frames 16w..16w+15 of
+//                                                                  the tile); accumulators stay in registers over all tiles
+// Each wave leaves its own partial [64 mix][2D+1]; gmm_em_reduce_kernel adds the 4 G partials in float64.
+template <int NCT>
+__global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
+    extern __shared__ float sm[];
+    const int D = a.D, W = 2 * D + 1, XS = D | 1, KS = (W + 1) / 2;  // KS k-steps of 2 over [x, x^2, 1] (+ a zero pad column)
+    float* xs = sm;                    // [64 frames][XS]
+    float* wsT = xs + EM_TF * XS;      // [2 KS][64 mix]   parameter chunk, k-major: the A operand of GEMM1
+    float* rs = wsT + 2 * KS * EM_KC;  // [64 frames][65]  responsibilities: the A operand of GEMM2
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 31, h = lane >> 5;
+    const int kc = blockIdx.y * EM_KC;
+    for (int i = tid; i < 2 * KS * EM_KC; i += 256) {
+        const int k = i / EM_KC, m = i - k * EM_KC;
+        wsT[i] = k < W ? a.par[(size_t)(kc + m) * W + k] : 0.f;
+    }
+    const int r1 = wave >> 1, c1 = wave & 1;  // GEMM1 tile of this wave
+    f32x16 acc2[2][NCT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[r][c][i] = 0.f;
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.G) {
+        const int64_t base = (int64_t)tile * EM_TF;
+        const int nt = (int)min<int64_t>(EM_TF, a.n - base);
+        __syncthreads();  // the previous tile's GEMM2 is done with xs / rs
+        for (int i = tid; i < EM_TF * D; i += 256) {
+            const int r = i / D, c = i - r * D;
+            xs[r * XS + c] = r < nt ? a.x[(base + r) * D + c] : 0.f;
+        }
+        __syncthreads();
+        // ---- GEMM1: A[row = mix 32 r1 + fl][k = 2 s + h], B[k = 2 s + h][col = frame 32 c1 + fl] = aug[frame][k]
+        f32x16 acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+        const float* xrow = xs + (32 * c1 + fl) * XS;
+        for (int s2 = 0; s2 < KS; ++s2) {
+            const int k = 2 * s2 + h;
+            const float av = wsT[k * EM_KC + 32 * r1 + fl];
+            float bv;
+            if (k < D) bv = xrow[k];
+            else if (k < 2 * D) { const float t = xrow[k - D]; bv = t * t; }
+            else bv = k == 2 * D ? 1.f : 0.f;
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc1, 0, 0, 0);
+        }
+        // ---- responsibilities of this lane's frame; accumulator i = mixture 32 r1 + (i & 3) + 8 (i >> 2) + 4 h
+        const int fr = 32 * c1 + fl;
+        const float l = fr < nt ? a.lse[base + fr] : INFINITY;  // frames beyond the end: resp = exp(-inf) = 0
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rs[fr * 65 + 32 * r1 + (i & 3) + 8 * (i >> 2) + 4 * h] = __expf(acc1[i] - l);
+        __syncthreads();
+        // ---- GEMM2 over this wave's 16 frames: A[row = mix 32 r + fl][k = frame], B[k = frame][col = 32 c + fl] = aug[frame][col]
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int f2 = 16 * wave + 2 * s2 + h;
+            float av[2], bv[NCT];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) av[r] = rs[f2 * 65 + 32 * r + fl];
+            const float* xr = xs + f2 * XS;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int col = 32 * c + fl;
+                float t = 0.f;
+                if (col < D) t = xr[col];
+                else if (col < 2 * D) { t = xr[col - D]; t = t * t; }
+                else if (col == 2 * D) t = 1.f;
+                bv[c] = t;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc2[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bv[c], acc2[r][c], 0, 0, 0);
+        }
+    }
+    float* out = a.part + ((size_t)(blockIdx.x * 4 + wave) * a.Kp + kc) * W;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const int col = 32 * c + fl;
+            if (col < W)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) out[(size_t)(32 * r + (i & 3) + 8 * (i >> 2) + 4 * h) * W + col] = acc2[r][c][i];
+        }
+}
+
 // out[j] = sum_g part[g][j] (float64, fixed order);  j over Kp * W columns, then the lse partials
 __global__ void gmm_em_reduce_kernel(const float* part, int G, int64_t cols, const float* lse_part, int64_t n_lse, double* out) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,6 +305,9 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
     if (n_tiles > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_em_stats: too many frames");
     const int G = (int)std::min<int64_t>(n_tiles, 2 * (int64_t)ctx->num_cu);
     const int64_t cols = (int64_t)Kp * W;
+    const int nct = (W + 31) / 32;
+    const bool mfma = nct <= 3 && !getenv("SSP_EM_NO_MFMA");  // D <= 47: both GEMM-shaped products on the matrix cores
+    const int GP = mfma ? 4 * G : G;                           // partials: one per wave on the MFMA path
     DevBuf d_par, d_lse, d_lsep, d_part, d_out;
     Staged sx;
     int rc;
@@ -210,29 +316,68 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
     SSP_TRY(d_par.alloc(par.size() * sizeof(float)));
     SSP_TRY(d_lse.alloc((size_t)n_frames * sizeof(float)));
     SSP_TRY(d_lsep.alloc((size_t)n_tiles * sizeof(float)));
-    SSP_TRY(d_part.alloc((size_t)G * cols * sizeof(float)));
+    SSP_TRY(d_part.alloc((size_t)GP * cols * sizeof(float)));
     SSP_TRY(d_out.alloc((size_t)(cols + 1) * sizeof(double)));
     SSP_HIP(hipMemcpyAsync(d_par.p, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice, s));
-    SSP_HIP(hipMemsetAsync(d_part.p, 0, (size_t)G * cols * sizeof(float), s));
+    SSP_HIP(hipMemsetAsync(d_part.p, 0, (size_t)GP * cols * sizeof(float), s));
     EmArgs a{d_x, d_par.as<float>(), d_lse.as<float>(), d_lsep.as<float>(), d_part.as<float>(), n_frames, D, K, Kp, G, (int32_t)n_tiles};
     const int XS = D | 1;
     const size_t lds1 = ((size_t)EM_TF * XS + (size_t)EM_KC * W + 512) * sizeof(float);
     const size_t lds2 = ((size_t)EM_TF * XS + (size_t)EM_KC * W + (size_t)EM_TF * 65) * sizeof(float);
+    const size_t lds3 = ((size_t)EM_TF * XS + (size_t)(W + 1) * EM_KC + (size_t)EM_TF * 65) * sizeof(float);
     if (lds1 > 64 * 1024)
         SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_lse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     if (lds2 > 64 * 1024)
         SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_acc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    // the per-frame log-sum-exp of the MFMA path comes from the scoring kernel (csrc/gmm.hip: fp32 MFMA, score_samples of ONE model)
+    ssp_gmm* scorer = nullptr;
+    ssp_segments* seg = nullptr;
+    if (mfma) {
+        const int64_t off[2] = {0, n_frames};
+        rc = ssp_gmm_pack(ctx, 1, K, D, weights, means, covars, 0, &scorer);
+        if (rc == SSP_OK) rc = segments_make(ctx, off, 1, &seg);
+        if (rc != SSP_OK) {
+            ssp_gmm_destroy(scorer);
+            return rc;
+        }
+    }
     Timer tm;
-    SSP_TRY(tm.start(kernel_ms != nullptr, s));
-    hipLaunchKernelGGL(gmm_em_lse_kernel, dim3((unsigned)n_tiles), dim3(256), lds1, s, a);
-    hipLaunchKernelGGL(gmm_em_acc_kernel, dim3(G, Kp / EM_KC), dim3(256), lds2, s, a);
-    hipLaunchKernelGGL(gmm_em_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, d_part.as<float>(), G, cols,
-                       d_lsep.as<float>(), n_tiles, d_out.as<double>());
-    SSP_HIP(hipGetLastError());
-    SSP_TRY(tm.stop(s, kernel_ms));
+    rc = tm.start(kernel_ms != nullptr, s);
+    if (rc == SSP_OK && mfma) {
+        rc = ssp_gmm_score(scorer, d_x, seg, d_lse.as<float>(), nullptr, nullptr, SSP_DEVICE, 0, nullptr);
+        if (rc == SSP_OK) {
+            hipLaunchKernelGGL(gmm_em_lsesum_kernel, dim3((unsigned)n_tiles), dim3(64), 0, s, d_lse.as<float>(), n_frames, d_lsep.as<float>());
+            switch (nct) {
+                case 1: hipLaunchKernelGGL(gmm_em_acc_mfma_kernel<1>, dim3(G, Kp / EM_KC), dim3(256), lds3, s, a); break;
+                case 2: hipLaunchKernelGGL(gmm_em_acc_mfma_kernel<2>, dim3(G, Kp / EM_KC), dim3(256), lds3, s, a); break;
+                default: hipLaunchKernelGGL(gmm_em_acc_mfma_kernel<3>, dim3(G, Kp / EM_KC), dim3(256), lds3, s, a); break;
+            }
+        }
+    } else if (rc == SSP_OK) {
+        hipLaunchKernelGGL(gmm_em_lse_kernel, dim3((unsigned)n_tiles), dim3(256), lds1, s, a);
+        hipLaunchKernelGGL(gmm_em_acc_kernel, dim3(G, Kp / EM_KC), dim3(256), lds2, s, a);
+    }
+    if (rc == SSP_OK) {
+        hipLaunchKernelGGL(gmm_em_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, d_part.as<float>(), GP, cols,
+                           d_lsep.as<float>(), n_tiles, d_out.as<double>());
+        if (hipGetLastError() != hipSuccess) {
+            set_error("ssp_gmm_em_stats: kernel launch failed");
+            rc = SSP_ERR_HIP;
+        }
+    }
+    if (rc == SSP_OK) rc = tm.stop(s, kernel_ms);
+    if (rc != SSP_OK) {
+        (void)hipStreamSynchronize(s);
+        ssp_gmm_destroy(scorer);
+        ssp_segments_destroy(seg);
+        return rc;
+    }
     std::vector<double> host((size_t)cols + 1);
-    SSP_HIP(hipMemcpyAsync(host.data(), d_out.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    SSP_HIP(hipStreamSynchronize(s));
+    hipError_t he = hipMemcpyAsync(host.data(), d_out.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    ssp_gmm_destroy(scorer);
+    ssp_segments_destroy(seg);
+    if (he != hipSuccess) SSP_FAIL(SSP_ERR_HIP, "ssp_gmm_em_stats: result copy failed: %s", hipGetErrorString(he));
     for (int k = 0; k < K; ++k) {
         const double* r = host.data() + (size_t)k * W;
         for (int d = 0; d < D; ++d) {
