@@ -141,11 +141,11 @@ __device__ __forceinline__ float fast_log(const FastArgs& f, float v) {
 
 // NZ: non-zero 32-sample rows of the window (13 for win <= 416, else 16); POWER: 1 magnitude | 2 power spectrum;
 // PRE: per-frame pre-emphasis on/off; FAST_WAVES: waves per workgroup
-// MELV: 0 = banded filterbank sweep from LDS tables | 2..4 = register-resident piece filterbank with MELV 16-byte reads per lane
-// TUNED: the 13-cepstra / <= 32-filter / delta_N == 2 shape of every dialect of the reference as compile-time constants
+// MELV: 0 = banded filterbank sweep from LDS tables | 2..5 = register-resident piece filterbank with MELV 16-byte reads per lane
+// TUNED (0 | 8 | 12): the 13-cepstra / <= 32- or <= 48-filter / delta_N == 2 shapes of the reference's dialects as compile-time constants
 //        (n_ceps 13, one DCT pass of 8 four-filter steps, <= 2 scan steps, N = 2 regression): no loop or branch overhead in
 //        the filterbank / DCT stages, and a delta tail that emits 4 consecutive frames per thread
-template <int NZ, int POWER, int PRE, int FAST_WAVES, int MELV, bool TUNED>
+template <int NZ, int POWER, int PRE, int FAST_WAVES, int MELV, int TUNED>
 #ifndef SSP_FAST_OCC
 #define SSP_FAST_OCC 3  // waves per SIMD the register budget is cut for (168 VGPRs)
 #endif
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-level control flow stays on the SALU
     const int g = lane >> 4, j = lane & 15;
     const int nc = TUNED ? 13 : a.n_ceps;
-    const int q_pass = TUNED ? 1 : f.q_pass, n_filt4 = TUNED ? 8 : f.n_filt4, mel_ns = TUNED ? 2 : f.mel_ns;
+    const int q_pass = TUNED ? 1 : f.q_pass, n_filt4 = TUNED ? TUNED : f.n_filt4, mel_ns = TUNED ? 2 : f.mel_ns;
 
     float* s_melw = reinterpret_cast<float*>(smem + f.off_melw);
     int* s_melpk = reinterpret_cast<int*>(smem + f.off_mello);  // storage start | (filter id + 1) << 16
@@ -870,7 +870,7 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     }
     // ---- register-resident piece filterbank (kernel template MELV > 0).  A piece = up to PW = 4*MELV consecutive taps of
     //      one filter starting on a 16-byte boundary of the P row; a filter's pieces occupy consecutive lanes of one
-    //      16-lane row (first-fit decreasing over the 4 rows).  The smallest MELV in 2..4 that fits 64 lanes wins;
+    //      16-lane row (first-fit decreasing over the 4 rows).  The smallest MELV in 2..5 that fits 64 lanes wins;
     //      filterbanks that fit none (e.g. 40 folded talkbox filters at 8 kHz) keep the banded sweep (MELV = 0).
     f.melv = 0;
     f.mel_ns = 0;
@@ -878,7 +878,7 @@ int build_fast_tables(ssp_mfcc_plan* p) {
     std::vector<int32_t> pc_ofs, pc_fid(64, -1);
     std::vector<float> pc_mask(64 * 4, 0.f);
     if (!getenv("SSP_MFCC_NO_PIECES")) {
-        for (int mv = 2; mv <= 4 && f.melv == 0; ++mv) {
+        for (int mv = 2; mv <= 5 && f.melv == 0; ++mv) {
             const int PW = 4 * mv;
             std::vector<int> cnt(c.n_filt, 0), ord;
             int maxc = 0;
@@ -1075,8 +1075,8 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
     if ((int64_t)p->fast_max_samples * 4 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): utterance too long for 32-bit offsets");
     bool launched = false;
     const ssp_mfcc_cfg& c = p->cfg;
-    const bool tuned = f.melv > 0 && f.mel_ns <= 2 && c.n_ceps == 13 && f.n_filt4 == 8 && f.q_pass == 1 &&
-                       (c.delta_order == 0 || c.delta_N == 2) && !getenv("SSP_MFCC_NO_TUNED");
+    const int tuned = (f.melv > 0 && f.mel_ns <= 2 && c.n_ceps == 13 && (f.n_filt4 == 8 || f.n_filt4 == 12) && f.q_pass == 1 &&
+                       (c.delta_order == 0 || c.delta_N == 2) && !getenv("SSP_MFCC_NO_TUNED")) ? f.n_filt4 : 0;
 #define SSP_FAST_CASE(NZ_, PW_, PR_, NW_, MV_, TU_)                                                                    \
     if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && nw == NW_ && f.melv == MV_ && tuned == TU_) {             \
         auto* kfn = mfcc_fused512_kernel<NZ_, PW_, PR_, NW_, MV_, TU_>;                                                \
@@ -1095,15 +1095,17 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, int c
         launched = true;                                                                                               \
     }
 #define SSP_FAST_MV(NZ_, PW_, PR_, NW_)                                                                                \
-    SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 0, false) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 2, false) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 3, false) \
-    SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 4, false) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 3, true) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 4, true)
+    SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 0, 0) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 2, 0) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 3, 0)            \
+    SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 4, 0) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 3, 8) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 4, 8)            \
+    SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 3, 12) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 4, 12) SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 5, 0)           \
+    SSP_FAST_CASE(NZ_, PW_, PR_, NW_, 5, 12)
 #ifdef SSP_FAST_WAVES8  // experiment: 8-wave workgroups (one per CU)
 #define SSP_FAST_NW(NZ_, PW_, PR_) SSP_FAST_MV(NZ_, PW_, PR_, 4) SSP_FAST_MV(NZ_, PW_, PR_, 8)
 #else
 #define SSP_FAST_NW(NZ_, PW_, PR_) SSP_FAST_MV(NZ_, PW_, PR_, 4)
 #endif
 #ifdef SSP_FAST_MINIMAL  // diagnostic builds: only the benchmark instance
-    SSP_FAST_CASE(13, 2, 1, 4, 3, true)
+    SSP_FAST_CASE(13, 2, 1, 4, 3, 8)
 #else
     SSP_FAST_NW(13, 2, 1)
     SSP_FAST_NW(13, 2, 0)
