@@ -101,6 +101,9 @@ struct ssp_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int num_cu = 256;
+    // grow-only device scratch shared by the entry points that are called in a loop (one EM iteration per call): a ctx is
+    // not thread-safe and its work is ordered on one stream, so consecutive calls may reuse the same buffers
+    ssp::DevBuf scratch[6];
 };
 
 struct ssp_segments {

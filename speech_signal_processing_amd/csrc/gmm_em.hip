@@ -308,16 +308,18 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
     const int nct = (W + 31) / 32;
     const bool mfma = nct <= 3 && !getenv("SSP_EM_NO_MFMA");  // D <= 47: both GEMM-shaped products on the matrix cores
     const int GP = mfma ? 4 * G : G;                           // partials: one per wave on the MFMA path
-    DevBuf d_par, d_lse, d_lsep, d_part, d_out;
+    // device scratch lives in the ctx (grow-only): an EM loop calls this once per iteration
+    DevBuf &d_par = ctx->scratch[0], &d_lse = ctx->scratch[1], &d_lsep = ctx->scratch[2], &d_part = ctx->scratch[3],
+           &d_out = ctx->scratch[4];
     Staged sx;
     int rc;
     const float* d_x = (const float*)sx.in(ctx, feats, (size_t)n_frames * D * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    SSP_TRY(d_par.alloc(par.size() * sizeof(float)));
-    SSP_TRY(d_lse.alloc((size_t)n_frames * sizeof(float)));
-    SSP_TRY(d_lsep.alloc((size_t)n_tiles * sizeof(float)));
-    SSP_TRY(d_part.alloc((size_t)GP * cols * sizeof(float)));
-    SSP_TRY(d_out.alloc((size_t)(cols + 1) * sizeof(double)));
+    SSP_TRY(d_par.reserve(par.size() * sizeof(float)));
+    SSP_TRY(d_lse.reserve((size_t)n_frames * sizeof(float)));
+    SSP_TRY(d_lsep.reserve((size_t)n_tiles * sizeof(float)));
+    SSP_TRY(d_part.reserve((size_t)GP * cols * sizeof(float)));
+    SSP_TRY(d_out.reserve((size_t)(cols + 1) * sizeof(double)));
     SSP_HIP(hipMemcpyAsync(d_par.p, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice, s));
     SSP_HIP(hipMemsetAsync(d_part.p, 0, (size_t)GP * cols * sizeof(float), s));
     EmArgs a{d_x, d_par.as<float>(), d_lse.as<float>(), d_lsep.as<float>(), d_part.as<float>(), n_frames, D, K, Kp, G, (int32_t)n_tiles};
