@@ -117,6 +117,12 @@ int ssp_cepstrum(ssp_ctx* ctx, const float* X, int64_t n_rows, int32_t n_bins, c
                  const float* dct, int32_t n_ceps, int32_t log_mode, int32_t floor_mode, float eps, float* out, int where,
                  float* kernel_ms);
 
+/* magnitude (power = 1) or power (2) spectrum, scaled, from rows of [re(0..n_bins) | im(0..n_bins)] — the |FFT|/L of
+ * utils/processing.py:137-139 when the transform itself ran as a DFT-matrix product (ssp_dense_forward) for frame sizes
+ * that are not powers of two.  reim: float[n_rows x 2 n_bins]; out: float[n_rows x n_bins]. */
+int ssp_spectrum_abs(ssp_ctx* ctx, const float* reim, int64_t n_rows, int32_t n_bins, float scale, int32_t power, float* out,
+                     int where, float* kernel_ms);
+
 /* ---- stand-alone delta / CMVN on feature matrices (GMM_UBM.delta, preprocessing.scale) - */
 int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim, int32_t N,
               float* out, int where, float* kernel_ms);

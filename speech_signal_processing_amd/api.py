@@ -229,6 +229,17 @@ def cepstrum(ctx: Context, X, fbank, dct, log_mode: int, floor_mode: int, eps: f
     return out
 
 
+def spectrum_abs(ctx: Context, reim, n_bins: int, scale: float = 1.0, power: int = 1):
+    """rows of [re | im] (rows, 2 n_bins) -> scale * |.| (power 1) or scale * |.|^2 (power 2), (rows, n_bins)."""
+    keep, ptr, where = _as_f32(reim, "reim")
+    if keep.ndim != 2 or keep.shape[1] != 2 * n_bins:
+        raise ValueError("reim must be (rows, 2 * n_bins)")
+    out = ctx._empty((int(keep.shape[0]), int(n_bins)), where)
+    optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
+    _lib.check(ctx._lib.ssp_spectrum_abs(ctx._h, ptr, int(keep.shape[0]), int(n_bins), float(scale), int(power), optr, where, None))
+    return out
+
+
 def delta_features(ctx: Context, feats, frame_seg: Segments, N: int = 2, timing: bool = False):
     keep, ptr, where = _as_f32(feats, "feats")
     if keep.ndim != 2:

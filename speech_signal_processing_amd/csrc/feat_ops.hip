@@ -240,3 +240,43 @@ int ssp_cmvn(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, in
 }
 
 }  // extern "C"
+
+namespace ssp {
+// |re + i im| (power 1) or re^2 + im^2 (power 2), scaled: rows of [re(0..nb) | im(0..nb)] -> rows of nb bins
+__global__ void spectrum_abs_kernel(const float* __restrict__ reim, int64_t n, int nb, float scale, int power, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = i / nb;
+    const int k = (int)(i - r * nb);
+    const float re = reim[r * 2 * nb + k], im = reim[r * 2 * nb + nb + k];
+    const float p = re * re + im * im;
+    out[i] = scale * (power == 2 ? p : sqrtf(p));
+}
+}  // namespace ssp
+
+extern "C" int ssp_spectrum_abs(ssp_ctx* ctx, const float* reim, int64_t n_rows, int32_t n_bins, float scale, int32_t power,
+                                float* out, int where, float* kernel_ms) {
+    using namespace ssp;
+    SSP_TRY(use_ctx(ctx));
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n_rows < 0 || n_bins < 1 || (power != 1 && power != 2)) SSP_FAIL(SSP_ERR_INVALID, "ssp_spectrum_abs: bad argument");
+    if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_spectrum_abs: where");
+    if (n_rows == 0) return SSP_OK;
+    if (!reim || !out) SSP_FAIL(SSP_ERR_INVALID, "ssp_spectrum_abs: null data pointer");
+    const int64_t n = n_rows * n_bins;
+    if ((n + 255) / 256 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_spectrum_abs: too many elements");
+    Staged si, so;
+    int rc;
+    const float* dI = (const float*)si.in(ctx, reim, (size_t)n * 2 * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    float* dO = (float*)so.out(out, (size_t)n * sizeof(float), where, &rc);
+    SSP_TRY(rc);
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
+    hipLaunchKernelGGL(spectrum_abs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dI, n, n_bins, scale, power, dO);
+    SSP_HIP(hipGetLastError());
+    SSP_TRY(tm.stop(ctx->stream, kernel_ms));
+    SSP_TRY(so.back(ctx, out, (size_t)n * sizeof(float), where));
+    if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(ctx->stream));
+    return SSP_OK;
+}

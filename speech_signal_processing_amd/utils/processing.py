@@ -45,9 +45,42 @@ def stMFCC(X, fbank, n_mfcc_feats):
     return np.asarray(out, dtype=np.float64).reshape(X.shape[:-1] + (int(n_mfcc_feats),))
 
 
+@functools.lru_cache(maxsize=8)
+def _dft_tables(fs, L):
+    """Frame sizes that are not powers of two: the length-L real DFT as a matrix ([cos | -sin] rows, float64 -> float32) for
+    the MFMA dense kernel, and the reference's filterbank over L bins folded onto the L // 2 + 1 one-sided bins."""
+    nb = L // 2 + 1
+    k = np.arange(nb)[:, None]
+    n = np.arange(L)[None, :]
+    ang = 2.0 * np.pi * ((k * n) % L) / L
+    Wt = np.concatenate([np.cos(ang), -np.sin(ang)]).astype(np.float32)      # (2 nb, L)
+    bank, _ = frontend.mfccInitFilterBanks(fs, L)
+    folded = np.array(bank[:, :nb])
+    m = (L - 1) // 2                                                         # bins 1..m have a mirror image L - k
+    folded[:, 1:m + 1] += bank[:, :L - m - 1:-1]
+    return Wt, folded.astype(np.float32)
+
+
+def _mfcc_any_size(x, fs, L, step):
+    """utils/processing.py:110-144 for any frame size: enframe (GPU) -> DFT as one MFMA matrix product -> |.| / L ->
+    filterbank + log10 + DCT (ssp_cepstrum)."""
+    ctx = api.default_context()
+    Wt, folded = _dft_tables(int(fs), int(L))
+    frames = np.asarray(api.enframe(ctx, x, L, step, np.hamming(L)))          # (L, n_frames), the reference's layout
+    rows = np.ascontiguousarray(frames.T)                                    # (n_frames, L): a re-layout, no arithmetic
+    reim = api.dense_forward(ctx, rows, Wt)
+    mag = api.spectrum_abs(ctx, reim, L // 2 + 1, scale=1.0 / L, power=1)
+    dct = frontend.dct2_ortho(40, 0, 13)
+    return np.asarray(api.cepstrum(ctx, mag, folded, dct, frontend.LOG_LOG10, frontend.FLOOR_ADD_EPS, eps), dtype=np.float64)
+
+
 def MFCC(raw_signal, fs=8000, frameSize=512, step=256):
-    """utils/processing.py:110-144 — (frames, 13) float64 MFCC matrix of one utterance, computed on the GPU."""
+    """utils/processing.py:110-144 — (frames, 13) float64 MFCC matrix of one utterance, computed on the GPU (the fused
+    kernel for power-of-two frame sizes, a DFT-matrix product on the matrix cores for any other size)."""
     x = np.ascontiguousarray(np.asarray(raw_signal).reshape(-1), dtype=np.float32)
+    L = int(frameSize)
+    if L < 64 or L > 4096 or (L & (L - 1)):
+        return _mfcc_any_size(x, int(fs), L, int(step))
     plan = _plan(int(fs), int(frameSize), int(step), 13, False)
     seg = api.Segments.from_lengths(plan.ctx, [x.shape[0]])
     feats = plan.run(x, seg)
@@ -57,6 +90,9 @@ def MFCC(raw_signal, fs=8000, frameSize=512, step=256):
 def MFCC_batch(signals, fs=8000, frameSize=512, step=256):
     """Batched form of MFCC(): list of 1-D signals -> list of (frames_i, 13) float64 (one kernel launch)."""
     sig = [np.asarray(s, dtype=np.float32).reshape(-1) for s in signals]
+    L = int(frameSize)
+    if L < 64 or L > 4096 or (L & (L - 1)):
+        return [_mfcc_any_size(s, int(fs), L, int(step)) for s in sig]
     plan = _plan(int(fs), int(frameSize), int(step), 13, False)
     seg = api.Segments.from_lengths(plan.ctx, [s.shape[0] for s in sig])
     fseg = plan.frame_segments(seg)

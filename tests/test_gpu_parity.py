@@ -224,6 +224,24 @@ def test_inrepo_dialect_both_kernels_vs_oracle(ssp, variant, geom):
         assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"inrepo {geom} utt {u} variant {variant}")
 
 
+@pytest.mark.parametrize("geom", [(16000, 400, 160), (8000, 401, 200), (16000, 480, 160), (8000, 100, 37)])
+def test_inrepo_mfcc_any_frame_size(ssp, geom):
+    """utils.processing.MFCC with frame sizes that are not powers of two (enframe's own default is 400 / 160): the DFT runs
+    as a matrix product on the matrix cores, the rest as the stand-alone kernels; against the float64 oracle (scipy FFT)"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd.utils import processing as P
+    fs, L, st = geom
+    for u, n in ((0, 5000), (1, 1234), (2, L // 2)):
+        x = synth_audio(u, n, fs)
+        got = P.MFCC(x, fs, L, st)
+        ref = O.MFCC(x, fs, L, st)
+        assert got.dtype == np.float64
+        assert_feat_close(got, ref, what=f"any-size {geom} utt {u}")
+    b = P.MFCC_batch([synth_audio(3, 3000, fs), synth_audio(4, 700, fs)], fs, L, st)
+    assert b[1].shape == O.MFCC(synth_audio(4, 700, fs), fs, L, st).shape
+
+
 def test_fast_kernel_long_utterance_chunking(ssp):
     """utterances longer than one workgroup's LDS budget are cut into chunks with recomputed delta halos"""
     pkg, api = ssp

@@ -121,3 +121,17 @@ def test_model_pickles_round_trip(tmp_path):
     assert sorted(p.name for p in (tmp_path / "Model").iterdir()) == ["GMM_MFCC_model.pkl", "UBM_MFCC_model.pkl"]
     gm2, ubm2 = GMM_UBM.load_models(str(tmp_path / "Model"))
     assert len(gm2) == 2 and np.array_equal(ubm2.means_, ubm.means_)
+
+
+def test_dft_tables_any_size():
+    """host tables of the any-frame-size MFCC path: DFT matrix + folded filterbank reproduce fbank . |FFT| for even and odd L"""
+    from speech_signal_processing_amd.utils import processing as P
+    from speech_signal_processing_amd import frontend as F
+    rng = np.random.default_rng(0)
+    for L in (400, 401, 10):
+        Wt, fold = P._dft_tables(16000, L)
+        bank, _ = F.mfccInitFilterBanks(16000, L)
+        x = rng.standard_normal(L)
+        nb = L // 2 + 1
+        re, im = Wt[:nb].astype(np.float64) @ x, Wt[nb:].astype(np.float64) @ x
+        assert np.abs(bank @ np.abs(np.fft.fft(x)) - fold.astype(np.float64) @ np.sqrt(re * re + im * im)).max() < 1e-6
