@@ -488,6 +488,25 @@ def test_gmm_fit_vs_sklearn_golden(golden, ssp, tag):
     assert abs(gm.score(x) - ref) <= 1e-4 * abs(ref)
 
 
+def test_gmm_default_init_reaches_sklearn_quality(ssp):
+    """without *_init arguments the GPU trainer starts from random frames + global variance (sklearn: k-means); on well
+    separated data both reach the same optimum: the lower bounds agree and the held-out scores match"""
+    from sklearn.mixture import GaussianMixture as SkGM
+    pkg, api = ssp
+    from speech_signal_processing_amd.gmm_train import GaussianMixture
+    rng = np.random.default_rng(31)
+    K, D, n = 6, 13, 6000
+    centres = 6.0 * rng.standard_normal((K, D))
+    lab = rng.integers(0, K, n)
+    X = (centres[lab] + rng.standard_normal((n, D))).astype(np.float32)
+    best = max((GaussianMixture(n_components=K, random_state=seed, max_iter=200).fit(X) for seed in range(3)), key=lambda g: g.lower_bound_)
+    sk = SkGM(n_components=K, covariance_type="diag", random_state=0, n_init=3).fit(X.astype(np.float64))
+    assert best.converged_
+    assert abs(best.lower_bound_ - sk.lower_bound_) < 5e-3 * abs(sk.lower_bound_)
+    Xt = (centres[rng.integers(0, K, 500)] + rng.standard_normal((500, D))).astype(np.float32)
+    assert abs(best.score(Xt) - sk.score(Xt.astype(np.float64))) < 5e-3 * abs(sk.score(Xt.astype(np.float64)))
+
+
 def test_gmm_train_end_to_end_speaker_id(ssp):
     """GMM_UBM.GMM(train, ...) with model=None: per-speaker GMMs + UBM trained on the GPU from random starts identify
     well separated synthetic speakers (the reference's train-then-score path, GMM_UBM.py:134-199)"""
