@@ -530,6 +530,36 @@ def test_gmm_train_end_to_end_speaker_id(ssp):
     assert len(gmms) == S and ubm.means_.shape == (4, D) and abs(ubm.weights_.sum() - 1) < 1e-12
 
 
+def test_end_to_end_gmm_ubm_recogniser_on_audio(ssp):
+    """the reference's GMM-UBM flow end to end on the GPU (GMM_UBM.py:120-199): synthetic audio of 5 speakers (SURVEY 8(d) recipe,
+    f0 = 90 + 3 s Hz) -> extract_feature (sidekit MFCC + delta + scale) -> GMM(train, ...) trains 5 speaker GMMs + the UBM by EM
+    -> score_matrix / arg-max.  The same features through sklearn's GaussianMixture + the reference's loop give the same
+    recogniser quality; with sklearn's models the GPU scorer reproduces the reference loop's decisions exactly."""
+    from sklearn.mixture import GaussianMixture as SkGM
+    pkg, api = ssp
+    from speech_signal_processing_amd import GMM_UBM
+    S = 5
+    # speakers differ by f0: synth_audio(utt, ...) uses s = utt % S_arg; force the speaker through the utt index
+    def spk_audio(s, r, n):
+        return synth_audio(s + 40 * r, n, 16000, S=40)   # utt % 40 = s for s < 40: f0 = 90 + 3 s Hz, noise seeded by utt
+    x_tr = [spk_audio(8 * s, r, 32000) for s in range(S) for r in range(1, 4)]
+    y_tr = [s for s in range(S) for r in range(1, 4)]
+    x_te = [spk_audio(8 * s, r, 24000) for s in range(S) for r in range(4, 6)]
+    y_te = [s for s in range(S) for r in range(4, 6)]
+    train, f_tr, _ = GMM_UBM.extract_feature(x_tr, y_tr, is_train=True)
+    f_te, _ = GMM_UBM.extract_feature(x_te, y_te)
+    assert f_tr[0].shape[1] == 26 and sorted(train.keys()) == list(range(S))
+    acc_tr, acc_te = GMM_UBM.GMM(train, f_tr, y_tr, f_te, y_te, n_components=4, random_state=0)
+    gm = [SkGM(4, covariance_type="diag", random_state=0).fit(train[s]) for s in range(S)]
+    ubm = SkGM(4, covariance_type="diag", random_state=0).fit(np.vstack([train[s] for s in range(S)]))
+    ref_acc = (np.array([[g.score(x) - ubm.score(x) for g in gm] for x in f_te]).argmax(1) == np.array(y_te)).mean()
+    # different EM starts (k-means there, random frames here): the recognisers must be of the same quality, not identical
+    assert acc_tr >= 0.9 and acc_te >= ref_acc - 0.101, (acc_tr, acc_te, ref_acc)
+    # and with sklearn-trained models the GPU scorer reproduces the reference loop's decisions exactly
+    pred = GMM_UBM.score_matrix(gm, ubm, f_te)[1]
+    assert (pred == np.array([[g.score(x) - ubm.score(x) for g in gm] for x in f_te]).argmax(1)).all()
+
+
 def test_gmm_em_stats_device_tensor_and_errors(ssp):
     import torch
     pkg, api = ssp
