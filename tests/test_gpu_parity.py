@@ -507,6 +507,28 @@ def test_gmm_default_init_reaches_sklearn_quality(ssp):
     assert abs(best.score(Xt) - sk.score(Xt.astype(np.float64))) < 5e-3 * abs(sk.score(Xt.astype(np.float64)))
 
 
+def test_gmm_kmeans_init(ssp):
+    """default init_params='kmeans' (k-means++ seeds + GPU Lloyd): on separated clusters ONE start lands on the optimum sklearn
+    finds, in a handful of EM iterations; 'random_from_data' is the other start; bad values are rejected"""
+    from sklearn.mixture import GaussianMixture as SkGM
+    pkg, api = ssp
+    from speech_signal_processing_amd.gmm_train import GaussianMixture
+    rng = np.random.default_rng(77)
+    K, D, n = 8, 20, 8000
+    centres = 8.0 * rng.standard_normal((K, D))
+    X = (centres[rng.integers(0, K, n)] + rng.standard_normal((n, D))).astype(np.float32)
+    g = GaussianMixture(n_components=K, random_state=3).fit(X)
+    sk = SkGM(n_components=K, covariance_type="diag", random_state=3).fit(X.astype(np.float64))
+    assert g.converged_ and g.n_iter_ <= 10
+    assert abs(g.lower_bound_ - sk.lower_bound_) < 2e-3 * abs(sk.lower_bound_)
+    order = np.argsort(g.means_[:, 0]), np.argsort(sk.means_[:, 0])
+    assert np.allclose(g.means_[order[0]], sk.means_[order[1]], atol=0.05)
+    r = GaussianMixture(n_components=K, random_state=3, init_params='random_from_data', max_iter=300).fit(X)
+    assert r.means_.shape == (K, D) and np.isfinite(r.lower_bound_)
+    with pytest.raises(ValueError):
+        GaussianMixture(n_components=2, init_params='k-means++')
+
+
 def test_gmm_train_end_to_end_speaker_id(ssp):
     """GMM_UBM.GMM(train, ...) with model=None: per-speaker GMMs + UBM trained on the GPU from random starts identify
     well separated synthetic speakers (the reference's train-then-score path, GMM_UBM.py:134-199)"""
