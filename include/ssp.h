@@ -162,6 +162,12 @@ int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double* weights, 
 int ssp_dtw_distances(ssp_ctx* ctx, const float* xq, const ssp_segments* q_seg, const float* xt, const ssp_segments* t_seg,
                       int32_t dim, int32_t normalize, float* dist_out, int where, float* kernel_ms);
 
+/* One pair WITH the warping path — what generate_template (MFCC_DTW.py:187-217) takes from accelerated_dtw: d and
+ * path = _traceback(D0) (first minimum of diagonal / up / left at every step), computed in float64 like the package.
+ * x: HOST float[r x dim], y: HOST float[c x dim]; path_i_out / path_j_out: HOST int32[r + c] (path_len_out entries are written). */
+int ssp_dtw_path(ssp_ctx* ctx, const float* x, int64_t r, const float* y, int64_t c, int32_t dim, double* dist_out,
+                 int32_t* path_i_out, int32_t* path_j_out, int32_t* path_len_out);
+
 /* ---- d-vector network forward: one Dense layer Y = act(X W + b) of the speaker network the reference runs with
  *      spkModel.predict (d_vector.py:171-189 builds Dense(256) x 4 with ReLU between; predict at d_vector.py:298-299,327,348) ---- */
 /* X: float[N x d_in]; Wt: float[units x d_in] = the Keras kernel (d_in x units) TRANSPOSED; bias: float[units] (nullable);

@@ -57,3 +57,23 @@ def classify(x_test, x_train, y_train, normalize=False):
     with distances[i, k] = distance_dtw(x_train[k], x_test[i]) and y_pred[i] = y_train[argmin_k]."""
     d = np.asarray(api.dtw_distances(api.default_context(), x_train, x_test, normalize=normalize), dtype=np.float64).T
     return d, [y_train[k] for k in d.argmin(axis=1)]
+
+
+def generate_template(x):
+    """MFCC_DTW.py:187-217 — one template per speaker: start from the longest sample; for every other sample warp it onto
+    the template (accelerated_dtw path), average the aligned values and keep the first entry of every template index, so the
+    template keeps the longest sample's length.  The DTW + traceback run on the GPU in float64 (api.dtw_path)."""
+    ctx = api.default_context()
+    max_length_index = int(np.argmax([np.asarray(_x).shape[0] for _x in x]))  # first of the longest, like the reference's scan
+    template = np.asarray(x[max_length_index], dtype=np.float64)
+    for index, _x in enumerate(x):
+        if index == max_length_index:
+            continue
+        _x = np.asarray(_x, dtype=np.float64)
+        _, p0, p1 = api.dtw_path(ctx, _x, template)
+        template = (_x[p0] + template[p1]) / 2
+        keep = np.empty(len(p1), dtype=bool)
+        keep[0] = True
+        keep[1:] = p1[1:] != p1[:-1]
+        template = template[keep]
+    return template

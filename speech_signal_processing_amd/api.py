@@ -407,6 +407,25 @@ def dtw_distances(ctx: Context, queries, templates, normalize: bool = False, tim
     return (out, ms.value) if timing else out
 
 
+def dtw_path(ctx: Context, x, y):
+    """d and the warping path of dtw.accelerated_dtw(x, y, 'euclidean') (ssp_dtw_path, float64 on the GPU).
+    x (r,) or (r, dim), y (c,) or (c, dim).  Returns (d, path_i int64[len], path_j int64[len])."""
+    a = np.asarray(x, dtype=np.float32)
+    b = np.asarray(y, dtype=np.float32)
+    a = np.ascontiguousarray(a.reshape(-1, 1) if a.ndim == 1 else a)
+    b = np.ascontiguousarray(b.reshape(-1, 1) if b.ndim == 1 else b)
+    if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1] or a.shape[0] < 1 or b.shape[0] < 1:
+        raise ValueError("x (r, dim) and y (c, dim) must be non-empty and share dim")
+    r, c = a.shape[0], b.shape[0]
+    pi = np.empty(r + c, dtype=np.int32)
+    pj = np.empty(r + c, dtype=np.int32)
+    d = C.c_double(0.0)
+    n = C.c_int32(0)
+    _lib.check(ctx._lib.ssp_dtw_path(ctx._h, a.ctypes.data, r, b.ctypes.data, c, a.shape[1], C.byref(d), pi.ctypes.data,
+                                      pj.ctypes.data, C.byref(n)))
+    return d.value, pi[:n.value].astype(np.int64), pj[:n.value].astype(np.int64)
+
+
 def dense_forward(ctx: Context, X, Wt, bias=None, relu: bool = False, timing: bool = False):
     """Y = act(X @ Wt.T + bias) — one Keras Dense layer (ssp_dense_forward).  X (N, d_in); Wt (units, d_in) is the Keras
     kernel transposed; all arrays numpy (host) or all torch CUDA tensors.  Returns Y (N, units) of the same kind."""

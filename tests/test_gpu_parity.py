@@ -693,6 +693,27 @@ def test_dtw_vs_oracle_flattened_mfcc(ssp):
     assert MFCC_DTW.distance_test(test[0], train).shape == (1, 3)
 
 
+def test_dtw_path_and_generate_template(ssp):
+    """the warping path (float64 wavefront + traceback on the GPU) equals the package's traceback step for step, and
+    generate_template (MFCC_DTW.py:187-217) reproduces the oracle's template"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd import MFCC_DTW
+    rng = np.random.default_rng(12)
+    for (r, c, dim) in ((50, 70, 1), (1, 9, 1), (9, 1, 1), (130, 1100, 1), (40, 33, 13)):
+        x = (rng.standard_normal((r, dim)) if dim > 1 else rng.standard_normal(r)).astype(np.float32)
+        y = (rng.standard_normal((c, dim)) if dim > 1 else rng.standard_normal(c)).astype(np.float32)
+        d, pi, pj = api.dtw_path(api.default_context(), x, y)
+        rd, rp, rq = O.dtw_path(x, y)
+        assert abs(d - rd) <= 1e-9 * max(1.0, abs(rd))
+        assert np.array_equal(pi, rp) and np.array_equal(pj, rq), (r, c, dim)
+    samples = [O.MFCC(synth_audio(u, n, 8000), 8000, 512, 256).flatten() for u, n in ((0, 5000), (1, 9000), (2, 7000), (3, 6500))]
+    got = MFCC_DTW.generate_template(samples)
+    ref = O.generate_template(samples)
+    assert got.shape == ref.shape == samples[1].shape
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("dim,lens_q,lens_t", [(1, [1, 2, 65, 300], [1, 64, 257]), (13, [5, 94], [94, 30, 1]), (1, [70], [2100, 4500]), (3, [40], [2050])])
 def test_dtw_shapes_vs_oracle(ssp, dim, lens_q, lens_t):
     """ragged lengths: single elements, lane-block boundaries, multi-dimensional rows, templates longer than one super-block"""

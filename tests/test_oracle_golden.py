@@ -155,3 +155,16 @@ def test_dtw_oracle_matches_plain_recurrence():
         assert O.dtw_distance(x, x) == 0.0
         assert abs(O.dtw_distance(x, y) - O.dtw_distance(y, x)) < 1e-12
     assert O.dtw_distance([0.0, 1.0, 2.0], [0.0, 2.0]) == 1.0
+
+
+def test_dtw_path_oracle():
+    """the oracle's path obeys the package's invariants: starts at (0, 0), ends at (r-1, c-1), unit steps, and its cost is d"""
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(31), rng.standard_normal(45)
+    d, p, q = O.dtw_path(x, y)
+    assert (p[0], q[0]) == (0, 0) and (p[-1], q[-1]) == (30, 44)
+    dp, dq = np.diff(p), np.diff(q)
+    assert ((dp >= 0) & (dq >= 0) & (dp + dq >= 1) & (dp <= 1) & (dq <= 1)).all()
+    assert abs(np.abs(x[p] - y[q]).sum() - d) < 1e-9 and abs(d - O.dtw_distance(x, y)) < 1e-12
+    t = O.generate_template([x, y, rng.standard_normal(20)])
+    assert t.shape == y.shape
