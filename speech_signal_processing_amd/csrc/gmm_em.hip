@@ -243,21 +243,30 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
         }
 }
 
-// out[j] = sum_g part[g][j] (float64, fixed order);  j over Kp * W columns, then the lse partials
-__global__ void gmm_em_reduce_kernel(const float* part, int G, int64_t cols, const float* lse_part, int64_t n_lse, double* out) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < cols) {
-        double s = 0.0;
-        for (int g = 0; g < G; ++g) s += (double)part[(size_t)g * cols + j];
-        out[j] = s;
+// out[j] = sum_g part[g][j] (float64, fixed order): block = 32 columns x 8 slices of the partial index (coalesced 128-byte
+// reads), the 8 slice sums are added in slice order;  block 0 also reduces the lse partials
+__global__ __launch_bounds__(256) void gmm_em_reduce_kernel(const float* part, int G, int64_t cols, const float* lse_part, int64_t n_lse,
+                                                            double* out) {
+    __shared__ double sh[256];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t j = (int64_t)blockIdx.x * 32 + tx;
+    double s = 0.0;
+    if (j < cols)
+        for (int g = ty; g < G; g += 8) s += (double)part[(size_t)g * cols + j];
+    sh[ty * 32 + tx] = s;
+    __syncthreads();
+    if (ty == 0 && j < cols) {
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += sh[k * 32 + tx];
+        out[j] = t;
     }
-    if (blockIdx.x == 0) {  // sum_t lse[t]: one workgroup, fixed strided order + tree
-        __shared__ double sh[256];
-        double s = 0.0;
-        for (int64_t i = threadIdx.x; i < n_lse; i += blockDim.x) s += (double)lse_part[i];
-        sh[threadIdx.x] = s;
+    if (blockIdx.x == 0) {  // sum_t lse[t]: fixed strided order + tree
         __syncthreads();
-        for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        double v = 0.0;
+        for (int64_t i = threadIdx.x; i < n_lse; i += 256) v += (double)lse_part[i];
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
             __syncthreads();
         }
@@ -360,7 +369,7 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
         hipLaunchKernelGGL(gmm_em_acc_kernel, dim3(G, Kp / EM_KC), dim3(256), lds2, s, a);
     }
     if (rc == SSP_OK) {
-        hipLaunchKernelGGL(gmm_em_reduce_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, d_part.as<float>(), GP, cols,
+        hipLaunchKernelGGL(gmm_em_reduce_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, s, d_part.as<float>(), GP, cols,
                            d_lsep.as<float>(), n_tiles, d_out.as<double>());
         if (hipGetLastError() != hipSuccess) {
             set_error("ssp_gmm_em_stats: kernel launch failed");
