@@ -18,6 +18,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int BM = 128;  // centroid rows per block step
 constexpr int BN = 128;  // embedding columns per workgroup
 constexpr int BK = 32;   // k-chunk
+constexpr int CPL = 128 * 4 + 4;  // floats per (q, h) plane of the operand image (+4 pad: conflict-free staging stores, csrc/dense.hip)
 
 struct CosArgs {
     const float* X;    // [N x d]
@@ -67,8 +68,8 @@ __device__ __forceinline__ float stage_slab(const float* __restrict__ A, int64_t
         }
         ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         const int q = c4 >> 1, e0 = (c4 & 1) * 2;  // kk = (c4&1)*4 + {0,1,2,3}: h = kk&1, e = kk>>1
-        float* b0 = img + ((size_t)(q * 2 + 0) * 128 + r) * 4 + e0;
-        float* b1 = img + ((size_t)(q * 2 + 1) * 128 + r) * 4 + e0;
+        float* b0 = img + (size_t)(q * 2 + 0) * CPL + r * 4 + e0;
+        float* b1 = img + (size_t)(q * 2 + 1) * CPL + r * 4 + e0;
         *reinterpret_cast<float2*>(b0) = make_float2(v.x, v.z);
         *reinterpret_cast<float2*>(b1) = make_float2(v.y, v.w);
     }
@@ -77,7 +78,7 @@ __device__ __forceinline__ float stage_slab(const float* __restrict__ A, int64_t
 
 __global__ __launch_bounds__(256) void cosine_kernel(CosArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SLAB = (BK / 8) * 2 * 128 * 4;  // floats per operand slab
+    constexpr int SLAB = (BK / 8) * 2 * CPL;  // floats per operand slab
     float* imgA = reinterpret_cast<float*>(smem);  // centroids
     float* imgB = imgA + SLAB;                     // embeddings
     float* inx = imgB + SLAB;                      // [BN] 1/|x|
@@ -120,10 +121,10 @@ __global__ __launch_bounds__(256) void cosine_kernel(CosArgs a) {
                 f32x4 av[2], bv[2];
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
-                    av[rt] = *reinterpret_cast<const f32x4*>(imgA + ((size_t)(q * 2 + h) * 128 + wr * 64 + rt * 32 + fl) * 4);
+                    av[rt] = *reinterpret_cast<const f32x4*>(imgA + (size_t)(q * 2 + h) * CPL + (wr * 64 + rt * 32 + fl) * 4);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
-                    bv[ct] = *reinterpret_cast<const f32x4*>(imgB + ((size_t)(q * 2 + h) * 128 + wc * 64 + ct * 32 + fl) * 4);
+                    bv[ct] = *reinterpret_cast<const f32x4*>(imgB + (size_t)(q * 2 + h) * CPL + (wc * 64 + ct * 32 + fl) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -441,7 +442,7 @@ int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, cons
         const int64_t grid = ceil_div<int64_t>(N, BN);
         if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
         CosArgs a{dX, dC, inc.as<float>(), dD, dA, dM, N, d, S};
-        constexpr size_t lds = (size_t)(2 * (BK / 8) * 2 * 128 * 4 + BN + 2 * BN) * sizeof(float) + 2 * BN * sizeof(int);
+        constexpr size_t lds = (size_t)(2 * (BK / 8) * 2 * CPL + BN + 2 * BN) * sizeof(float) + 2 * BN * sizeof(int);
         SSP_TRY(tm.start(kernel_ms != nullptr, s));
         hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, s, dC, (int64_t)S, d, inc.as<float>());
         SSP_HIP(hipGetLastError());

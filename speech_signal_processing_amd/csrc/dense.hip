@@ -13,6 +13,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int DBM = 128;  // units per block step
 constexpr int DBN = 128;  // samples per workgroup
 constexpr int DBK = 32;   // k-chunk
+constexpr int DPL = 128 * 4 + 4;  // floats per (q, h) plane of the operand image: 128 rows x 4 + 4 pad, so that the 8 planes the
+                                  // 16 lanes of a ds_write_b64 group touch start on different banks (unpadded: 4-way conflicts)
 
 struct DenseArgs {
     const float* X;     // [N x d_in]
@@ -46,14 +48,14 @@ __device__ __forceinline__ void dense_stage(const float* __restrict__ A, int64_t
             }
         }
         const int q = c4 >> 1, e0 = (c4 & 1) * 2;
-        *reinterpret_cast<float2*>(img + ((size_t)(q * 2 + 0) * 128 + r) * 4 + e0) = make_float2(v.x, v.z);
-        *reinterpret_cast<float2*>(img + ((size_t)(q * 2 + 1) * 128 + r) * 4 + e0) = make_float2(v.y, v.w);
+        *reinterpret_cast<float2*>(img + (size_t)(q * 2 + 0) * DPL + r * 4 + e0) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2*>(img + (size_t)(q * 2 + 1) * DPL + r * 4 + e0) = make_float2(v.y, v.w);
     }
 }
 
 __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SLAB = (DBK / 8) * 2 * 128 * 4;
+    constexpr int SLAB = (DBK / 8) * 2 * DPL;
     float* imgA = reinterpret_cast<float*>(smem);  // weights (units)
     float* imgB = imgA + SLAB;                     // samples
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -83,10 +85,10 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
                 f32x4 av[2], bv[2];
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
-                    av[rt] = *reinterpret_cast<const f32x4*>(imgA + ((size_t)(q * 2 + h) * 128 + wr * 64 + rt * 32 + fl) * 4);
+                    av[rt] = *reinterpret_cast<const f32x4*>(imgA + (size_t)(q * 2 + h) * DPL + (wr * 64 + rt * 32 + fl) * 4);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
-                    bv[ct] = *reinterpret_cast<const f32x4*>(imgB + ((size_t)(q * 2 + h) * 128 + wc * 64 + ct * 32 + fl) * 4);
+                    bv[ct] = *reinterpret_cast<const f32x4*>(imgB + (size_t)(q * 2 + h) * DPL + (wc * 64 + ct * 32 + fl) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -155,7 +157,7 @@ extern "C" int ssp_dense_forward(ssp_ctx* ctx, const float* X, int64_t N, int32_
     float* dY = (float*)sy.out(Y, (size_t)N * units * sizeof(float), where, &rc);
     SSP_TRY(rc);
     DenseArgs a{dX, dW, dB, dY, N, d_in, units, relu ? 1 : 0};
-    constexpr size_t lds = (size_t)2 * (DBK / 8) * 2 * 128 * 4 * sizeof(float);
+    constexpr size_t lds = (size_t)2 * (DBK / 8) * 2 * DPL * sizeof(float);
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, s));
     hipLaunchKernelGGL(dense_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
