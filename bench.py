@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused fast kernel")
-    ap.add_argument("--stages", default="mfcc,gmm,gmm4,cosine,em,dnn,dtw")
+    ap.add_argument("--stages", default="mfcc,gmm,gmm4,cosine,em,dnn,dvec,dtw")
     ap.add_argument("--gmm4-utts", type=int, default=2000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
@@ -374,6 +374,41 @@ def main():
                                  "roofline": {"bound": "mfma", "achieved": flop / tot / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                               "frac": flop / tot / 1e9 / MFMA_F32_PEAK_TF, "traffic": None}}
         del Xd, h
+    if "dvec" in stages:
+        # the d-vector recogniser end to end on device-resident audio (d_vector.py:80-115 chunking + sidekit MFCC -> (98, 13) ->
+        # 1274-d input -> Dense(256) x 4 -> cosine against 1251 enrolment centroids -> arg-min), zero-copy between the stages
+        n_ch_utt = min(n_utt, 100000)
+        chunks = audio[:n_ch_utt].reshape(-1, fs)                      # 1 s chunks: (3 n_utt, 16000)
+        n_ch = int(chunks.shape[0])
+        plan13 = api.MfccPlan(ctx, pkg.preset_sidekit(fs=fs, delta_order=0, cmvn=0))
+        seg13 = api.Segments.from_lengths(ctx, np.full(n_ch, fs, dtype=np.int64))
+        fseg13 = plan13.frame_segments(seg13)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(23 + rank)
+        dims = [98 * 13, 256, 256, 256, 256]
+        We = [torch.randn((dims[i + 1], dims[i]), generator=gen, device=device) / dims[i] ** 0.5 for i in range(4)]
+        be = [torch.zeros(dims[i + 1], device=device) for i in range(4)]
+        Ce = torch.randn((1251, 256), generator=gen, device=device)
+        f13 = torch.empty((fseg13.total, 13), dtype=torch.float32, device=device)
+
+        def run_e2e():
+            plan13.run(chunks.reshape(-1), seg13, fseg13, out=f13)
+            h = f13.view(n_ch, 98 * 13)
+            for i in range(4):
+                h = api.dense_forward(ctx, h, We[i], be[i], relu=i < 3)
+            return api.cosine_identify(ctx, h, Ce, minval=False)["argmin"]
+        run_e2e()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ids = run_e2e()
+        torch.cuda.synchronize()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0, device)
+        result["dvector_pipeline"] = {"metric": "d-vector recogniser end to end: 1 s chunks -> MFCC 98x13 -> Dense 1274-256x4 -> cosine vs 1251 -> arg-min",
+                                      "value": n_ch * world / dt, "unit": "chunks/s", "chunks_per_gpu": n_ch, "ms": dt * 1e3,
+                                      "audio_seconds_per_second": n_ch * world / dt, "dtype": "f32", "ids_checksum": int(ids.long().sum().item())}
+        del chunks, f13, ids
     if "dtw" in stages:
         rng = np.random.default_rng(13)
         nq, nt, L = 128, 64, 1222
