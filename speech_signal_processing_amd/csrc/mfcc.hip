@@ -58,6 +58,10 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
     float* ddl = reinterpret_cast<float*>(smem + a.lds_ddl_off);
     float* lmrows = reinterpret_cast<float*>(smem + a.lds_lmrows_off);
     float* stats = reinterpret_cast<float*>(smem + a.lds_stats_off);  // [2][d_out] mean, inv std; [256] reduce scratch
+    // twiddles W_nfft^k, k < n_fft, in LDS: the FFT passes would otherwise wait on 3 dependent global loads per butterfly
+    float2* tw = reinterpret_cast<float2*>(smem + a.lds_tw_off);
+    for (int i = tid; i < a.n_fft; i += 256) tw[i] = a.twiddle[i];
+    __syncthreads();
 
     const MfccChunk ch = a.chunks[blockIdx.x];
     const int64_t s0 = a.sample_off[ch.utt];
@@ -102,9 +106,9 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
                 const int k = j & (Ns - 1);
                 float2 v0 = in[j], v1 = in[j + q], v2 = in[j + 2 * q], v3 = in[j + 3 * q];
                 if (Ns > 1) {
-                    v1 = cmul(v1, a.twiddle[k * tstride]);
-                    v2 = cmul(v2, a.twiddle[2 * k * tstride]);
-                    v3 = cmul(v3, a.twiddle[3 * k * tstride]);
+                    v1 = cmul(v1, tw[k * tstride]);
+                    v2 = cmul(v2, tw[2 * k * tstride]);
+                    v3 = cmul(v3, tw[3 * k * tstride]);
                 }
                 const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
                 const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
             for (int j = lane; j < h; j += 64) {
                 const int k = j & (Ns - 1);
                 const float2 v0 = in[j];
-                const float2 v1 = cmul(in[j + h], a.twiddle[k * tstride]);
+                const float2 v1 = cmul(in[j + h], tw[k * tstride]);
                 const int d = ((j - k) << 1) + k;
                 outb[d] = make_float2(v0.x + v1.x, v0.y + v1.y);
                 outb[d + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
             const float2 zm = in[(M - k) & (M - 1)];
             const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);   // E = (Z[k] + conj Z[M-k]) / 2
             const float dr = 0.5f * (zk.x - zm.x), di = 0.5f * (zk.y + zm.y);   // D = (Z[k] - conj Z[M-k]) / 2
-            const float2 w = a.twiddle[k];                                      // W_nfft^k
+            const float2 w = tw[k];                                              // W_nfft^k
             const float2 o = cmul(make_float2(di, -dr), w);                     // (-i D) W^k
             const float re = er + o.x, im = ei + o.y;
             float p = re * re + im * im;

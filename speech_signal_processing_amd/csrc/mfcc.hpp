@@ -31,7 +31,7 @@ struct MfccArgs {
     int32_t frame_mode, preemph_mode, spec_power, log_mode, floor_mode, delta_order, delta_N, cmvn;
     float preemph, spec_scale, eps, top_db, delta_inv_denom;
     // LDS carve (bytes from the dynamic LDS base; all multiples of 16)
-    int32_t lds_logmel_off, lds_ceps_off, lds_dlt_off, lds_ddl_off, lds_lmrows_off, lds_stats_off;
+    int32_t lds_logmel_off, lds_ceps_off, lds_dlt_off, lds_ddl_off, lds_lmrows_off, lds_stats_off, lds_tw_off;
 };
 
 constexpr int MFCC_FAST_MAX_PASS = 4;  // <= 64 filters in the fused n_fft == 512 kernel

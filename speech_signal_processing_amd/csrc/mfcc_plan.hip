@@ -58,7 +58,9 @@ static size_t generic_lds_layout(const ssp_mfcc_cfg& c, int ch, MfccArgs* a) {
     a->lds_lmrows_off = (int32_t)off;
     if (c.top_db >= 0.f) off = align16(off + (size_t)ch * c.n_filt * sizeof(float));
     a->lds_stats_off = (int32_t)off;
-    off = align16(off + (size_t)(2 * c.n_ceps * (1 + c.delta_order) + 8) * sizeof(float));
+    off = align16(off + (size_t)(2 * c.n_ceps * (1 + c.delta_order) + 8 + 256) * sizeof(float));
+    a->lds_tw_off = (int32_t)off;
+    off = align16(off + (size_t)c.n_fft * sizeof(float2));
     return off;
 }
 
