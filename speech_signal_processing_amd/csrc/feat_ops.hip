@@ -72,6 +72,14 @@ __global__ __launch_bounds__(256) void cmvn_kernel(const float* __restrict__ in,
     }
 }
 
+int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, hipStream_t stream) {
+    if (n_utt <= 0) return SSP_OK;
+    if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cmvn: too many utterances");
+    hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)n_utt), dim3(256), (size_t)6 * dim * sizeof(float), stream, in, out, frame_off_dev, dim);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
+}
+
 // utils/processing.py:19-38 — framing + window; out is row-major (frame_size, n_frames) like the reference ndarray
 __global__ __launch_bounds__(256) void enframe_kernel(const float* __restrict__ x, int64_t n, int frame_size, int step,
                                                       int64_t n_frames, const float* __restrict__ window,

@@ -72,6 +72,8 @@ struct FastArgs {
 };
 
 int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, hipStream_t stream);
+// per-utterance CMVN over a feature matrix in global memory (feat_ops.hip; in == out allowed), any utterance length
+int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, hipStream_t stream);
 
 }  // namespace ssp
 
@@ -85,6 +87,7 @@ struct ssp_mfcc_plan {
     uint64_t cache_sseg = 0;  // ssp_segments::serial
     uint64_t cache_fseg = 0;
     int cache_variant = -1;
+    bool cache_split_cmvn = false;  // CMVN as a second kernel (an utterance exceeds one workgroup's chunk)
     int cache_chunk_frames = 0;
     size_t cache_lds = 0;
     int32_t cache_n_chunks = 0;

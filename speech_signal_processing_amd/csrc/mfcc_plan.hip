@@ -66,7 +66,8 @@ static size_t generic_lds_layout(const ssp_mfcc_cfg& c, int ch, MfccArgs* a) {
 
 static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segments* fseg, int variant) {
     const ssp_mfcc_cfg& c = p->cfg;
-    const bool whole = c.cmvn || c.top_db >= 0.f;  // needs utterance-level statistics inside one workgroup
+    bool whole = c.cmvn || c.top_db >= 0.f;  // needs utterance-level statistics inside one workgroup
+    bool split_cmvn = false;                 // utterances too long for that: features un-normalised, then the CMVN kernel in place
     const int64_t max_T = fseg->max_len();
     const size_t lds_cap = 160 * 1024;
     int ch;
@@ -79,9 +80,11 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), std::min(512, cap));
         if (whole) {
             ch = (int)std::max<int64_t>(max_T, 1);
-            if (ch > cap)
-                SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): cmvn needs a whole utterance per workgroup; %lld frames exceed the LDS",
-                         (long long)max_T);
+            if (ch > cap) {  // (top_db never reaches the fused kernel)
+                split_cmvn = true;
+                whole = false;
+                ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), std::min(512, cap));
+            }
         }
         lds = mfcc_fast_lds(c, tmp, ch);
         if (lds > lds_cap) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
@@ -91,10 +94,15 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         while (ch > 16 && generic_lds_layout(c, ch, &tmp) > 64 * 1024 && !whole) ch = (ch * 3) / 4;
         if (whole) {
             ch = (int)std::max<int64_t>(max_T, 1);
-            if (generic_lds_layout(c, ch, &tmp) > lds_cap)
-                SSP_FAIL(SSP_ERR_UNSUPPORTED,
-                         "mfcc: cmvn/top_db need a whole utterance per workgroup; %lld frames exceed the 160 KiB LDS",
-                         (long long)max_T);
+            if (generic_lds_layout(c, ch, &tmp) > lds_cap) {
+                if (c.top_db >= 0.f)
+                    SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: top_db needs a whole utterance per workgroup; %lld frames exceed the 160 KiB LDS",
+                             (long long)max_T);
+                split_cmvn = true;
+                whole = false;
+                ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
+                while (ch > 16 && generic_lds_layout(c, ch, &tmp) > 64 * 1024) ch = (ch * 3) / 4;
+            }
         }
         lds = generic_lds_layout(c, ch, &p->args);
         if (lds > lds_cap) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: LDS footprint %zu B exceeds 160 KiB", lds);
@@ -117,6 +125,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     p->cache_sseg = sseg->serial;
     p->cache_fseg = fseg->serial;
     p->cache_variant = variant;
+    p->cache_split_cmvn = split_cmvn;
     return SSP_OK;
 }
 
@@ -299,6 +308,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     SSP_TRY(rc);
 
     MfccArgs a = plan->args;
+    if (plan->cache_split_cmvn) a.cmvn = 0;  // utterances longer than one workgroup's chunk: normalised by the CMVN kernel below
     a.samples = d_samples;
     a.sample_off = sample_seg->dev.as<int64_t>();
     a.frame_off = frame_seg->dev.as<int64_t>();
@@ -310,6 +320,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
         SSP_TRY(launch_mfcc_fast(a, plan, plan->cache_n_chunks, plan->cache_chunk_frames, s));
     else
         SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, s));
+    if (plan->cache_split_cmvn) SSP_TRY(launch_cmvn(d_out, d_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->d_out, s));
     SSP_TRY(tm.stop(s, kernel_ms));
     SSP_TRY(sout.back(plan->ctx, feats_out, out_bytes, where));
     if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(s));

@@ -242,6 +242,22 @@ def test_inrepo_mfcc_any_frame_size(ssp, geom):
     assert b[1].shape == O.MFCC(synth_audio(4, 700, fs), fs, L, st).shape
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_cmvn_long_utterances(ssp, variant):
+    """extract_feature's CMVN on utterances longer than one workgroup can hold (20 s and 45 s next to a short one): the
+    features are computed chunked and normalised by the CMVN kernel in place; all three kernel choices against the oracle"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    sigs = [synth_audio(1, 16000 * 20 + 77, 16000), synth_audio(2, 16000 * 2, 16000), synth_audio(3, 16000 * 45, 16000)]
+    tables = pkg.preset_sidekit(delta_order=1, cmvn=1)
+    got, fseg = _run_plan(api, tables, sigs, variant=variant)
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=1, cmvn=1)
+    for u, s_ in enumerate(sigs):
+        ref = O.mfcc_pipeline(s_, cfg, w, fb, dct)
+        assert_feat_close(got[u], ref, tol=2e-4, what=f"long cmvn utt {u} variant {variant}")
+        assert abs(got[u].mean()) < 1e-4 and abs(got[u].std(0).mean() - 1) < 1e-3
+
+
 def test_fast_kernel_long_utterance_chunking(ssp):
     """utterances longer than one workgroup's LDS budget are cut into chunks with recomputed delta halos"""
     pkg, api = ssp
