@@ -164,8 +164,10 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
             float acc = 0.f;
             for (int i = 0; i < len; ++i) acc = fmaf(P[lo + i], w[i], acc);
             lm[j] = apply_log(a, acc);
+            if (a.lm_out && t >= t0 && t < t0 + n) a.lm_out[(size_t)(f0 + t) * a.n_filt + j] = lm[j];
         }
         wave_lds_sync();
+        if (a.lm_out) continue;  // two-pass top_db: the clamp needs the utterance maximum, the DCT follows in a second kernel
         // ---- DCT-II rows (skipped here when the utterance-level top_db clamp must come first)
         if (a.top_db < 0.f) {
             for (int q = lane; q < nc; q += 64) {
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
         wave_lds_sync();
     }
     __syncthreads();
+    if (a.lm_out) return;
 
     if (a.top_db >= 0.f) {  // whole utterance is in this chunk (host guarantees): max over all log-mel values
         float mx = -INFINITY;
@@ -270,6 +273,42 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
         if (a.cmvn) v = (v - stats[d]) * stats[D + d];
         out[i] = v;
     }
+}
+
+// one workgroup per utterance: max over its log-mel rows, clamp at max - top_db (librosa power_to_db over the WHOLE utterance),
+// DCT-II rows.  Any utterance length (global memory, no LDS rows).
+__global__ __launch_bounds__(256) void topdb_dct_kernel(const float* __restrict__ lm, const int64_t* __restrict__ off, int n_filt, int nc,
+                                                        const float* __restrict__ dct, float top_db, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t f0 = off[u];
+    const int64_t T = off[u + 1] - f0;
+    if (T == 0) return;
+    const float* __restrict__ x = lm + f0 * n_filt;
+    float mx = -INFINITY;
+    for (int64_t i = tid; i < T * n_filt; i += 256) mx = fmaxf(mx, x[i]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    const float thr = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - top_db;
+    for (int64_t i = tid; i < T * nc; i += 256) {
+        const int64_t r = i / nc;
+        const int q = (int)(i - r * nc);
+        const float* __restrict__ row = x + r * n_filt;
+        const float* __restrict__ drow = dct + (size_t)q * n_filt;
+        float acc = 0.f;
+        for (int j = 0; j < n_filt; ++j) acc = fmaf(fmaxf(row[j], thr), drow[j], acc);
+        out[(f0 + r) * nc + q] = acc;
+    }
+}
+
+int launch_topdb_dct(const float* logmel, const int64_t* frame_off_dev, int64_t n_utt, int n_filt, int n_ceps, const float* dct,
+                     float top_db, float* out, hipStream_t stream) {
+    if (n_utt <= 0) return SSP_OK;
+    if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "top_db: too many utterances");
+    hipLaunchKernelGGL(topdb_dct_kernel, dim3((unsigned)n_utt), dim3(256), 0, stream, logmel, frame_off_dev, n_filt, n_ceps, dct, top_db, out);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
 }
 
 int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, hipStream_t stream) {

@@ -17,6 +17,8 @@ struct MfccArgs {
     const int64_t* sample_off;  // [n_utt+1] device
     const int64_t* frame_off;   // [n_utt+1] device
     float* out;                 // [total_frames x d_out]
+    float* lm_out;              // non-null: the generic kernel only writes log-mel rows [total_frames x n_filt] here (first pass of
+                                // the two-pass top_db path for utterances longer than one workgroup's LDS)
     const MfccChunk* chunks;
     // tables (device)
     const float* window;    // [n_fft] zero padded
@@ -74,6 +76,10 @@ struct FastArgs {
 int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, hipStream_t stream);
 // per-utterance CMVN over a feature matrix in global memory (feat_ops.hip; in == out allowed), any utterance length
 int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, hipStream_t stream);
+// second pass of the two-pass top_db path: per-utterance max of the log-mel rows, clamp at max - top_db, DCT rows -> out [F x n_ceps]
+int launch_topdb_dct(const float* logmel, const int64_t* frame_off_dev, int64_t n_utt, int n_filt, int n_ceps, const float* dct,
+                     float top_db, float* out, hipStream_t stream);
+    
 
 }  // namespace ssp
 
@@ -88,6 +94,8 @@ struct ssp_mfcc_plan {
     uint64_t cache_fseg = 0;
     int cache_variant = -1;
     bool cache_split_cmvn = false;  // CMVN as a second kernel (an utterance exceeds one workgroup's chunk)
+    bool cache_split_topdb = false; // top_db as a second kernel (log-mel rows through a global scratch)
+    ssp::DevBuf lm_scratch;
     int cache_chunk_frames = 0;
     size_t cache_lds = 0;
     int32_t cache_n_chunks = 0;

@@ -68,6 +68,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     const ssp_mfcc_cfg& c = p->cfg;
     bool whole = c.cmvn || c.top_db >= 0.f;  // needs utterance-level statistics inside one workgroup
     bool split_cmvn = false;                 // utterances too long for that: features un-normalised, then the CMVN kernel in place
+    bool split_topdb = false;                // ... or log-mel rows through a global scratch, then the clamp + DCT kernel
     const int64_t max_T = fseg->max_len();
     const size_t lds_cap = 160 * 1024;
     int ch;
@@ -95,16 +96,31 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         if (whole) {
             ch = (int)std::max<int64_t>(max_T, 1);
             if (generic_lds_layout(c, ch, &tmp) > lds_cap) {
-                if (c.top_db >= 0.f)
-                    SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: top_db needs a whole utterance per workgroup; %lld frames exceed the 160 KiB LDS",
-                             (long long)max_T);
-                split_cmvn = true;
+                if (c.top_db >= 0.f) {
+                    if (c.delta_order != 0 || c.cmvn)
+                        SSP_FAIL(SSP_ERR_UNSUPPORTED,
+                                 "mfcc: top_db with deltas / cmvn needs a whole utterance per workgroup; %lld frames exceed the 160 KiB LDS",
+                                 (long long)max_T);
+                    split_topdb = true;
+                } else {
+                    split_cmvn = true;
+                }
                 whole = false;
                 ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
                 while (ch > 16 && generic_lds_layout(c, ch, &tmp) > 64 * 1024) ch = (ch * 3) / 4;
+                if (split_topdb) {  // the chunked first pass keeps no per-chunk log-mel rows: lay the LDS out as if top_db were off
+                    ssp_mfcc_cfg c2 = c;
+                    c2.top_db = -1.f;
+                    ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
+                    while (ch > 16 && generic_lds_layout(c2, ch, &tmp) > 64 * 1024) ch = (ch * 3) / 4;
+                }
             }
         }
-        lds = generic_lds_layout(c, ch, &p->args);
+        {
+            ssp_mfcc_cfg c2 = c;
+            if (split_topdb) c2.top_db = -1.f;
+            lds = generic_lds_layout(c2, ch, &p->args);
+        }
         if (lds > lds_cap) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: LDS footprint %zu B exceeds 160 KiB", lds);
     }
     std::vector<MfccChunk> chunks;
@@ -126,6 +142,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     p->cache_fseg = fseg->serial;
     p->cache_variant = variant;
     p->cache_split_cmvn = split_cmvn;
+    p->cache_split_topdb = split_topdb;
     return SSP_OK;
 }
 
@@ -309,6 +326,12 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
 
     MfccArgs a = plan->args;
     if (plan->cache_split_cmvn) a.cmvn = 0;  // utterances longer than one workgroup's chunk: normalised by the CMVN kernel below
+    a.lm_out = nullptr;
+    if (plan->cache_split_topdb && v == 1) {  // two-pass top_db: log-mel rows to a scratch, clamp + DCT in a second kernel
+        SSP_TRY(plan->lm_scratch.reserve((size_t)total_frames * plan->cfg.n_filt * sizeof(float)));
+        a.lm_out = plan->lm_scratch.as<float>();
+        a.top_db = -1.f;
+    }
     a.samples = d_samples;
     a.sample_off = sample_seg->dev.as<int64_t>();
     a.frame_off = frame_seg->dev.as<int64_t>();
@@ -320,6 +343,9 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
         SSP_TRY(launch_mfcc_fast(a, plan, plan->cache_n_chunks, plan->cache_chunk_frames, s));
     else
         SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, s));
+    if (a.lm_out)
+        SSP_TRY(launch_topdb_dct(a.lm_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->cfg.n_filt, plan->cfg.n_ceps, plan->dct.as<float>(),
+                                 plan->cfg.top_db, d_out, s));
     if (plan->cache_split_cmvn) SSP_TRY(launch_cmvn(d_out, d_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->d_out, s));
     SSP_TRY(tm.stop(s, kernel_ms));
     SSP_TRY(sout.back(plan->ctx, feats_out, out_bytes, where));

@@ -258,6 +258,20 @@ def test_cmvn_long_utterances(ssp, variant):
         assert abs(got[u].mean()) < 1e-4 and abs(got[u].std(0).mean() - 1) < 1e-3
 
 
+def test_librosa_long_utterance_two_pass_top_db(ssp):
+    """MFCC_lib on utterances longer than one workgroup's LDS (30 s and 70 s at 8 kHz next to a short one): log-mel rows go
+    through a global scratch and the utterance-wide top_db clamp + DCT run as a second kernel"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd import MFCC_DTW
+    sigs = [synth_audio(1, 8000 * 30 + 5, 8000), synth_audio(2, 8000 * 2, 8000), synth_audio(3, 8000 * 70, 8000)]
+    got, _ = _run_plan(api, pkg.preset_librosa(8000, 13), sigs, variant=0)
+    cfg, w, fb, dct = O.librosa_tables(8000, 13)
+    for u, s_ in enumerate(sigs):
+        assert_feat_close(got[u], O.mfcc_pipeline(s_, cfg, w, fb, dct), tol=2e-4, what=f"librosa long utt {u}")
+    assert_feat_close(MFCC_DTW.MFCC_lib(sigs[0]), O.librosa_mfcc_flat(sigs[0]), tol=2e-4, what="MFCC_lib long")
+
+
 def test_fast_kernel_long_utterance_chunking(ssp):
     """utterances longer than one workgroup's LDS budget are cut into chunks with recomputed delta halos"""
     pkg, api = ssp
