@@ -88,6 +88,20 @@ def test_fails_loudly_without_gpu():
     from speech_signal_processing_amd.utils import processing as P
     with pytest.raises(_lib.SspError):
         P.MFCC(np.zeros(1000, dtype=np.float32))
+    with pytest.raises(_lib.SspError):
+        P.MFCC(np.zeros(1000, dtype=np.float32), 8000, 400, 160)      # the any-frame-size path
+    from speech_signal_processing_amd import GMM_UBM, MFCC_DTW, d_vector
+    from speech_signal_processing_amd.gmm_train import GaussianMixture
+    with pytest.raises(_lib.SspError):
+        GaussianMixture(n_components=2).fit(np.zeros((10, 3), dtype=np.float32))   # EM training
+    with pytest.raises(_lib.SspError):
+        MFCC_DTW.distance_dtw(np.zeros(5), np.ones(7))                            # DTW matcher
+    with pytest.raises(_lib.SspError):
+        MFCC_DTW.generate_template([np.zeros(5), np.ones(7)])
+    with pytest.raises(_lib.SspError):
+        d_vector.cosine_scores(np.zeros((2, 4), np.float32), np.ones((3, 4), np.float32))
+    with pytest.raises(_lib.SspError):
+        GMM_UBM.delta(np.zeros((5, 3)))
 
 
 def test_frame_count_and_dim_helpers_need_no_gpu():
