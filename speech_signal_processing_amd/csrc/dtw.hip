@@ -127,6 +127,76 @@ __global__ __launch_bounds__(256) void dtw_kernel(DtwArgs a) {
 }
 
 
+// dim == 1 all-pairs matcher, tuned: the lane's previous row is updated in place (three scalars carry diagonal / left / new
+// value along the row), x[i + 1] is fetched one step ahead (the plain kernel stalls a full memory latency per step on x[i]),
+// columns past the end propagate the last valid value so that the lane's hand-over value is always prev[W - 1].
+template <int W>
+__global__ __launch_bounds__(256) void dtw1_kernel(DtwArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave_id >= a.n_pairs) return;
+    const int q = (int)(wave_id / a.n_t), p = (int)(wave_id - (int64_t)q * a.n_t);
+    const int r = (int)(a.q_off[q + 1] - a.q_off[q]), c = (int)(a.t_off[p + 1] - a.t_off[p]);
+    const float* __restrict__ x = a.xq + a.q_off[q];
+    const float* __restrict__ y = a.xt + a.t_off[p];
+    float* __restrict__ bnd = static_cast<float*>(a.bnd) + wave_id * a.max_r;
+    float result = INFINITY;
+    if (r > 0 && c > 0) {
+        for (int cb0 = 0; cb0 < c; cb0 += 64 * W) {
+            const int cb = min(64 * W, c - cb0);
+            const int lanes = (cb + W - 1) / W;
+            const int j0 = cb0 + lane * W;
+            const int nvalid = max(0, min(W, c - j0));  // this lane's columns inside the template
+            const bool more = cb0 + 64 * W < c;
+            float yreg[W], prev[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                yreg[k] = k < nvalid ? y[j0 + k] : 0.f;
+                prev[k] = INFINITY;  // row -1
+            }
+            float last = INFINITY, diagl = INFINITY;
+            float xnext = lane < lanes && r > 0 ? x[0] : 0.f;  // this lane starts with row 0 at step `lane`
+            for (int s = 0; s < r + lanes - 1; ++s) {
+                const int i = s - lane;
+                float left = __shfl_up(last, 1);
+                const bool act = i >= 0 && i < r && lane < lanes;
+                if (lane == 0) {
+                    if (cb0 == 0) {
+                        left = INFINITY;
+                        diagl = i == 0 ? 0.f : INFINITY;
+                    } else if (act) {
+                        left = __hip_atomic_load(&bnd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        diagl = i > 0 ? __hip_atomic_load(&bnd[i - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
+                    }
+                }
+                if (act) {
+                    const float xi = xnext;
+                    if (i + 1 < r) xnext = x[i + 1];  // in flight during this row's W cells
+                    float d = diagl, l = left;
+#pragma unroll
+                    for (int k = 0; k < W; ++k) {
+                        const float up = prev[k];
+                        const float v = fabsf(xi - yreg[k]) + fminf(d, fminf(up, l));
+                        d = up;
+                        l = k < nvalid ? v : l;  // past the end: carry the last valid value
+                        prev[k] = l;
+                    }
+                    diagl = left;
+                    last = l;
+                    if (lane == lanes - 1) {
+                        if (more) __hip_atomic_store(&bnd[i], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (i == r - 1 && !more) result = l;
+                    }
+                }
+            }
+            if (more) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        }
+    }
+    float v = result;
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    if (lane == 0) static_cast<float*>(a.out)[wave_id] = (a.normalize && r + c > 0) ? v / (float)(r + c) : v;
+}
+
 // the package's _traceback over D0 (= D1 with a +inf border and D0[0][0] = 0): from (r-1, c-1) back to (0, 0), at each step the
 // first minimum of (diagonal, up, left).  One thread; writes the path backwards into the END of path_i / path_j (capacity r + c)
 __global__ void dtw_traceback_kernel(const double* __restrict__ D1, int r, int c, int32_t* path_i, int32_t* path_j, int32_t* path_len) {
@@ -184,9 +254,10 @@ extern "C" int ssp_dtw_distances(ssp_ctx* ctx, const float* xq, const ssp_segmen
     SSP_TRY(rc);
     float* dout = (float*)so.out(dist_out, (size_t)n_pairs * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    // column block per lane: the smallest of {4, 8, 16, 32} that covers the longest template in one super-block, else 32
+    // column block per lane: the smallest of {4, 8, (12,) 16, (20, 24,) 32} that covers the longest template in one super-block, else 32
     const int need = (int)((max_c + 63) / 64);
-    const int W = need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 32;
+    int W = need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 32;
+    if (dim == 1) W = need <= 4 ? 4 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 16 ? 16 : need <= 20 ? 20 : need <= 24 ? 24 : 32;
     const bool multi = max_c > 64 * (int64_t)W;
     DevBuf bnd;
     SSP_TRY(bnd.alloc(multi ? (size_t)n_pairs * max_r * sizeof(float) : 16));
@@ -196,11 +267,23 @@ extern "C" int ssp_dtw_distances(ssp_ctx* ctx, const float* xq, const ssp_segmen
     if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_dtw_distances: too many pairs");
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, s));
-    switch (W) {
-        case 4: hipLaunchKernelGGL((dtw_kernel<4, float, false>), dim3((unsigned)grid), dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((dtw_kernel<8, float, false>), dim3((unsigned)grid), dim3(256), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((dtw_kernel<16, float, false>), dim3((unsigned)grid), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((dtw_kernel<32, float, false>), dim3((unsigned)grid), dim3(256), 0, s, a); break;
+    if (dim == 1) {
+        switch (W) {
+            case 4: hipLaunchKernelGGL(dtw1_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+            case 8: hipLaunchKernelGGL(dtw1_kernel<8>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+            case 12: hipLaunchKernelGGL(dtw1_kernel<12>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+            case 20: hipLaunchKernelGGL(dtw1_kernel<20>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+            case 24: hipLaunchKernelGGL(dtw1_kernel<24>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+            case 16: hipLaunchKernelGGL(dtw1_kernel<16>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL(dtw1_kernel<32>, dim3((unsigned)grid), dim3(256), 0, s, a); break;
+        }
+    } else {
+        switch (W) {
+            case 4: hipLaunchKernelGGL((dtw_kernel<4, float, false>), dim3((unsigned)grid), dim3(256), 0, s, a); break;
+            case 8: hipLaunchKernelGGL((dtw_kernel<8, float, false>), dim3((unsigned)grid), dim3(256), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((dtw_kernel<16, float, false>), dim3((unsigned)grid), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((dtw_kernel<32, float, false>), dim3((unsigned)grid), dim3(256), 0, s, a); break;
+        }
     }
     SSP_HIP(hipGetLastError());
     SSP_TRY(tm.stop(s, kernel_ms));
