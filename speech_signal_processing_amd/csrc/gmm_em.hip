@@ -179,14 +179,36 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
         for (int c = 0; c < NCT; ++c)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc2[r][c][i] = 0.f;
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.G) {
+    // the frame tile of the NEXT iteration is fetched into registers while this one's MFMAs run (a synchronous load would expose a
+    // full memory latency per 64-frame tile): EM_XP floats per thread cover 64 x D <= 64 x 47
+    constexpr int EM_XP = 12;
+    float xpre[EM_XP];
+    float lpre = INFINITY;
+    auto fetch = [&](int tile) {
         const int64_t base = (int64_t)tile * EM_TF;
-        const int nt = (int)min<int64_t>(EM_TF, a.n - base);
-        __syncthreads();  // the previous tile's GEMM2 is done with xs / rs
-        for (int i = tid; i < EM_TF * D; i += 256) {
-            const int r = i / D, c = i - r * D;
-            xs[r * XS + c] = r < nt ? a.x[(base + r) * D + c] : 0.f;
+        const int nt = tile < a.n_tiles ? (int)min<int64_t>(EM_TF, a.n - base) : 0;
+#pragma unroll
+        for (int u = 0; u < EM_XP; ++u) {
+            const int i = tid + u * 256;
+            const int r = i / D;
+            xpre[u] = (i < EM_TF * D && r < nt) ? a.x[base * D + i] : 0.f;
         }
+        const int fr = 32 * c1 + fl;
+        lpre = fr < nt ? a.lse[base + fr] : INFINITY;  // frames beyond the end: resp = exp(-inf) = 0
+    };
+    fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.G) {
+        __syncthreads();  // the previous tile's GEMM2 is done with xs / rs
+#pragma unroll
+        for (int u = 0; u < EM_XP; ++u) {
+            const int i = tid + u * 256;
+            if (i < EM_TF * D) {
+                const int r = i / D, c = i - r * D;
+                xs[r * XS + c] = xpre[u];
+            }
+        }
+        const float l = lpre;
+        fetch(tile + a.G);
         __syncthreads();
         // ---- GEMM1: A[row = mix 32 r1 + fl][k = 2 s + h], B[k = 2 s + h][col = frame 32 c1 + fl] = aug[frame][k]
         f32x16 acc1;
@@ -204,7 +226,6 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
         }
         // ---- responsibilities of this lane's frame; accumulator i = mixture 32 r1 + (i & 3) + 8 (i >> 2) + 4 h
         const int fr = 32 * c1 + fl;
-        const float l = fr < nt ? a.lse[base + fr] : INFINITY;  // frames beyond the end: resp = exp(-inf) = 0
 #pragma unroll
         for (int i = 0; i < 16; ++i) rs[fr * 65 + 32 * r1 + (i & 3) + 8 * (i >> 2) + 4 * h] = __expf(acc1[i] - l);
         __syncthreads();
