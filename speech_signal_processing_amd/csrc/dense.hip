@@ -25,31 +25,39 @@ struct DenseArgs {
     int32_t d_in, units, relu;
 };
 
-// stage a [128 x DBK] slab of a row-major matrix into the MFMA operand image [q=DBK/8][h=2][row=128][e=4]:
-// element (row, k = 8q + 2e + h)
-__device__ __forceinline__ void dense_stage(const float* __restrict__ A, int64_t row0, int64_t n_rows, int d, int k0,
-                                            float* __restrict__ img, int tid, bool vec) {
+// a [128 x DBK] slab of a row-major matrix goes global -> registers -> MFMA operand image [q=DBK/8][h=2] planes of [row=128][e=4]
+// (element (row, k = 8q + 2e + h)) in two steps: the loads of slab kc + 1 are issued before the MFMAs of slab kc and land under them
+__device__ __forceinline__ void dense_load(const float* __restrict__ A, int64_t row0, int64_t n_rows, int d, int k0, int tid,
+                                           bool vec, float4 (&v)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * 256;
         const int r = idx >> 3, c4 = idx & 7;
         const int64_t gr = row0 + r;
         const int k = k0 + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gr < n_rows) {
             const float* __restrict__ p = A + gr * d + k;
             if (vec && k + 3 < d) {
-                v = *reinterpret_cast<const float4*>(p);
+                v[i] = *reinterpret_cast<const float4*>(p);
             } else {
-                if (k < d) v.x = p[0];
-                if (k + 1 < d) v.y = p[1];
-                if (k + 2 < d) v.z = p[2];
-                if (k + 3 < d) v.w = p[3];
+                if (k < d) v[i].x = p[0];
+                if (k + 1 < d) v[i].y = p[1];
+                if (k + 2 < d) v[i].z = p[2];
+                if (k + 3 < d) v[i].w = p[3];
             }
         }
+    }
+}
+
+__device__ __forceinline__ void dense_store(float* __restrict__ img, int tid, const float4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;
+        const int r = idx >> 3, c4 = idx & 7;
         const int q = c4 >> 1, e0 = (c4 & 1) * 2;
-        *reinterpret_cast<float2*>(img + (size_t)(q * 2 + 0) * DPL + r * 4 + e0) = make_float2(v.x, v.z);
-        *reinterpret_cast<float2*>(img + (size_t)(q * 2 + 1) * DPL + r * 4 + e0) = make_float2(v.y, v.w);
+        *reinterpret_cast<float2*>(img + (size_t)(q * 2 + 0) * DPL + r * 4 + e0) = make_float2(v[i].x, v[i].z);
+        *reinterpret_cast<float2*>(img + (size_t)(q * 2 + 1) * DPL + r * 4 + e0) = make_float2(v[i].y, v[i].w);
     }
 }
 
@@ -75,11 +83,18 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+        float4 va[4], vb[4];
+        dense_load(a.Wt, (int64_t)rb * DBM, a.units, d, 0, tid, vec, va);
+        dense_load(a.X, col0, a.N, d, 0, tid, vec, vb);
         for (int kc = 0; kc < n_kc; ++kc) {
+            __syncthreads();  // the previous slab is consumed
+            dense_store(imgA, tid, va);
+            dense_store(imgB, tid, vb);
             __syncthreads();
-            dense_stage(a.Wt, (int64_t)rb * DBM, a.units, d, kc * DBK, imgA, tid, vec);
-            dense_stage(a.X, col0, a.N, d, kc * DBK, imgB, tid, vec);
-            __syncthreads();
+            if (kc + 1 < n_kc) {  // next slab: in flight during this slab's MFMAs (one LDS buffer: occupancy stays)
+                dense_load(a.Wt, (int64_t)rb * DBM, a.units, d, (kc + 1) * DBK, tid, vec, va);
+                dense_load(a.X, col0, a.N, d, (kc + 1) * DBK, tid, vec, vb);
+            }
 #pragma unroll
             for (int q = 0; q < DBK / 8; ++q) {
                 f32x4 av[2], bv[2];
