@@ -6,10 +6,14 @@
 // sklearn.preprocessing.scale (GMM_UBM.py:93).
 //
 // Two kernels:
-//   mfcc_generic_kernel  — table driven, any power-of-two n_fft <= 2048, every cfg knob. One wave per frame,
-//                          radix-4 Stockham FFT through wave-private LDS.
+//   mfcc_generic_kernel  — table driven, any power-of-two n_fft <= 2048, every cfg knob. One wave per frame, Stockham FFT
+//                          with radix-16 / 8 / 4 passes in registers over ONE wave-private (in-place, padded) LDS buffer.
 //   mfcc_fused512_kernel — (mfcc_fast.hip) the throughput kernel for n_fft == 512.
+#include <algorithm>
+#include <cstdlib>
+
 #include "mfcc.hpp"
+#include "cplx.hpp"
 
 namespace ssp {
 
@@ -19,8 +23,61 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+struct __attribute__((packed, aligned(4))) f4u {
+    float x, y, z, w;
+};
+
+// One wave keeps its frame's M complex points in ONE wave-private LDS buffer, element i at i + (i >> 4) (one pad slot per 16: the
+// stride-R scatters of the Stockham passes stay spread over the banks).  A pass reads everything it needs into registers, then
+// writes in place.
+__host__ __device__ constexpr int zpad(int i) { return i + (i >> 4); }
+
+// points per lane and FFT pass: 16 for n_fft 2048 (passes 16, 16, 4), 8 for 1024 (8, 8, 8), 4 below (4, ..., then 2 if needed)
+__host__ __device__ constexpr int fft_points_per_lane(int n_fft) { return n_fft >= 2048 ? 16 : (n_fft >= 1024 ? 8 : 4); }
+
+// Stockham autosort pass of radix R: butterfly j < M/R takes in[j + m M/R] W_{R Ns}^{m k} (k = j mod Ns) and leaves its DFT_R at
+// (j - k) R + k + r Ns.  A lane owns E/R butterflies (E points).  FIRST: the input is the unpadded windowed frame, no twiddles.
+template <int NFFT, int R, int NS, bool FIRST>
+__device__ __forceinline__ void fft_pass(v2f* buf, const v2f* tw, int lane) {
+    constexpr int M = NFFT / 2, E = fft_points_per_lane(NFFT), NB = E / R, nb = M / R, active = M / E;
+    constexpr int tstride = NFFT / (R * NS);
+    v2f v[NB][R];
+    if (active >= 64 || lane < active) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int j = lane + b * active;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[b][r] = FIRST ? buf[j + r * nb] : buf[zpad(j + r * nb)];
+            if (!FIRST) {
+                const int kt = (j & (NS - 1)) * tstride;
+#pragma unroll
+                for (int r = 1; r < R; ++r) v[b][r] = cmul(v[b][r], tw[r * kt]);
+            }
+            fft_small<R>(v[b]);
+        }
+    }
+    wave_lds_sync();
+    if (active >= 64 || lane < active) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int j = lane + b * active;
+            const int k = j & (NS - 1);
+            const int d = (j - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) buf[zpad(d + r * NS)] = v[b][r];
+        }
+    }
+    wave_lds_sync();
+}
+
+template <int NFFT, int NS>
+__device__ __forceinline__ void fft_rest(v2f* buf, const v2f* tw, int lane) {
+    constexpr int M = NFFT / 2, E = fft_points_per_lane(NFFT);
+    if constexpr (NS < M) {
+        constexpr int R = M / NS >= E ? E : M / NS;
+        fft_pass<NFFT, R, NS, false>(buf, tw, lane);
+        fft_rest<NFFT, NS * R>(buf, tw, lane);
+    }
 }
 
 // sample i of frame t (frame-local index), before pre-emphasis / window
@@ -45,24 +102,72 @@ __device__ __forceinline__ float apply_log(const MfccArgs& a, float v) {
     return 10.0f * log10f(v);
 }
 
-__global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int M = a.n_fft >> 1;
-    const int nc = a.n_ceps;
+#ifdef SSP_GSTAMP
+// Diagnostic build only (never shipped): per-phase cycle accounting with s_memtime stamps.
+__device__ unsigned long long g_gstamps[16];
+#define GSTAMP(ph)                                                                                  \
+    {                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        unsigned long long t_;                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        st_acc[ph] += t_ - st_last;                                                                 \
+        st_last = t_;                                                                               \
+    }
+#else
+#define GSTAMP(ph)
+#endif
 
-    float2* fftbuf = reinterpret_cast<float2*>(smem) + (size_t)wave * 2 * M;  // [2][M] per wave
+template <int NFFT>
+__global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = NFFT / 2, E = fft_points_per_lane(NFFT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = blockDim.x, nw = nt >> 6;
+    const int nc = a.n_ceps;
+#ifdef SSP_GSTAMP
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+
+    v2f* buf = reinterpret_cast<v2f*>(smem) + (size_t)wave * (M + (M >> 4));  // wave-private, M padded complex points
     float* logmel = reinterpret_cast<float*>(smem + a.lds_logmel_off) + wave * a.n_filt;
     float* ceps = reinterpret_cast<float*>(smem + a.lds_ceps_off);
     float* dlt = reinterpret_cast<float*>(smem + a.lds_dlt_off);
     float* ddl = reinterpret_cast<float*>(smem + a.lds_ddl_off);
     float* lmrows = reinterpret_cast<float*>(smem + a.lds_lmrows_off);
-    float* stats = reinterpret_cast<float*>(smem + a.lds_stats_off);  // [2][d_out] mean, inv std; [256] reduce scratch
-    // twiddles W_nfft^k, k < n_fft, in LDS: the FFT passes would otherwise wait on 3 dependent global loads per butterfly
-    float2* tw = reinterpret_cast<float2*>(smem + a.lds_tw_off);
-    for (int i = tid; i < a.n_fft; i += 256) tw[i] = a.twiddle[i];
+    float* stats = reinterpret_cast<float*>(smem + a.lds_stats_off);  // [2][d_out] mean, inv std; [8] reduce scratch
+    // tables staged in LDS: twiddles W_nfft^k (k < n_fft) and, when they fit, the transposed DCT matrix and the filter taps
+    v2f* tw = reinterpret_cast<v2f*>(smem + a.lds_tw_off);
+    for (int i = tid; i < NFFT; i += nt) tw[i] = reinterpret_cast<const v2f*>(a.twiddle)[i];
+    // DCT matrix: transposed [n_filt][n_ceps] for the per-frame product; [n_ceps][n_filt4] (rows zero padded to a multiple of 4) for
+    // the clamped product over a whole utterance's log-mel rows (top_db)
+    float* dct_lds = reinterpret_cast<float*>(smem + (a.lds_dct_off >= 0 ? a.lds_dct_off : 0));
+    const int n_filt4 = (a.n_filt + 3) & ~3;
+    if (a.lds_dct_off >= 0) {
+        if (a.top_db >= 0.f) {
+            for (int i = tid; i < nc * n_filt4; i += nt) {
+                const int q = i / n_filt4, j = i - q * n_filt4;
+                dct_lds[i] = j < a.n_filt ? a.dct[q * a.n_filt + j] : 0.f;
+            }
+        } else {
+            for (int i = tid; i < a.n_filt * nc; i += nt) dct_lds[i] = a.dctT[i];
+        }
+    }
+    v4f* wt_lds = reinterpret_cast<v4f*>(smem + (a.lds_wt_off >= 0 ? a.lds_wt_off : 0));
+    if (a.lds_wt_off >= 0)
+        for (int i = tid; i < a.filt_w4_total; i += nt) wt_lds[i] = reinterpret_cast<const v4f*>(a.filt_wT)[i];
     __syncthreads();
 
+    // this lane's filters in the first two groups of 64 (later groups reload theirs per frame): first bin rounded down to 4
+    const int lo_0 = lane < a.n_filt ? a.filt_lo4[lane] : 0, lo_1 = lane + 64 < a.n_filt ? a.filt_lo4[lane + 64] : 0;
+    const int gs_0 = a.filt_grp[0], gs_1 = a.filt_grp[1], go_0 = a.filt_grp[8], go_1 = a.filt_grp[9];
+    // DCT: lanes = (coefficient, part of the filter range); parts are summed by xor shuffles
+    const int ncp = a.dct_ncp, dparts = 64 / ncp, dpart = lane / ncp, dq = lane & (ncp - 1);
+
+    const bool pre = a.preemph_mode == 1;
+    // one chunk per workgroup (persistent workgroups looping over chunks measured 20 % slower: the hardware dispatcher balances better
+    // than a static stride, and the loop cost registers)
     const MfccChunk ch = a.chunks[blockIdx.x];
     const int64_t s0 = a.sample_off[ch.utt];
     const int64_t N = a.sample_off[ch.utt + 1] - s0;
@@ -72,133 +177,227 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
     const int t0 = ch.t0, n = ch.n;
     const int H = a.delta_order * a.delta_N;
     const int ta = max(t0 - H, 0), tb = min(t0 + n + H, T);  // cepstra rows kept in LDS
-
-    for (int t = ta + wave; t < tb; t += 4) {
-        // ---- frame -> complex sequence z[m] = (y[2m], y[2m+1]), windowed, zero padded to n_fft
-        float2* in = fftbuf;
-        float2* outb = fftbuf + M;
-        for (int m = lane; m < M; m += 64) {
-            const int i0 = 2 * m;
-            float v0 = 0.f, v1 = 0.f;
-            if (i0 < a.win_len) {
-                const float xm1 = frame_sample(a, x, N, t, i0 > 0 ? i0 - 1 : 0);
-                const float x0 = frame_sample(a, x, N, t, i0);
-                const float x1 = (i0 + 1 < a.win_len) ? frame_sample(a, x, N, t, i0 + 1) : 0.f;
-                if (a.preemph_mode == 1) {
-                    v0 = x0 - a.preemph * xm1;
-                    v1 = x1 - a.preemph * x0;
-                } else {
-                    v0 = x0;
-                    v1 = x1;
+    GSTAMP(5)
+    for (int t = ta + wave; t < tb; t += nw) {
+        // ---- frame -> y[i] = (x[i] - p x[i-1]) w[i] (zero beyond win_len), unpadded floats over the wave buffer.  x[i-1] of a
+        // lane's first sample comes from the neighbouring lane (lane 0: lane 63 of the previous sweep; i = 0: itself)
+        float* yb = reinterpret_cast<float*>(buf);
+        float carry = 0.f;
+        const int64_t g0 = (int64_t)t * a.hop - (a.frame_mode == 2 ? M : 0);
+        if (NFFT >= 256 && g0 >= 0 && g0 + NFFT <= N) {
+            // interior frame: 4 consecutive samples per lane and sweep, every load of the frame in flight together
+            constexpr int NSW = NFFT >= 256 ? NFFT / 256 : 1;
+            const float* __restrict__ xp = x + g0 + 4 * lane;
+            const float* __restrict__ wp = a.window + 4 * lane;
+            f4u xv[NSW];
+            v4f wv[NSW];
+#pragma unroll
+            for (int s = 0; s < NSW; ++s) {
+                xv[s] = *reinterpret_cast<const f4u*>(xp + 256 * s);
+                wv[s] = *reinterpret_cast<const v4f*>(wp + 256 * s);
+            }
+            GSTAMP(8)
+#pragma unroll
+            for (int s = 0; s < NSW; ++s) {
+                const int i = 4 * lane + 256 * s;
+                v4f xs = {xv[s].x, xv[s].y, xv[s].z, xv[s].w};
+                if (i + 3 >= a.win_len) {
+                    xs.x = i < a.win_len ? xs.x : 0.f;
+                    xs.y = i + 1 < a.win_len ? xs.y : 0.f;
+                    xs.z = i + 2 < a.win_len ? xs.z : 0.f;
+                    xs.w = 0.f;
                 }
-                v0 *= a.window[i0];
-                v1 = (i0 + 1 < a.win_len) ? v1 * a.window[i0 + 1] : 0.f;
+                float prev = __shfl_up(xs.w, 1);
+                if (lane == 0) prev = s == 0 ? xs.x : carry;
+                carry = __shfl(xs.w, 63);
+                v4f y = xs;
+                if (pre) y = xs - a.preemph * v4f{prev, xs.x, xs.y, xs.z};
+                *reinterpret_cast<v4f*>(yb + i) = y * wv[s];
             }
-            in[m] = make_float2(v0, v1);
-        }
-        wave_lds_sync();
-        // ---- M-point complex FFT, Stockham autosort, radix 4 (+ one radix-2 pass if log2(M) is odd)
-        int Ns = 1;
-        for (; Ns * 4 <= M; Ns *= 4) {
-            const int q = M >> 2;
-            const int tstride = M / (2 * Ns);  // W_{4Ns}^{k} = W_nfft^{k * nfft/(4Ns)}
-            for (int j = lane; j < q; j += 64) {
-                const int k = j & (Ns - 1);
-                float2 v0 = in[j], v1 = in[j + q], v2 = in[j + 2 * q], v3 = in[j + 3 * q];
-                if (Ns > 1) {
-                    v1 = cmul(v1, tw[k * tstride]);
-                    v2 = cmul(v2, tw[2 * k * tstride]);
-                    v3 = cmul(v3, tw[3 * k * tstride]);
+        } else {
+            for (int i0 = lane; i0 < NFFT; i0 += 512) {  // 8 sweeps at a time: their loads are all in flight together
+                float xv[8], wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 64 * u;
+                    xv[u] = i < a.win_len ? frame_sample(a, x, N, t, i) : 0.f;
+                    wv[u] = i < NFFT ? a.window[i] : 0.f;
                 }
-                const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-                const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-                const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-                const float2 a3 = make_float2(v1.y - v3.y, -(v1.x - v3.x));  // -i * (v1 - v3)
-                const int d = ((j - k) << 2) + k;
-                outb[d] = make_float2(a0.x + a2.x, a0.y + a2.y);
-                outb[d + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
-                outb[d + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
-                outb[d + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 64 * u;
+                    float prev = __shfl_up(xv[u], 1);
+                    if (lane == 0) prev = i == 0 ? xv[u] : carry;
+                    carry = __shfl(xv[u], 63);
+                    if (i < NFFT) yb[i] = (pre ? xv[u] - a.preemph * prev : xv[u]) * wv[u];
+                }
             }
-            wave_lds_sync();
-            float2* tmp = in;
-            in = outb;
-            outb = tmp;
-        }
-        if (Ns < M) {  // one radix-2 pass, Ns == M/2
-            const int h = M >> 1;
-            const int tstride = M / Ns;  // W_{2Ns}^k = W_nfft^{k * nfft/(2Ns)}
-            for (int j = lane; j < h; j += 64) {
-                const int k = j & (Ns - 1);
-                const float2 v0 = in[j];
-                const float2 v1 = cmul(in[j + h], tw[k * tstride]);
-                const int d = ((j - k) << 1) + k;
-                outb[d] = make_float2(v0.x + v1.x, v0.y + v1.y);
-                outb[d + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
-            }
-            wave_lds_sync();
-            float2* tmp = in;
-            in = outb;
-            outb = tmp;
-        }
-        // ---- real-FFT split + magnitude / power: bins 0..M from Z = in[]
-        float* P = reinterpret_cast<float*>(outb);
-        for (int k = lane; k <= M; k += 64) {
-            const float2 zk = in[k & (M - 1)];
-            const float2 zm = in[(M - k) & (M - 1)];
-            const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);   // E = (Z[k] + conj Z[M-k]) / 2
-            const float dr = 0.5f * (zk.x - zm.x), di = 0.5f * (zk.y + zm.y);   // D = (Z[k] - conj Z[M-k]) / 2
-            const float2 w = tw[k];                                              // W_nfft^k
-            const float2 o = cmul(make_float2(di, -dr), w);                     // (-i D) W^k
-            const float re = er + o.x, im = ei + o.y;
-            float p = re * re + im * im;
-            if (a.spec_power == 1) p = sqrtf(p);
-            P[k] = p * a.spec_scale;
         }
         wave_lds_sync();
-        // ---- banded filterbank + log
-        float* lm = a.top_db >= 0.f ? lmrows + (size_t)(t - ta) * a.n_filt : logmel;
-        for (int j = lane; j < a.n_filt; j += 64) {
-            const int lo = a.filt_lo[j], len = a.filt_len[j];
-            const float* __restrict__ w = a.filt_w + a.filt_ofs[j];
-            float acc = 0.f;
-            for (int i = 0; i < len; ++i) acc = fmaf(P[lo + i], w[i], acc);
-            lm[j] = apply_log(a, acc);
-            if (a.lm_out && t >= t0 && t < t0 + n) a.lm_out[(size_t)(f0 + t) * a.n_filt + j] = lm[j];
+        GSTAMP(0)
+        // touch the cache lines of this wave's NEXT frame (one dword per 128-byte line and lane): its staging loads then hit the
+        // L2 instead of waiting microseconds on HBM with nothing else to run
+        float touch0 = 0.f, touch1 = 0.f;
+        if (a.prefetch && t + nw < tb) {
+            const int64_t gn = (int64_t)(t + nw) * a.hop - (a.frame_mode == 2 ? M : 0);
+            const int64_t gl = gn + 32 * min(lane, NFFT / 32), ge = gn + NFFT - 1;
+            touch0 = x[max((int64_t)0, min(gl, N - 1))];
+            touch1 = x[max((int64_t)0, min(ge, N - 1))];
+        }
+        // ---- M-point complex FFT of z[m] = (y[2m], y[2m+1])
+        fft_pass<NFFT, (E < M ? E : M), 1, true>(buf, tw, lane);
+        fft_rest<NFFT, (E < M ? E : M)>(buf, tw, lane);
+        GSTAMP(1)
+        // ---- real-FFT split + magnitude / power.  Bins k and M - k come from the same pair: with E = (Z[k] + conj Z[M-k]) / 2,
+        // D = (Z[k] - conj Z[M-k]) / 2 and o = (-i D) W^k:  X[k] = E + o,  X[M-k] = conj(E - o).  Into registers, then P[0..M] as
+        // unpadded floats over the same buffer.
+        constexpr int NSP = (M / 2 + 1 + 63) / 64;
+        float pa[NSP], pb[NSP];
+#pragma unroll
+        for (int i = 0; i < NSP; ++i) {
+            const int k = lane + 64 * i;
+            pa[i] = pb[i] = 0.f;
+            if (k <= M / 2) {
+                const v2f zk = buf[zpad(k)];
+                const v2f zm = buf[zpad((M - k) & (M - 1))];
+                const v2f hz = zk * 0.5f;
+                const v2f e = __builtin_elementwise_fma(zm, v2f{0.5f, -0.5f}, hz);
+                const v2f d = __builtin_elementwise_fma(zm, v2f{-0.5f, 0.5f}, hz);
+                const v2f o = cmul_negi(d, tw[k]);
+                const v2f xa = e + o, xb = e - o;
+                float p0 = xa.x * xa.x + xa.y * xa.y, p1 = xb.x * xb.x + xb.y * xb.y;
+                if (a.spec_power == 1) {
+                    p0 = sqrtf(p0);
+                    p1 = sqrtf(p1);
+                }
+                pa[i] = p0 * a.spec_scale;
+                pb[i] = p1 * a.spec_scale;
+            }
         }
         wave_lds_sync();
-        if (a.lm_out) continue;  // two-pass top_db: the clamp needs the utterance maximum, the DCT follows in a second kernel
+        float* P = reinterpret_cast<float*>(buf);
+#pragma unroll
+        for (int i = 0; i < NSP; ++i) {
+            const int k = lane + 64 * i;
+            if (k <= M / 2) {
+                P[k] = pa[i];
+                P[M - k] = pb[i];
+            }
+        }
+        wave_lds_sync();
+        GSTAMP(2)
+        // ---- banded filterbank + log: a lane per filter, 64 filters at a time, four taps per 16-byte read; the taps of a group
+        // come from a transposed, zero-padded table (a filter's reads start at its first bin rounded down to 4 and may run past
+        // bin M into stale, finite buffer contents under zero weights)
+        float* lm = a.top_db >= 0.f ? lmrows + (size_t)(t - ta) * a.lm_stride : logmel;
+        auto filterbank = [&](const v4f* wtab) {
+            for (int g = 0; g * 64 < a.n_filt; ++g) {
+                const int j = g * 64 + lane;
+                const bool valid = j < a.n_filt;
+                const int lo = g == 0 ? lo_0 : (g == 1 ? lo_1 : (valid ? a.filt_lo4[j] : 0));
+                const int nstep = g == 0 ? gs_0 : (g == 1 ? gs_1 : a.filt_grp[g]);  // 16-byte steps, even
+                const v4f* wt = wtab + (g == 0 ? go_0 : (g == 1 ? go_1 : a.filt_grp[8 + g])) + lane;
+                const float* pp = P + lo;
+                v4f acc = {0.f, 0.f, 0.f, 0.f};
+                for (int st = 0; st < nstep; st += 2) {
+                    const v4f w0 = wt[st * 64], w1 = wt[st * 64 + 64];
+                    const v4f p0 = *reinterpret_cast<const v4f*>(pp + 4 * st), p1 = *reinterpret_cast<const v4f*>(pp + 4 * st + 4);
+                    acc = __builtin_elementwise_fma(p0, w0, acc);
+                    acc = __builtin_elementwise_fma(p1, w1, acc);
+                }
+                if (valid) {
+                    const float v = apply_log(a, (acc.x + acc.y) + (acc.z + acc.w));
+                    lm[j] = v;
+                    if (a.lm_out && t >= t0 && t < t0 + n) a.lm_out[(size_t)(f0 + t) * a.n_filt + j] = v;
+                }
+            }
+        };
+        if (a.lds_wt_off >= 0) filterbank(wt_lds);
+        else filterbank(reinterpret_cast<const v4f*>(a.filt_wT));
+        if (a.top_db >= 0.f && a.n_filt + lane < n_filt4) lm[a.n_filt + lane] = 0.f;  // rows are read 16 bytes at a time below
+        wave_lds_sync();
+        GSTAMP(3)
+        if (a.lm_out) {  // two-pass top_db: the clamp needs the utterance maximum, the DCT follows in a second kernel
+            asm volatile("" ::"v"(touch0), "v"(touch1));
+            continue;
+        }
         // ---- DCT-II rows (skipped here when the utterance-level top_db clamp must come first)
         if (a.top_db < 0.f) {
-            for (int q = lane; q < nc; q += 64) {
-                const float* __restrict__ drow = a.dct + (size_t)q * a.n_filt;
-                float acc = 0.f;
-                for (int j = 0; j < a.n_filt; ++j) acc = fmaf(lm[j], drow[j], acc);
-                ceps[(size_t)(t - ta) * nc + q] = acc;
-            }
+            auto dct_rows = [&](const float* tbl) {
+                for (int q0 = 0; q0 < nc; q0 += ncp) {
+                    const int q = q0 + dq;
+                    const float* tq = tbl + (q < nc ? q : 0);
+                    float acc = 0.f;
+                    int j = dpart;
+                    for (; j + 3 * dparts < a.n_filt; j += 4 * dparts) {
+                        const float l0 = lm[j], l1 = lm[j + dparts], l2 = lm[j + 2 * dparts], l3 = lm[j + 3 * dparts];
+                        const float c0 = tq[j * nc], c1 = tq[(j + dparts) * nc], c2 = tq[(j + 2 * dparts) * nc], c3 = tq[(j + 3 * dparts) * nc];
+                        acc = fmaf(l0, c0, acc);
+                        acc = fmaf(l1, c1, acc);
+                        acc = fmaf(l2, c2, acc);
+                        acc = fmaf(l3, c3, acc);
+                    }
+                    for (; j < a.n_filt; j += dparts) acc = fmaf(lm[j], tq[j * nc], acc);
+                    for (int o = ncp; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+                    if (q < nc && dpart == 0) ceps[(size_t)(t - ta) * nc + q] = acc;
+                }
+            };
+            if (a.lds_dct_off >= 0) dct_rows(dct_lds);
+            else dct_rows(a.dctT);
         }
         wave_lds_sync();
+        asm volatile("" ::"v"(touch0), "v"(touch1));
+        GSTAMP(4)
     }
     __syncthreads();
+    GSTAMP(6)
     if (a.lm_out) return;
 
     if (a.top_db >= 0.f) {  // whole utterance is in this chunk (host guarantees): max over all log-mel values
         float mx = -INFINITY;
-        const int tot = (tb - ta) * a.n_filt;
-        for (int i = tid; i < tot; i += 256) mx = fmaxf(mx, lmrows[i]);
+        const int rows = tb - ta;
+        for (int i = tid; i < rows * a.n_filt; i += nt) {
+            const int r = i / a.n_filt;
+            mx = fmaxf(mx, lmrows[(size_t)r * a.lm_stride + (i - r * a.n_filt)]);
+        }
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float* red = stats + 2 * a.d_out;
         if (lane == 0) red[wave] = mx;
         __syncthreads();
-        const float thr = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - a.top_db;
-        for (int i = tid; i < (tb - ta) * nc; i += 256) {
-            const int r = i / nc, q = i - r * nc;
-            const float* __restrict__ drow = a.dct + (size_t)q * a.n_filt;
-            const float* lm = lmrows + (size_t)r * a.n_filt;
-            float acc = 0.f;
-            for (int j = 0; j < a.n_filt; ++j) acc = fmaf(fmaxf(lm[j], thr), drow[j], acc);
-            ceps[i] = acc;
-        }
+        float thr = red[0];
+        for (int w = 1; w < nw; ++w) thr = fmaxf(thr, red[w]);
+        thr -= a.top_db;
+        // consecutive lanes take consecutive rows (stride 4 x odd floats: conflict-free 16-byte reads) of two coefficients, whose
+        // DCT rows are broadcast reads
+        auto dct_clamped4 = [&](const float* tbl) {
+            const int nq2 = (nc + 1) >> 1;
+            for (int i = tid; i < rows * nq2; i += nt) {
+                const int qb = i / rows, r = i - qb * rows;
+                const int q0 = 2 * qb, q1 = min(q0 + 1, nc - 1);
+                const float* lm = lmrows + (size_t)r * a.lm_stride;
+                const float *d0 = tbl + q0 * n_filt4, *d1 = tbl + q1 * n_filt4;
+                v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < n_filt4; j += 4) {
+                    v4f l = *reinterpret_cast<const v4f*>(lm + j);
+                    l = v4f{fmaxf(l.x, thr), fmaxf(l.y, thr), fmaxf(l.z, thr), fmaxf(l.w, thr)};
+                    acc0 = __builtin_elementwise_fma(l, *reinterpret_cast<const v4f*>(d0 + j), acc0);
+                    acc1 = __builtin_elementwise_fma(l, *reinterpret_cast<const v4f*>(d1 + j), acc1);
+                }
+                ceps[(size_t)r * nc + q0] = (acc0.x + acc0.y) + (acc0.z + acc0.w);
+                if (q0 + 1 < nc) ceps[(size_t)r * nc + q1] = (acc1.x + acc1.y) + (acc1.z + acc1.w);
+            }
+        };
+        auto dct_clamped = [&](const float* tbl) {  // table in global memory, transposed [n_filt][n_ceps]
+            for (int i = tid; i < rows * nc; i += nt) {
+                const int q = i / rows, r = i - q * rows;
+                const float* lm = lmrows + (size_t)r * a.lm_stride;
+                float acc = 0.f;
+                for (int j = 0; j < a.n_filt; ++j) acc = fmaf(fmaxf(lm[j], thr), tbl[j * nc + q], acc);
+                ceps[(size_t)r * nc + q] = acc;
+            }
+        };
+        if (a.lds_dct_off >= 0) dct_clamped4(dct_lds);
+        else dct_clamped(a.dctT);
         __syncthreads();
     }
 
@@ -210,7 +409,7 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
         const int ext = (a.delta_order - 1) * Nd;
         da = max(t0 - ext, 0);
         db = min(t0 + n + ext, T);
-        for (int i = tid; i < (db - da) * nc; i += 256) {
+        for (int i = tid; i < (db - da) * nc; i += nt) {
             const int r = i / nc, q = i - r * nc;
             const int u = da + r;
             float acc = 0.f;
@@ -223,7 +422,7 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
         __syncthreads();
     }
     if (a.delta_order >= 2) {
-        for (int i = tid; i < n * nc; i += 256) {
+        for (int i = tid; i < n * nc; i += nt) {
             const int r = i / nc, q = i - r * nc;
             const int u = t0 + r;
             float acc = 0.f;
@@ -245,7 +444,7 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
     };
 
     if (a.cmvn) {  // per-utterance, per-dimension (x - mean) / std, ddof = 0, std < 10 eps -> 1 (sklearn scale)
-        for (int d = wave; d < D; d += 4) {
+        for (int d = wave; d < D; d += nw) {
             float s = 0.f;
             for (int r = lane; r < n; r += 64) s += value(r, d);
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -267,12 +466,18 @@ __global__ __launch_bounds__(256) void mfcc_generic_kernel(MfccArgs a) {
     }
 
     float* __restrict__ out = a.out + (size_t)(f0 + t0) * D;
-    for (int i = tid; i < n * D; i += 256) {
+    for (int i = tid; i < n * D; i += nt) {
         const int r = i / D, d = i - r * D;
         float v = value(r, d);
         if (a.cmvn) v = (v - stats[d]) * stats[D + d];
         out[i] = v;
     }
+    GSTAMP(7)
+#ifdef SSP_GSTAMP
+    if (lane == 0)
+        for (int i = 0; i < 10; ++i) atomicAdd(&g_gstamps[i], st_acc[i]);
+    if (tid == 0) atomicAdd(&g_gstamps[15], (unsigned long long)nw);
+#endif
 }
 
 // one workgroup per utterance: max over its log-mel rows, clamp at max - top_db (librosa power_to_db over the WHOLE utterance),
@@ -311,15 +516,41 @@ int launch_topdb_dct(const float* logmel, const int64_t* frame_off_dev, int64_t 
     return SSP_OK;
 }
 
-int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, hipStream_t stream) {
-    if (n_chunks <= 0) return SSP_OK;
-    if (lds_bytes > 64 * 1024) {
-        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_generic_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    }
-    hipLaunchKernelGGL(mfcc_generic_kernel, dim3(n_chunks), dim3(256), lds_bytes, stream, args);
+template <int NFFT>
+static int launch_generic_n(MfccArgs args, int n_chunks, size_t lds_bytes, int n_waves, int num_cu, hipStream_t stream) {
+    const void* kfn = reinterpret_cast<const void*>(mfcc_generic_kernel<NFFT>);
+    if (lds_bytes > 64 * 1024) SSP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    (void)num_cu;
+    args.n_chunks = n_chunks;
+    args.prefetch = 1;
+    hipLaunchKernelGGL((mfcc_generic_kernel<NFFT>), dim3(n_chunks), dim3(64 * n_waves), lds_bytes, stream, args);
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }
 
+int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, int n_waves, int num_cu, hipStream_t stream) {
+    if (n_chunks <= 0) return SSP_OK;
+    if (n_waves != 4 && n_waves != 8) SSP_FAIL(SSP_ERR_INVALID, "mfcc: %d waves per workgroup", n_waves);
+    switch (args.n_fft) {
+        case 64: return launch_generic_n<64>(args, n_chunks, lds_bytes, n_waves, num_cu, stream);
+        case 128: return launch_generic_n<128>(args, n_chunks, lds_bytes, n_waves, num_cu, stream);
+        case 256: return launch_generic_n<256>(args, n_chunks, lds_bytes, n_waves, num_cu, stream);
+        case 512: return launch_generic_n<512>(args, n_chunks, lds_bytes, n_waves, num_cu, stream);
+        case 1024: return launch_generic_n<1024>(args, n_chunks, lds_bytes, n_waves, num_cu, stream);
+        case 2048: return launch_generic_n<2048>(args, n_chunks, lds_bytes, n_waves, num_cu, stream);
+    }
+    SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: n_fft=%d", args.n_fft);
+}
+
 }  // namespace ssp
+
+#ifdef SSP_GSTAMP
+extern "C" int ssp_debug_gstamps(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ssp::g_gstamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ssp::g_gstamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -23,17 +23,24 @@ struct MfccArgs {
     // tables (device)
     const float* window;    // [n_fft] zero padded
     const float2* twiddle;  // [n_fft]  W_nfft^k = exp(-2 pi i k / n_fft)
-    const int32_t* filt_lo;
-    const int32_t* filt_len;
-    const int32_t* filt_ofs;
-    const float* filt_w;
-    const float* dct;  // [n_ceps x n_filt]
+    const int32_t* filt_lo4;   // [n_filt] first non-zero bin of each filter, rounded down to a multiple of 4
+    const float* filt_wT;      // per group of 64 filters [gsteps][64][4]: taps 4 s .. 4 s + 3 (from filt_lo4) of filter 64 g + l, zero padded
+    const int32_t* filt_grp;   // [2][8] per group: 16-byte steps of its widest filter (even); offset of its block in filt_wT (16-byte units)
+    int32_t filt_w4_total;     // 16-byte entries in filt_wT
+    int32_t dct_ncp;           // DCT lanes per coefficient block: power of two >= min(n_ceps, 64)
+    const float* dct;          // [n_ceps x n_filt]
+    const float* dctT;         // [n_filt x n_ceps]
     // cfg
     int32_t win_len, hop, n_fft, n_filt, n_ceps, d_out;
     int32_t frame_mode, preemph_mode, spec_power, log_mode, floor_mode, delta_order, delta_N, cmvn;
     float preemph, spec_scale, eps, top_db, delta_inv_denom;
     // LDS carve (bytes from the dynamic LDS base; all multiples of 16)
     int32_t lds_logmel_off, lds_ceps_off, lds_dlt_off, lds_ddl_off, lds_lmrows_off, lds_stats_off, lds_tw_off;
+    int32_t lds_dct_off;  // transposed DCT matrix staged in LDS (-1: read from global memory)
+    int32_t lds_wt_off;   // filter taps staged in LDS (-1: read from global memory)
+    int32_t lm_stride;    // floats per log-mel row kept in LDS (4 x odd: 16-byte reads down a column are conflict free)
+    int32_t n_chunks;
+    int32_t prefetch;     // touch the next frame's cache lines ahead of its staging loads
 };
 
 constexpr int MFCC_FAST_MAX_PASS = 4;  // <= 64 filters in the fused n_fft == 512 kernel
@@ -73,7 +80,7 @@ struct FastArgs {
     int32_t n_chunks;  // log(max(v + log_add, log_max)) * log_k  (floor_mode / log_mode, branch free)
 };
 
-int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, hipStream_t stream);
+int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, int n_waves, int num_cu, hipStream_t stream);
 // per-utterance CMVN over a feature matrix in global memory (feat_ops.hip; in == out allowed), any utterance length
 int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, hipStream_t stream);
 // second pass of the two-pass top_db path: per-utterance max of the log-mel rows, clamp at max - top_db, DCT rows -> out [F x n_ceps]
@@ -87,7 +94,7 @@ struct ssp_mfcc_plan {
     ssp_ctx* ctx = nullptr;
     ssp_mfcc_cfg cfg{};
     int32_t d_out = 0;
-    ssp::DevBuf window, twiddle, filt_lo, filt_len, filt_ofs, filt_w, dct, fbank_dense;
+    ssp::DevBuf window, twiddle, filt_lo4, filt_grp, filt_wT, dct, dctT, fbank_dense;
     int32_t max_filt_len = 0;
     // cached work table for the last (sample_seg, frame_seg, variant) seen
     uint64_t cache_sseg = 0;  // ssp_segments::serial
@@ -98,6 +105,7 @@ struct ssp_mfcc_plan {
     ssp::DevBuf lm_scratch;
     int cache_chunk_frames = 0;
     size_t cache_lds = 0;
+    int cache_waves = 4;  // waves per workgroup of the generic kernel
     int32_t cache_n_chunks = 0;
     ssp::DevBuf chunks;
     ssp::MfccArgs args{};

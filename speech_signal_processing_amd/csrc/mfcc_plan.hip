@@ -43,12 +43,13 @@ static int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
 
 static size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
 
-// LDS carve of the generic kernel for chunks of `ch` frames; returns total bytes
-static size_t generic_lds_layout(const ssp_mfcc_cfg& c, int ch, MfccArgs* a) {
+// LDS carve of the generic kernel for chunks of `ch` frames and `nw` waves per workgroup; returns total bytes
+static size_t generic_lds_layout(const ssp_mfcc_cfg& c, int ch, int nw, MfccArgs* a) {
     const int H = c.delta_order * c.delta_N;
-    size_t off = (size_t)4 * c.n_fft * sizeof(float2);  // 4 waves x [2][n_fft/2] float2
+    const int M = c.n_fft / 2;
+    size_t off = (size_t)nw * (M + M / 16) * sizeof(float2);  // per wave: M complex points, one pad slot per 16
     a->lds_logmel_off = (int32_t)off;
-    off = align16(off + (size_t)4 * c.n_filt * sizeof(float));
+    off = align16(off + (size_t)nw * c.n_filt * sizeof(float));
     a->lds_ceps_off = (int32_t)off;
     off = align16(off + (size_t)(ch + 2 * H) * c.n_ceps * sizeof(float));
     a->lds_dlt_off = (int32_t)off;
@@ -56,11 +57,23 @@ static size_t generic_lds_layout(const ssp_mfcc_cfg& c, int ch, MfccArgs* a) {
     a->lds_ddl_off = (int32_t)off;
     if (c.delta_order >= 2) off = align16(off + (size_t)ch * c.n_ceps * sizeof(float));
     a->lds_lmrows_off = (int32_t)off;
-    if (c.top_db >= 0.f) off = align16(off + (size_t)ch * c.n_filt * sizeof(float));
+    a->lm_stride = 4 * (((c.n_filt + 3) / 4) | 1);
+    if (c.top_db >= 0.f) off = align16(off + (size_t)ch * a->lm_stride * sizeof(float));
     a->lds_stats_off = (int32_t)off;
-    off = align16(off + (size_t)(2 * c.n_ceps * (1 + c.delta_order) + 8 + 256) * sizeof(float));
+    off = align16(off + (size_t)(2 * c.n_ceps * (1 + c.delta_order) + 16) * sizeof(float));
     a->lds_tw_off = (int32_t)off;
     off = align16(off + (size_t)c.n_fft * sizeof(float2));
+    a->lds_dct_off = a->lds_wt_off = -1;
+    const size_t wt_bytes = (size_t)a->filt_w4_total * 16;
+    if (wt_bytes <= 32 * 1024) {
+        a->lds_wt_off = (int32_t)off;
+        off = align16(off + wt_bytes);
+    }
+    const size_t dct_bytes = (size_t)((c.n_filt + 3) & ~3) * c.n_ceps * sizeof(float);
+    if (dct_bytes <= 16 * 1024) {
+        a->lds_dct_off = (int32_t)off;
+        off = align16(off + dct_bytes);
+    }
     return off;
 }
 
@@ -71,7 +84,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     bool split_topdb = false;                // ... or log-mel rows through a global scratch, then the clamp + DCT kernel
     const int64_t max_T = fseg->max_len();
     const size_t lds_cap = 160 * 1024;
-    int ch;
+    int ch, nw = 4;
     size_t lds = 0;
     if (variant == 2) {
         // persistent workgroups with a fixed LDS footprint; a chunk's cepstra (+ delta halo) and a block of output rows
@@ -90,12 +103,22 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         lds = mfcc_fast_lds(c, tmp, ch);
         if (lds > lds_cap) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
     } else {
-        MfccArgs tmp{};
-        ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
-        while (ch > 16 && generic_lds_layout(c, ch, &tmp) > 64 * 1024 && !whole) ch = (ch * 3) / 4;
+        // chunked work: 4 waves per workgroup and <= 80 KiB, so two workgroups share a CU; whole-utterance work (CMVN / top_db
+        // inside the kernel): 8 waves when the utterance's rows still fit the 160 KiB, else 4
+        MfccArgs tmp = p->args;  // (the table sizes the layout depends on)
+        const size_t half_cap = 80 * 1024;
+        auto chunk_for = [&](const ssp_mfcc_cfg& cc) {
+            int k = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
+            while (k > 16 && generic_lds_layout(cc, k, 4, &tmp) > half_cap) k = (k * 3) / 4;
+            return k;
+        };
+        nw = 4;
+        ch = chunk_for(c);
         if (whole) {
             ch = (int)std::max<int64_t>(max_T, 1);
-            if (generic_lds_layout(c, ch, &tmp) > lds_cap) {
+            if (generic_lds_layout(c, ch, 8, &tmp) <= lds_cap) {
+                nw = 8;
+            } else if (generic_lds_layout(c, ch, 4, &tmp) > lds_cap) {
                 if (c.top_db >= 0.f) {
                     if (c.delta_order != 0 || c.cmvn)
                         SSP_FAIL(SSP_ERR_UNSUPPORTED,
@@ -106,20 +129,18 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
                     split_cmvn = true;
                 }
                 whole = false;
-                ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
-                while (ch > 16 && generic_lds_layout(c, ch, &tmp) > 64 * 1024) ch = (ch * 3) / 4;
+                ch = chunk_for(c);
                 if (split_topdb) {  // the chunked first pass keeps no per-chunk log-mel rows: lay the LDS out as if top_db were off
                     ssp_mfcc_cfg c2 = c;
                     c2.top_db = -1.f;
-                    ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
-                    while (ch > 16 && generic_lds_layout(c2, ch, &tmp) > 64 * 1024) ch = (ch * 3) / 4;
+                    ch = chunk_for(c2);
                 }
             }
         }
         {
             ssp_mfcc_cfg c2 = c;
             if (split_topdb) c2.top_db = -1.f;
-            lds = generic_lds_layout(c2, ch, &p->args);
+            lds = generic_lds_layout(c2, ch, nw, &p->args);
         }
         if (lds > lds_cap) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: LDS footprint %zu B exceeds 160 KiB", lds);
     }
@@ -138,6 +159,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     p->cache_n_chunks = (int32_t)chunks.size();
     p->cache_chunk_frames = ch;
     p->cache_lds = lds;
+    p->cache_waves = nw;
     p->cache_sseg = sseg->serial;
     p->cache_fseg = fseg->serial;
     p->cache_variant = variant;
@@ -205,16 +227,54 @@ int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* win
         maxlen = std::max(maxlen, len[j]);
     }
     p->max_filt_len = maxlen;
+    // generic kernel: per group of 64 filters a transposed, zero-padded tap table read 4 taps at a time from the first bin
+    // rounded down to a multiple of 4
+    const int n_grp = (cfg->n_filt + 63) / 64;  // <= 8 (n_filt <= 512)
+    std::vector<int32_t> lo4(cfg->n_filt);
+    std::vector<float> wT;
+    MfccArgs& ga = p->args;
+    const int buf_floats = n_fft + n_fft / 16;  // the wave buffer the spectrum row sits in
+    std::vector<int32_t> grp(16, 0);
+    for (int g = 0; g < n_grp; ++g) {
+        const int j1 = std::min(cfg->n_filt, g * 64 + 64);
+        int32_t taps = 0;
+        for (int j = g * 64; j < j1; ++j) {
+            lo4[j] = lo[j] & ~3;
+            taps = std::max(taps, len[j] + (lo[j] - lo4[j]));
+        }
+        const int32_t steps = ((taps + 7) / 8) * 2;
+        for (int j = g * 64; j < j1; ++j)
+            if (lo4[j] + 4 * steps > buf_floats) {
+                delete p;
+                SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: filter %d (bins %d..%d) next to %d-tap filters does not fit the kernel's spectrum row",
+                         j, lo[j], lo[j] + len[j] - 1, taps);
+            }
+        grp[g] = steps;
+        grp[8 + g] = (int32_t)(wT.size() / 4);
+        const size_t base = wT.size();
+        wT.resize(base + (size_t)steps * 64 * 4, 0.f);
+        for (int j = g * 64; j < j1; ++j)
+            for (int k = 0; k < len[j]; ++k) {
+                const int tap = k + (lo[j] - lo4[j]);
+                wT[base + ((size_t)(tap / 4) * 64 + (j - g * 64)) * 4 + (tap & 3)] = w[(size_t)ofs[j] + k];
+            }
+    }
+    ga.filt_w4_total = (int32_t)(wT.size() / 4);
+    ga.dct_ncp = 1;
+    while (ga.dct_ncp < std::min(cfg->n_ceps, 64)) ga.dct_ncp *= 2;
+    std::vector<float> dctT((size_t)cfg->n_ceps * cfg->n_filt);
+    for (int q = 0; q < cfg->n_ceps; ++q)
+        for (int j = 0; j < cfg->n_filt; ++j) dctT[(size_t)j * cfg->n_ceps + q] = dct[(size_t)q * cfg->n_filt + j];
     std::vector<float> dctv(dct, dct + (size_t)cfg->n_ceps * cfg->n_filt);
     std::vector<float> dense(fbank, fbank + (size_t)cfg->n_filt * nb);
     hipStream_t s = ctx->stream;
     int rc = upload(p->window, win, s);
     if (rc == SSP_OK) rc = upload(p->twiddle, tw, s);
-    if (rc == SSP_OK) rc = upload(p->filt_lo, lo, s);
-    if (rc == SSP_OK) rc = upload(p->filt_len, len, s);
-    if (rc == SSP_OK) rc = upload(p->filt_ofs, ofs, s);
-    if (rc == SSP_OK) rc = upload(p->filt_w, w, s);
+    if (rc == SSP_OK) rc = upload(p->filt_lo4, lo4, s);
+    if (rc == SSP_OK) rc = upload(p->filt_grp, grp, s);
+    if (rc == SSP_OK) rc = upload(p->filt_wT, wT, s);
     if (rc == SSP_OK) rc = upload(p->dct, dctv, s);
+    if (rc == SSP_OK) rc = upload(p->dctT, dctT, s);
     if (rc == SSP_OK) rc = upload(p->fbank_dense, dense, s);
     if (rc == SSP_OK && hipStreamSynchronize(s) != hipSuccess) {
         set_error("mfcc plan: table upload failed");
@@ -231,11 +291,11 @@ int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* win
     MfccArgs& a = p->args;
     a.window = p->window.as<float>();
     a.twiddle = p->twiddle.as<float2>();
-    a.filt_lo = p->filt_lo.as<int32_t>();
-    a.filt_len = p->filt_len.as<int32_t>();
-    a.filt_ofs = p->filt_ofs.as<int32_t>();
-    a.filt_w = p->filt_w.as<float>();
+    a.filt_lo4 = p->filt_lo4.as<int32_t>();
+    a.filt_grp = p->filt_grp.as<int32_t>();
+    a.filt_wT = p->filt_wT.as<float>();
     a.dct = p->dct.as<float>();
+    a.dctT = p->dctT.as<float>();
     a.win_len = cfg->win_len;
     a.hop = cfg->hop;
     a.n_fft = cfg->n_fft;
@@ -342,7 +402,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     if (v == 2)
         SSP_TRY(launch_mfcc_fast(a, plan, plan->cache_n_chunks, plan->cache_chunk_frames, s));
     else
-        SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, s));
+        SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, plan->cache_waves, plan->ctx->num_cu, s));
     if (a.lm_out)
         SSP_TRY(launch_topdb_dct(a.lm_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->cfg.n_filt, plan->cfg.n_ceps, plan->dct.as<float>(),
                                  plan->cfg.top_db, d_out, s));

@@ -8,7 +8,10 @@ g = torch.Generator(device='cuda'); g.manual_seed(1)
 for name, tables, n_utt, n in (("in-repo 8 kHz 512/256 (utils.processing.MFCC, 13-d)", pkg.preset_inrepo(8000, 512, 256), 100000, 24000),
                                ("in-repo 16 kHz 512/256", pkg.preset_inrepo(16000, 512, 256), 100000, 48000),
                                ("sidekit 26-d + CMVN (GMM_UBM.extract_feature)", pkg.preset_sidekit(delta_order=1, cmvn=1), 100000, 48000),
-                               ("librosa 8 kHz 2048/512 (MFCC_lib, generic kernel)", pkg.preset_librosa(8000, 13), 20000, 24000)):
+                               ("in-repo 16 kHz 1024/512 (generic kernel)", pkg.preset_inrepo(16000, 1024, 512), 20000, 48000),
+                               ("in-repo 8 kHz 256/128 (generic kernel)", pkg.preset_inrepo(8000, 256, 128), 20000, 24000),
+                               ("librosa 8 kHz 2048/512 (MFCC_lib, generic kernel)", pkg.preset_librosa(8000, 13), 20000, 24000),
+                               ("librosa 16 kHz 2048/512, 10 s utterances (two-pass top_db)", pkg.preset_librosa(16000, 13), 4000, 160000)):
     audio = (0.1 * torch.randn(n_utt * n, generator=g, device='cuda')).float()
     plan = api.MfccPlan(ctx, tables)
     seg = api.Segments.from_lengths(ctx, np.full(n_utt, n, dtype=np.int64))
