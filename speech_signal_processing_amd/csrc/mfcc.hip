@@ -177,6 +177,7 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
     const int t0 = ch.t0, n = ch.n;
     const int H = a.delta_order * a.delta_N;
     const int ta = max(t0 - H, 0), tb = min(t0 + n + H, T);  // cepstra rows kept in LDS
+    float wave_max = -INFINITY;  // two-pass top_db: this wave's largest log-mel value
     GSTAMP(5)
     for (int t = ta + wave; t < tb; t += nw) {
         // ---- frame -> y[i] = (x[i] - p x[i-1]) w[i] (zero beyond win_len), unpadded floats over the wave buffer.  x[i-1] of a
@@ -308,7 +309,10 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
                 if (valid) {
                     const float v = apply_log(a, (acc.x + acc.y) + (acc.z + acc.w));
                     lm[j] = v;
-                    if (a.lm_out && t >= t0 && t < t0 + n) a.lm_out[(size_t)(f0 + t) * a.n_filt + j] = v;
+                    if (a.lm_out && t >= t0 && t < t0 + n) {
+                        a.lm_out[(size_t)(f0 + t) * a.n_filt + j] = v;
+                        wave_max = fmaxf(wave_max, v);
+                    }
                 }
             }
         };
@@ -351,7 +355,14 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
     }
     __syncthreads();
     GSTAMP(6)
-    if (a.lm_out) return;
+    if (a.lm_out) {  // utterance maximum for the second pass: one atomic per wave (float order through the integer trick)
+        for (int o = 32; o > 0; o >>= 1) wave_max = fmaxf(wave_max, __shfl_xor(wave_max, o));
+        if (lane == 0 && wave_max > -INFINITY) {
+            if (wave_max >= 0.f) atomicMax(reinterpret_cast<int*>(a.utt_max + ch.utt), __float_as_int(wave_max));
+            else atomicMin(reinterpret_cast<unsigned*>(a.utt_max + ch.utt), __float_as_uint(wave_max));
+        }
+        return;
+    }
 
     if (a.top_db >= 0.f) {  // whole utterance is in this chunk (host guarantees): max over all log-mel values
         float mx = -INFINITY;
@@ -507,11 +518,65 @@ __global__ __launch_bounds__(256) void topdb_dct_kernel(const float* __restrict_
     }
 }
 
-int launch_topdb_dct(const float* logmel, const int64_t* frame_off_dev, int64_t n_utt, int n_filt, int n_ceps, const float* dct,
-                     float top_db, float* out, hipStream_t stream) {
+// second pass, one workgroup per chunk of the first pass: rows staged in LDS 64 at a time (stride 4 x odd floats), DCT rows in LDS
+// [n_ceps][n_filt4], clamp at the utterance maximum - top_db, two coefficients per thread
+__global__ __launch_bounds__(256) void topdb_dct_chunk_kernel(const float* __restrict__ lm, const MfccChunk* __restrict__ chunks,
+                                                              const int64_t* __restrict__ off, const float* __restrict__ utt_max,
+                                                              int n_filt, int nc, const float* __restrict__ dct, float top_db,
+                                                              float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int n_filt4 = (n_filt + 3) & ~3, stride = 4 * ((n_filt4 / 4) | 1);
+    float* dl = reinterpret_cast<float*>(smem);  // [nc][n_filt4]
+    float* rows = dl + nc * n_filt4;             // [64][stride]
+    for (int i = tid; i < nc * n_filt4; i += 256) {
+        const int q = i / n_filt4, j = i - q * n_filt4;
+        dl[i] = j < n_filt ? dct[q * n_filt + j] : 0.f;
+    }
+    const MfccChunk ch = chunks[blockIdx.x];
+    const int64_t fbase = off[ch.utt] + ch.t0;
+    const float thr = utt_max[ch.utt] - top_db;
+    const int nq2 = (nc + 1) >> 1;
+    for (int r0 = 0; r0 < ch.n; r0 += 64) {
+        const int nr = min(64, ch.n - r0);
+        __syncthreads();
+        const float* __restrict__ src = lm + (fbase + r0) * n_filt;
+        for (int i = tid; i < nr * n_filt4; i += 256) {
+            const int r = i / n_filt4, j = i - r * n_filt4;
+            rows[r * stride + j] = j < n_filt ? src[(size_t)r * n_filt + j] : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < nr * nq2; i += 256) {
+            const int qb = i / nr, r = i - qb * nr;
+            const int q0 = 2 * qb, q1 = min(q0 + 1, nc - 1);
+            const float* l_ = rows + r * stride;
+            const float *d0 = dl + q0 * n_filt4, *d1 = dl + q1 * n_filt4;
+            v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < n_filt4; j += 4) {
+                v4f l = *reinterpret_cast<const v4f*>(l_ + j);
+                l = v4f{fmaxf(l.x, thr), fmaxf(l.y, thr), fmaxf(l.z, thr), fmaxf(l.w, thr)};
+                acc0 = __builtin_elementwise_fma(l, *reinterpret_cast<const v4f*>(d0 + j), acc0);
+                acc1 = __builtin_elementwise_fma(l, *reinterpret_cast<const v4f*>(d1 + j), acc1);
+            }
+            float* __restrict__ o = out + (fbase + r0 + r) * nc;
+            o[q0] = (acc0.x + acc0.y) + (acc0.z + acc0.w);
+            if (q0 + 1 < nc) o[q1] = (acc1.x + acc1.y) + (acc1.z + acc1.w);
+        }
+    }
+}
+
+int launch_topdb_dct(const float* logmel, const int64_t* frame_off_dev, int64_t n_utt, const MfccChunk* chunks, int n_chunks,
+                     const float* utt_max, int n_filt, int n_ceps, const float* dct, float top_db, float* out, hipStream_t stream) {
     if (n_utt <= 0) return SSP_OK;
     if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "top_db: too many utterances");
-    hipLaunchKernelGGL(topdb_dct_kernel, dim3((unsigned)n_utt), dim3(256), 0, stream, logmel, frame_off_dev, n_filt, n_ceps, dct, top_db, out);
+    const int n_filt4 = (n_filt + 3) & ~3, stride = 4 * ((n_filt4 / 4) | 1);
+    const size_t lds = ((size_t)n_ceps * n_filt4 + (size_t)64 * stride) * sizeof(float);
+    if (lds <= 64 * 1024 && n_chunks > 0) {
+        hipLaunchKernelGGL(topdb_dct_chunk_kernel, dim3(n_chunks), dim3(256), lds, stream, logmel, chunks, frame_off_dev, utt_max, n_filt,
+                           n_ceps, dct, top_db, out);
+    } else {  // a DCT matrix too large for the LDS: one workgroup per utterance straight from global memory
+        hipLaunchKernelGGL(topdb_dct_kernel, dim3((unsigned)n_utt), dim3(256), 0, stream, logmel, frame_off_dev, n_filt, n_ceps, dct, top_db, out);
+    }
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }

@@ -20,6 +20,7 @@ struct MfccArgs {
     float* lm_out;              // non-null: the generic kernel only writes log-mel rows [total_frames x n_filt] here (first pass of
                                 // the two-pass top_db path for utterances longer than one workgroup's LDS)
     const MfccChunk* chunks;
+    float* utt_max;             // [n_utt] two-pass top_db: largest log-mel value of each utterance (-inf before the first pass)
     // tables (device)
     const float* window;    // [n_fft] zero padded
     const float2* twiddle;  // [n_fft]  W_nfft^k = exp(-2 pi i k / n_fft)
@@ -84,8 +85,8 @@ int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, in
 // per-utterance CMVN over a feature matrix in global memory (feat_ops.hip; in == out allowed), any utterance length
 int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, hipStream_t stream);
 // second pass of the two-pass top_db path: per-utterance max of the log-mel rows, clamp at max - top_db, DCT rows -> out [F x n_ceps]
-int launch_topdb_dct(const float* logmel, const int64_t* frame_off_dev, int64_t n_utt, int n_filt, int n_ceps, const float* dct,
-                     float top_db, float* out, hipStream_t stream);
+int launch_topdb_dct(const float* logmel, const int64_t* frame_off_dev, int64_t n_utt, const MfccChunk* chunks, int n_chunks,
+                     const float* utt_max, int n_filt, int n_ceps, const float* dct, float top_db, float* out, hipStream_t stream);
     
 
 }  // namespace ssp
@@ -102,7 +103,7 @@ struct ssp_mfcc_plan {
     int cache_variant = -1;
     bool cache_split_cmvn = false;  // CMVN as a second kernel (an utterance exceeds one workgroup's chunk)
     bool cache_split_topdb = false; // top_db as a second kernel (log-mel rows through a global scratch)
-    ssp::DevBuf lm_scratch;
+    ssp::DevBuf lm_scratch, umax_scratch;
     int cache_chunk_frames = 0;
     size_t cache_lds = 0;
     int cache_waves = 4;  // waves per workgroup of the generic kernel

@@ -390,6 +390,9 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     if (plan->cache_split_topdb && v == 1) {  // two-pass top_db: log-mel rows to a scratch, clamp + DCT in a second kernel
         SSP_TRY(plan->lm_scratch.reserve((size_t)total_frames * plan->cfg.n_filt * sizeof(float)));
         a.lm_out = plan->lm_scratch.as<float>();
+        SSP_TRY(plan->umax_scratch.reserve((size_t)frame_seg->n * sizeof(float)));
+        a.utt_max = plan->umax_scratch.as<float>();
+        SSP_HIP(hipMemsetD32Async((hipDeviceptr_t)a.utt_max, (int)0xff800000u, (size_t)frame_seg->n, s));  // -inf
         a.top_db = -1.f;
     }
     a.samples = d_samples;
@@ -404,7 +407,8 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     else
         SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, plan->cache_waves, plan->ctx->num_cu, s));
     if (a.lm_out)
-        SSP_TRY(launch_topdb_dct(a.lm_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->cfg.n_filt, plan->cfg.n_ceps, plan->dct.as<float>(),
+        SSP_TRY(launch_topdb_dct(a.lm_out, frame_seg->dev.as<int64_t>(), frame_seg->n, a.chunks, plan->cache_n_chunks, a.utt_max,
+                                 plan->cfg.n_filt, plan->cfg.n_ceps, plan->dct.as<float>(),
                                  plan->cfg.top_db, d_out, s));
     if (plan->cache_split_cmvn) SSP_TRY(launch_cmvn(d_out, d_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->d_out, s));
     SSP_TRY(tm.stop(s, kernel_ms));
