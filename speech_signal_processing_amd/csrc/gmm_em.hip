@@ -157,13 +157,18 @@ __global__ __launch_bounds__(64) void gmm_em_lsesum_kernel(const float* __restri
 //   GEMM2  S[64 mix x (2D+1)] += resp[64 mix x 64 frames] . aug    split over the waves by frames (wave w: frames 16w..16w+15 of
 //                                                                  the tile); accumulators stay in registers over all tiles
 // Each wave leaves its own partial [64 mix][2D+1]; gmm_em_reduce_kernel adds the 4 G partials in float64.
-template <int NCT>
+// FUSE (K <= 64: the workgroup sees every mixture of a frame): the per-frame log-sum-exp is taken right here from the GEMM1
+// accumulators (in-lane over 16 mixtures, across the two half-waves, across the two waves that share a frame through LDS) instead of a
+// separate scoring pass; sum_t lse[t] leaves as one partial per workgroup.
+template <int NCT, bool FUSE>
 __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
     extern __shared__ float sm[];
     const int D = a.D, W = 2 * D + 1, XS = D | 1, KS = (W + 1) / 2;  // KS k-steps of 2 over [x, x^2, 1] (+ a zero pad column)
     float* xs = sm;                    // [64 frames][XS]
     float* wsT = xs + EM_TF * XS;      // [2 KS][64 mix]   parameter chunk, k-major: the A operand of GEMM1
     float* rs = wsT + 2 * KS * EM_KC;  // [64 frames][65]  responsibilities: the A operand of GEMM2
+    float* ex = rs + EM_TF * 65;       // [2 mixture halves][64 frames][2]  (max, sum) exchange of the fused log-sum-exp
+    float lsum = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 31, h = lane >> 5;
     const int kc = blockIdx.y * EM_KC;
@@ -194,7 +199,8 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
             xpre[u] = (i < EM_TF * D && r < nt) ? a.x[base * D + i] : 0.f;
         }
         const int fr = 32 * c1 + fl;
-        lpre = fr < nt ? a.lse[base + fr] : INFINITY;  // frames beyond the end: resp = exp(-inf) = 0
+        if (FUSE) lpre = fr < nt ? 0.f : INFINITY;
+        else lpre = fr < nt ? a.lse[base + fr] : INFINITY;  // frames beyond the end: resp = exp(-inf) = 0
     };
     fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += a.G) {
@@ -226,8 +232,32 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
         }
         // ---- responsibilities of this lane's frame; accumulator i = mixture 32 r1 + (i & 3) + 8 (i >> 2) + 4 h
         const int fr = 32 * c1 + fl;
+        if (FUSE) {
+            float m = acc1[0];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rs[fr * 65 + 32 * r1 + (i & 3) + 8 * (i >> 2) + 4 * h] = __expf(acc1[i] - l);
+            for (int i = 1; i < 16; ++i) m = fmaxf(m, acc1[i]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float e[16], ssum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                e[i] = __expf(acc1[i] - m);
+                ssum += e[i];
+            }
+            ssum += __shfl_xor(ssum, 32);
+            if (h == 0) *reinterpret_cast<float2*>(ex + (r1 * 64 + fr) * 2) = make_float2(m, ssum);
+            __syncthreads();
+            const float2 o = *reinterpret_cast<const float2*>(ex + ((1 - r1) * 64 + fr) * 2);
+            const float mm = fmaxf(m, o.x);
+            const float tot = ssum * __expf(m - mm) + o.y * __expf(o.x - mm);
+            const bool valid = l == 0.f;
+            const float scale = valid ? __expf(m - mm) / tot : 0.f;
+            if (valid && r1 == 0 && h == 0) lsum += mm + __logf(tot);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rs[fr * 65 + 32 * r1 + (i & 3) + 8 * (i >> 2) + 4 * h] = e[i] * scale;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rs[fr * 65 + 32 * r1 + (i & 3) + 8 * (i >> 2) + 4 * h] = __expf(acc1[i] - l);
+        }
         __syncthreads();
         // ---- GEMM2 over this wave's 16 frames: A[row = mix 32 r + fl][k = frame], B[k = frame][col = 32 c + fl] = aug[frame][col]
 #pragma unroll
@@ -251,6 +281,13 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) acc2[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bv[c], acc2[r][c], 0, 0, 0);
         }
+    }
+    if (FUSE) {  // sum of this workgroup's lse values: lanes (r1 == 0, h == 0) of waves 0 and 1 hold them
+        for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+        __syncthreads();
+        if (lane == 0 && r1 == 0) ex[c1] = lsum;
+        __syncthreads();
+        if (tid == 0) a.lse_part[blockIdx.x] = ex[0] + ex[1];
     }
     float* out = a.part + ((size_t)(blockIdx.x * 4 + wave) * a.Kp + kc) * W;
 #pragma unroll
@@ -347,7 +384,7 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
     SSP_TRY(rc);
     SSP_TRY(d_par.reserve(par.size() * sizeof(float)));
     SSP_TRY(d_lse.reserve((size_t)n_frames * sizeof(float)));
-    SSP_TRY(d_lsep.reserve((size_t)n_tiles * sizeof(float)));
+    SSP_TRY(d_lsep.reserve((size_t)std::max<int64_t>(n_tiles, G) * sizeof(float)));
     SSP_TRY(d_part.reserve((size_t)GP * cols * sizeof(float)));
     SSP_TRY(d_out.reserve((size_t)(cols + 1) * sizeof(double)));
     SSP_HIP(hipMemcpyAsync(d_par.p, par.data(), par.size() * sizeof(float), hipMemcpyHostToDevice, s));
@@ -356,7 +393,8 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
     const int XS = D | 1;
     const size_t lds1 = ((size_t)EM_TF * XS + (size_t)EM_KC * W + 512) * sizeof(float);
     const size_t lds2 = ((size_t)EM_TF * XS + (size_t)EM_KC * W + (size_t)EM_TF * 65) * sizeof(float);
-    const size_t lds3 = ((size_t)EM_TF * XS + (size_t)(W + 1) * EM_KC + (size_t)EM_TF * 65) * sizeof(float);
+    const size_t lds3 = ((size_t)EM_TF * XS + (size_t)(W + 1) * EM_KC + (size_t)EM_TF * 65 + 256) * sizeof(float);
+    const bool fuse = mfma && Kp == EM_KC && !getenv("SSP_EM_NO_FUSE");  // K <= 64: log-sum-exp inside the accumulation kernel
     if (lds1 > 64 * 1024)
         SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_lse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     if (lds2 > 64 * 1024)
@@ -364,7 +402,7 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
     // the per-frame log-sum-exp of the MFMA path comes from the scoring kernel (csrc/gmm.hip: fp32 MFMA, score_samples of ONE model)
     ssp_gmm* scorer = nullptr;
     ssp_segments* seg = nullptr;
-    if (mfma) {
+    if (mfma && !fuse) {
         const int64_t off[2] = {0, n_frames};
         rc = ssp_gmm_pack(ctx, 1, K, D, weights, means, covars, 0, &scorer);
         if (rc == SSP_OK) rc = segments_make(ctx, off, 1, &seg);
@@ -375,14 +413,20 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
     }
     Timer tm;
     rc = tm.start(kernel_ms != nullptr, s);
-    if (rc == SSP_OK && mfma) {
+    if (rc == SSP_OK && fuse) {
+        switch (nct) {
+            case 1: hipLaunchKernelGGL((gmm_em_acc_mfma_kernel<1, true>), dim3(G, 1), dim3(256), lds3, s, a); break;
+            case 2: hipLaunchKernelGGL((gmm_em_acc_mfma_kernel<2, true>), dim3(G, 1), dim3(256), lds3, s, a); break;
+            default: hipLaunchKernelGGL((gmm_em_acc_mfma_kernel<3, true>), dim3(G, 1), dim3(256), lds3, s, a); break;
+        }
+    } else if (rc == SSP_OK && mfma) {
         rc = ssp_gmm_score(scorer, d_x, seg, d_lse.as<float>(), nullptr, nullptr, SSP_DEVICE, 0, nullptr);
         if (rc == SSP_OK) {
             hipLaunchKernelGGL(gmm_em_lsesum_kernel, dim3((unsigned)n_tiles), dim3(64), 0, s, d_lse.as<float>(), n_frames, d_lsep.as<float>());
             switch (nct) {
-                case 1: hipLaunchKernelGGL(gmm_em_acc_mfma_kernel<1>, dim3(G, Kp / EM_KC), dim3(256), lds3, s, a); break;
-                case 2: hipLaunchKernelGGL(gmm_em_acc_mfma_kernel<2>, dim3(G, Kp / EM_KC), dim3(256), lds3, s, a); break;
-                default: hipLaunchKernelGGL(gmm_em_acc_mfma_kernel<3>, dim3(G, Kp / EM_KC), dim3(256), lds3, s, a); break;
+                case 1: hipLaunchKernelGGL((gmm_em_acc_mfma_kernel<1, false>), dim3(G, Kp / EM_KC), dim3(256), lds3, s, a); break;
+                case 2: hipLaunchKernelGGL((gmm_em_acc_mfma_kernel<2, false>), dim3(G, Kp / EM_KC), dim3(256), lds3, s, a); break;
+                default: hipLaunchKernelGGL((gmm_em_acc_mfma_kernel<3, false>), dim3(G, Kp / EM_KC), dim3(256), lds3, s, a); break;
             }
         }
     } else if (rc == SSP_OK) {
@@ -391,7 +435,7 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
     }
     if (rc == SSP_OK) {
         hipLaunchKernelGGL(gmm_em_reduce_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, s, d_part.as<float>(), GP, cols,
-                           d_lsep.as<float>(), n_tiles, d_out.as<double>());
+                           d_lsep.as<float>(), fuse ? (int64_t)G : n_tiles, d_out.as<double>());
         if (hipGetLastError() != hipSuccess) {
             set_error("ssp_gmm_em_stats: kernel launch failed");
             rc = SSP_ERR_HIP;
