@@ -129,6 +129,16 @@ int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, i
 int ssp_cmvn(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim,
              float* out, int where, float* kernel_ms);
 
+/* ---- PLP back end: replaces sidekit.frontend.features.plp after its power spectrum -> Bark bands -> ln stage (call sites
+ * GMM_UBM.py:95, d_vector.py:93, UI/GMM_UBM_GUI.py:93, UI/tmp.py:315-318; that front stage is ssp_mfcc_run with a Bark table and
+ * an identity DCT).  logspec: float[F x n_bands] ln critical-band energies laid out by frame_seg (which must start at frame 0);
+ * rasta != 0: RASTA filtering along time per utterance (first four frames of an utterance come out as the flat-spectrum
+ * cepstrum, as in rastamat); then equal-loudness (band centres 0..fmax_hz in Bark), ^0.33, autocorrelation, Levinson-Durbin of
+ * order plp_order - 1, LPC -> cepstrum, lifter n^lift.  ceps_out: float[F x plp_order] (c0 first).  sidekit's source is absent
+ * from the reference tree: the arithmetic follows the published rastamat algorithm it ports (parity unpinned). */
+int ssp_plp_post(ssp_ctx* ctx, const float* logspec, const ssp_segments* frame_seg, int32_t n_bands, float fmax_hz,
+                 int32_t plp_order, int32_t rasta, float lift, float* ceps_out, int where, float* kernel_ms);
+
 /* ---- GMM-UBM scoring: replaces the GMM[i].score(x_j) - UBM.score(x_j) double loop
  *      (GMM_UBM.py:181-197) and sklearn GaussianMixture.score_samples/score for diag models ---- */
 /* weights: HOST double[n_models x K]; means, covars: HOST double[n_models x K x D].

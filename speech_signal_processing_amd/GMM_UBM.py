@@ -1,7 +1,7 @@
 """GPU-backed mirror of the hot-path functions of the reference's ``GMM_UBM.py``.
 
 * ``delta``            GMM_UBM.py:53-69
-* ``extract_feature``  GMM_UBM.py:72-118  (sidekit mfcc -> [c, delta c] -> per-utterance scale; one fused kernel)
+* ``extract_feature``  GMM_UBM.py:72-118  (sidekit mfcc -> [c, delta c] -> per-utterance scale; one fused kernel; 'PLP': plp back end)
 * ``score_matrix``     the scoring loops GMM_UBM.py:181-197 as a function that returns what the reference prints
 * ``GMM``              GMM_UBM.py:134-199: trains one GMM per speaker + the UBM (EM on the GPU, gmm_train.GaussianMixture)
                        or takes pre-trained models, then scores
@@ -16,6 +16,7 @@ import numpy as np
 
 from . import api, frontend
 from .gmm_train import GaussianMixture
+from .sidekit_features import mfcc, plp, plp_batch  # noqa: F401  (GMM_UBM.py:20 imports both names)
 
 
 def delta(feat, N=2):
@@ -34,7 +35,7 @@ def delta(feat, N=2):
 @functools.lru_cache(maxsize=8)
 def _feature_plan(feature_type, fs, delta_order):
     if feature_type != 'MFCC':
-        raise NameError  # GMM_UBM.py:100-101; PLP needs sidekit's plp (next)
+        raise NameError  # GMM_UBM.py:100-101
     return api.MfccPlan(api.default_context(), frontend.preset_sidekit(fs=fs, delta_order=delta_order, cmvn=1))
 
 
@@ -42,6 +43,14 @@ def extract_feature(x, y, is_train=False, feature_type='MFCC', fs=16000, delta_o
     """GMM_UBM.py:72-118.  x: list of 1-D audio arrays, y: list of labels.
     Returns (feature, y) or (train_data, feature, y); every feature is (T_i, 26) float64 = scale([c, delta c]).
     ``delta_order=2`` appends delta-delta (39-d) — an extension used by the benchmark configs."""
+    if feature_type == 'PLP':  # GMM_UBM.py:94-99: plp -> hstack(c, delta c) -> scale
+        feature = _extract_plp(x, int(fs), int(delta_order))
+        if not is_train:
+            return feature, y
+        train_data = {}
+        for f, lab in zip(feature, y):
+            train_data[lab] = np.vstack((train_data[lab], f)) if lab in train_data else f
+        return train_data, feature, y
     plan = _feature_plan(feature_type, int(fs), int(delta_order))
     sig = [np.asarray(s, dtype=np.float32).reshape(-1) for s in x]
     seg = api.Segments.from_lengths(plan.ctx, [s.shape[0] for s in sig])
@@ -55,6 +64,17 @@ def extract_feature(x, y, is_train=False, feature_type='MFCC', fs=16000, delta_o
     for f, lab in zip(feature, y):
         train_data[lab] = np.vstack((train_data[lab], f)) if lab in train_data else f
     return train_data, feature, y
+
+
+def _extract_plp(x, fs, delta_order):
+    """[c, delta c (, delta delta c)] of the PLP cepstra, per-utterance scaled; every stage on the GPU."""
+    ctx = api.default_context()
+    c, fseg = plp_batch(x, fs=fs)
+    blocks = [c]
+    for _ in range(delta_order):
+        blocks.append(api.delta_features(ctx, blocks[-1], fseg, 2))
+    feats = np.asarray(api.cmvn_features(ctx, np.ascontiguousarray(np.hstack(blocks)), fseg), dtype=np.float64)
+    return [feats[fseg.offsets[i]:fseg.offsets[i + 1]] for i in range(len(x))]
 
 
 def score_matrix(models, ubm, feats):

@@ -7,6 +7,6 @@ There is no CPU fallback: without the built library and a gfx950 device every
 compute entry point raises.
 """
 from . import frontend  # noqa: F401  (host-side tables; numpy only)
-from .frontend import MfccConfig, preset_inrepo, preset_sidekit, preset_librosa  # noqa: F401
+from .frontend import MfccConfig, preset_inrepo, preset_sidekit, preset_sidekit_plp, preset_librosa  # noqa: F401
 
-__all__ = ["frontend", "MfccConfig", "preset_inrepo", "preset_sidekit", "preset_librosa"]
+__all__ = ["frontend", "MfccConfig", "preset_inrepo", "preset_sidekit", "preset_sidekit_plp", "preset_librosa"]

@@ -55,6 +55,7 @@ SIGNATURES = {
     "ssp_spectrum_abs": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, C.c_float, C.c_int32, _F32P, C.c_int, _MSP]),
     "ssp_delta": (C.c_int, [_P, _F32P, _P, C.c_int32, C.c_int32, _F32P, C.c_int, _MSP]),
     "ssp_cmvn": (C.c_int, [_P, _F32P, _P, C.c_int32, _F32P, C.c_int, _MSP]),
+    "ssp_plp_post": (C.c_int, [_P, _F32P, _P, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_float, _F32P, C.c_int, _MSP]),
     "ssp_gmm_pack": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.POINTER(_P)]),
     "ssp_gmm_destroy": (C.c_int, [_P]),
     "ssp_gmm_score": (C.c_int, [_P, _F32P, _P, _F32P, _F32P, _P, C.c_int, C.c_int, _MSP]),

@@ -262,6 +262,21 @@ def cmvn_features(ctx: Context, feats, frame_seg: Segments, timing: bool = False
     return (out, ms.value) if timing else out
 
 
+def plp_post(ctx: Context, logspec, frame_seg: Segments, fmax_hz: float, plp_order: int = 13, rasta: bool = True, lift: float = 0.6,
+             timing: bool = False):
+    """Back end of sidekit's plp on the GPU (ssp_plp_post): (frames, bands) ln critical-band energies -> (frames, plp_order)
+    cepstra (RASTA along each utterance of ``frame_seg``, equal loudness, ^0.33, autocorrelation, Levinson, LPC->cepstrum, lifter)."""
+    keep, ptr, where = _as_f32(logspec, "logspec")
+    if keep.ndim != 2:
+        raise ValueError("logspec must be (frames, bands)")
+    out = ctx._empty((int(keep.shape[0]), int(plp_order)), where)
+    ms = C.c_float(0.0)
+    optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
+    _lib.check(ctx._lib.ssp_plp_post(ctx._h, ptr, frame_seg._h, int(keep.shape[1]), float(fmax_hz), int(plp_order), int(bool(rasta)),
+                                     float(lift), optr, where, C.byref(ms) if timing else None))
+    return (out, ms.value) if timing else out
+
+
 def gmm_em_stats(ctx: "Context", weights, means, covars, feats, timing: bool = False) -> dict:
     """E step + M-step sums of ONE EM iteration of a diagonal GMM on the GPU (ssp_gmm_em_stats).
     weights (K,), means (K,D), covars (K,D) float64; feats (n, D) float32 (numpy or device tensor).

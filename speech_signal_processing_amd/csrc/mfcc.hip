@@ -294,19 +294,22 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
         auto filterbank = [&](const v4f* wtab) {
             for (int g = 0; g * 64 < a.n_filt; ++g) {
                 const int j = g * 64 + lane;
-                const bool valid = j < a.n_filt;
+                const int nl = min(64, a.n_filt - g * 64);  // filters (= table columns) of this group
+                const bool valid = lane < nl;
                 const int lo = g == 0 ? lo_0 : (g == 1 ? lo_1 : (valid ? a.filt_lo4[j] : 0));
                 const int nstep = g == 0 ? gs_0 : (g == 1 ? gs_1 : a.filt_grp[g]);  // 16-byte steps, even
-                const v4f* wt = wtab + (g == 0 ? go_0 : (g == 1 ? go_1 : a.filt_grp[8 + g])) + lane;
+                const v4f* wt = wtab + (g == 0 ? go_0 : (g == 1 ? go_1 : a.filt_grp[8 + g])) + min(lane, nl - 1);
                 const float* pp = P + lo;
-                v4f acc = {0.f, 0.f, 0.f, 0.f};
-                for (int st = 0; st < nstep; st += 2) {
-                    const v4f w0 = wt[st * 64], w1 = wt[st * 64 + 64];
+                v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                int st = 0;
+                for (; st < nstep; st += 2) {  // (nstep is even; 4 steps per iteration measured no faster and cost registers)
+                    const v4f w0 = wt[st * nl], w1 = wt[(st + 1) * nl];
                     const v4f p0 = *reinterpret_cast<const v4f*>(pp + 4 * st), p1 = *reinterpret_cast<const v4f*>(pp + 4 * st + 4);
-                    acc = __builtin_elementwise_fma(p0, w0, acc);
-                    acc = __builtin_elementwise_fma(p1, w1, acc);
+                    acc0 = __builtin_elementwise_fma(p0, w0, acc0);
+                    acc1 = __builtin_elementwise_fma(p1, w1, acc1);
                 }
                 if (valid) {
+                    const v4f acc = acc0 + acc1;
                     const float v = apply_log(a, (acc.x + acc.y) + (acc.z + acc.w));
                     lm[j] = v;
                     if (a.lm_out && t >= t0 && t < t0 + n) {
@@ -326,7 +329,9 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
             continue;
         }
         // ---- DCT-II rows (skipped here when the utterance-level top_db clamp must come first)
-        if (a.top_db < 0.f) {
+        if (a.top_db < 0.f && a.dct_identity) {  // (the PLP front end: Bark log spectrum out)
+            for (int q = lane; q < nc; q += 64) ceps[(size_t)(t - ta) * nc + q] = lm[q];
+        } else if (a.top_db < 0.f) {
             auto dct_rows = [&](const float* tbl) {
                 for (int q0 = 0; q0 < nc; q0 += ncp) {
                     const int q = q0 + dq;

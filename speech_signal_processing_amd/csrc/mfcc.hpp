@@ -25,9 +25,10 @@ struct MfccArgs {
     const float* window;    // [n_fft] zero padded
     const float2* twiddle;  // [n_fft]  W_nfft^k = exp(-2 pi i k / n_fft)
     const int32_t* filt_lo4;   // [n_filt] first non-zero bin of each filter, rounded down to a multiple of 4
-    const float* filt_wT;      // per group of 64 filters [gsteps][64][4]: taps 4 s .. 4 s + 3 (from filt_lo4) of filter 64 g + l, zero padded
+    const float* filt_wT;      // per group of 64 filters [gsteps][filters in the group][4]: taps 4 s .. 4 s + 3 (from filt_lo4), zero padded
     const int32_t* filt_grp;   // [2][8] per group: 16-byte steps of its widest filter (even); offset of its block in filt_wT (16-byte units)
     int32_t filt_w4_total;     // 16-byte entries in filt_wT
+    int32_t dct_identity;      // n_ceps == n_filt and the DCT matrix is the identity: the log filterbank row is the output
     int32_t dct_ncp;           // DCT lanes per coefficient block: power of two >= min(n_ceps, 64)
     const float* dct;          // [n_ceps x n_filt]
     const float* dctT;         // [n_filt x n_ceps]

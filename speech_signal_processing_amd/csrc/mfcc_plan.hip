@@ -1,5 +1,6 @@
 // Host side of the MFCC pass: plan (device tables), framing rules, chunk work table, launch.
 #include <cmath>
+#include <cstdlib>
 
 #include "mfcc.hpp"
 
@@ -106,7 +107,8 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         // chunked work: 4 waves per workgroup and <= 80 KiB, so two workgroups share a CU; whole-utterance work (CMVN / top_db
         // inside the kernel): 8 waves when the utterance's rows still fit the 160 KiB, else 4
         MfccArgs tmp = p->args;  // (the table sizes the layout depends on)
-        const size_t half_cap = 80 * 1024;
+        size_t half_cap = 80 * 1024;
+        if (const char* e = getenv("SSP_GENERIC_LDS_CAP_KB")) half_cap = (size_t)atoi(e) * 1024;
         auto chunk_for = [&](const ssp_mfcc_cfg& cc) {
             int k = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
             while (k > 16 && generic_lds_layout(cc, k, 4, &tmp) > half_cap) k = (k * 3) / 4;
@@ -237,14 +239,23 @@ int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* win
     std::vector<int32_t> grp(16, 0);
     for (int g = 0; g < n_grp; ++g) {
         const int j1 = std::min(cfg->n_filt, g * 64 + 64);
-        int32_t taps = 0;
-        for (int j = g * 64; j < j1; ++j) {
-            lo4[j] = lo[j] & ~3;
-            taps = std::max(taps, len[j] + (lo[j] - lo4[j]));
+        // a filter's reads start at its first bin rounded down to 4 and cover `steps` 16-byte steps (the group's widest filter,
+        // rounded up to 2 steps); reads that would leave the wave buffer start earlier instead (leading zero taps)
+        int32_t steps = 2, taps = 0;
+        for (int pass = 0; pass < 8; ++pass) {
+            taps = 0;
+            const int lo_cap = std::max(0, (buf_floats - 4 * steps) & ~3);
+            for (int j = g * 64; j < j1; ++j) {
+                lo4[j] = std::min(lo[j] & ~3, lo_cap);
+                taps = std::max(taps, len[j] + (lo[j] - lo4[j]));
+            }
+            const int32_t need = std::max(2, ((taps + 7) / 8) * 2);
+            if (need <= steps) break;
+            steps = need;
         }
-        const int32_t steps = ((taps + 7) / 8) * 2;
+        const int nl = j1 - g * 64;
         for (int j = g * 64; j < j1; ++j)
-            if (lo4[j] + 4 * steps > buf_floats) {
+            if (lo4[j] + 4 * steps > buf_floats || len[j] + (lo[j] - lo4[j]) > 4 * steps) {
                 delete p;
                 SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: filter %d (bins %d..%d) next to %d-tap filters does not fit the kernel's spectrum row",
                          j, lo[j], lo[j] + len[j] - 1, taps);
@@ -252,14 +263,21 @@ int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* win
         grp[g] = steps;
         grp[8 + g] = (int32_t)(wT.size() / 4);
         const size_t base = wT.size();
-        wT.resize(base + (size_t)steps * 64 * 4, 0.f);
+        wT.resize(base + (size_t)steps * nl * 4, 0.f);
         for (int j = g * 64; j < j1; ++j)
             for (int k = 0; k < len[j]; ++k) {
                 const int tap = k + (lo[j] - lo4[j]);
-                wT[base + ((size_t)(tap / 4) * 64 + (j - g * 64)) * 4 + (tap & 3)] = w[(size_t)ofs[j] + k];
+                wT[base + ((size_t)(tap / 4) * nl + (j - g * 64)) * 4 + (tap & 3)] = w[(size_t)ofs[j] + k];
             }
     }
     ga.filt_w4_total = (int32_t)(wT.size() / 4);
+    ga.dct_identity = cfg->n_ceps == cfg->n_filt;
+    for (int q = 0; q < cfg->n_ceps && ga.dct_identity; ++q)
+        for (int j = 0; j < cfg->n_filt; ++j)
+            if (dct[(size_t)q * cfg->n_filt + j] != (q == j ? 1.f : 0.f)) {
+                ga.dct_identity = 0;
+                break;
+            }
     ga.dct_ncp = 1;
     while (ga.dct_ncp < std::min(cfg->n_ceps, 64)) ga.dct_ncp *= 2;
     std::vector<float> dctT((size_t)cfg->n_ceps * cfg->n_filt);
@@ -363,7 +381,12 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
             SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: frame segment %lld does not match the framing rule", (long long)u);
     }
     int v = variant;
-    if (v == 0) v = (mfcc_fast_supported(plan->cfg) && plan->fast_ready) ? 2 : 1;
+    if (v == 0) {
+        v = (mfcc_fast_supported(plan->cfg) && plan->fast_ready) ? 2 : 1;
+        // wide / dense filterbanks (e.g. the Bark rows of the PLP front end) fall to the fused kernel's banded LDS sweep, which the
+        // generic kernel's register-accumulated 4-tap reads beat (62 vs 75 ms at 21 x 257 taps)
+        if (v == 2 && plan->fast.melv == 0 && plan->max_filt_len > 64) v = 1;
+    }
     if (v == 2 && !(mfcc_fast_supported(plan->cfg) && plan->fast_ready))
         SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the fused fast kernel does not cover this cfg");
     if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_variant != v) {

@@ -75,6 +75,8 @@ class Data_gen:
 
     @functools.lru_cache(maxsize=4)
     def _plan(self, feature_type):
+        if feature_type == 'PLP':  # d_vector.py:92-93: plp(x, fs)[0]
+            return api.MfccPlan(api.default_context(), frontend.preset_sidekit_plp(fs=self.sample_rate))
         if feature_type != 'MFCC':
             raise NameError  # d_vector.py:94-95
         return api.MfccPlan(api.default_context(), frontend.preset_sidekit(fs=self.sample_rate))
@@ -94,7 +96,10 @@ class Data_gen:
             return [], []
         seg = api.Segments.from_lengths(plan.ctx, [sr] * len(chunks))
         fseg = plan.frame_segments(seg)
-        feats = np.asarray(plan.run(np.concatenate(chunks), seg, fseg), dtype=np.float64)
+        feats = plan.run(np.concatenate(chunks), seg, fseg)
+        if feature_type == 'PLP':
+            feats = api.plp_post(plan.ctx, feats, fseg, sr / 2.0)
+        feats = np.asarray(feats, dtype=np.float64)
         feature, label = [], []
         for i, lab in enumerate(labels):
             f = feats[fseg.offsets[i]:fseg.offsets[i + 1]]

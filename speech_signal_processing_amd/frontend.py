@@ -158,6 +158,44 @@ def preset_sidekit(fs=16000, nwin=0.025, shift=0.01, nlogfilt=24, nceps=13, lowf
                       dct2_ortho(nlogfilt, 1, nceps).astype(np.float32))  # c0 dropped
 
 
+def hz2bark(f):
+    return 6.0 * np.arcsinh(np.asarray(f, dtype=np.float64) / 600.0)
+
+
+def plp_num_bands(fs) -> int:
+    """sidekit / rastamat audspec default: ceil(hz2bark(fs / 2)) + 1 critical bands (21 at 16 kHz, 17 at 8 kHz)."""
+    return int(math.ceil(float(hz2bark(fs / 2.0)))) + 1
+
+
+def bark_filterbank(n_fft: int, fs: float, nfilts: int, width: float = 1.0, minfreq: float = 0.0, maxfreq: float = 8000.0) -> np.ndarray:
+    """rastamat fft2barkmx over the n_fft/2+1 rfft bins: 10^(min(0, min(hif, -2.5 lof) / width)) around Bark-spaced centres."""
+    maxfreq = min(float(maxfreq), fs / 2.0)
+    min_bark = float(hz2bark(minfreq))
+    nyqbark = float(hz2bark(maxfreq)) - min_bark
+    step = nyqbark / (nfilts - 1)
+    binbarks = hz2bark(np.arange(n_fft // 2 + 1) * fs / float(n_fft))
+    wts = np.zeros((nfilts, n_fft // 2 + 1))
+    for i in range(nfilts):
+        mid = min_bark + i * step
+        wts[i] = 10.0 ** (np.minimum(0.0, np.minimum(binbarks - mid + 0.5, -2.5 * (binbarks - mid - 0.5)) / width))
+    return wts
+
+
+def preset_sidekit_plp(fs=16000, nwin=0.025, shift=0.01, prefac=0.97) -> MfccTables:
+    """Front end of sidekit's plp up to ln(audspec(power_spectrum)): the sidekit framing / per-frame pre-emphasis / hanning /
+    power spectrum of ``preset_sidekit`` into Bark bands, natural log, identity "DCT" (n_ceps = n_filt = bands).  The back end
+    (RASTA ... lifter) is ``api.plp_post``.  sidekit's source is absent: restated from the rastamat algorithm it ports."""
+    win_len = int(round(nwin * fs))
+    hop = int(shift * fs)
+    n_fft = 1 << int(math.ceil(math.log2(win_len)))
+    nb = plp_num_bands(fs)
+    cfg = MfccConfig(sample_rate=int(fs), win_len=win_len, hop=hop, n_fft=n_fft, n_filt=nb, n_ceps=nb,
+                     frame_mode=FRAME_FLOOR, preemph_mode=1, preemph=float(prefac), spec_power=2, spec_scale=1.0,
+                     log_mode=LOG_LN, floor_mode=FLOOR_NONE, eps=0.0, top_db=-1.0, delta_order=0, delta_N=2, cmvn=0)
+    return MfccTables(cfg, np.hanning(win_len).astype(np.float32), bark_filterbank(n_fft, float(fs), nb).astype(np.float32),
+                      np.eye(nb, dtype=np.float32))
+
+
 def _slaney_mel(f):
     f = np.asarray(f, dtype=np.float64)
     lin = f * (3.0 / 200.0)

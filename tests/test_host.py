@@ -102,6 +102,10 @@ def test_fails_loudly_without_gpu():
         d_vector.cosine_scores(np.zeros((2, 4), np.float32), np.ones((3, 4), np.float32))
     with pytest.raises(_lib.SspError):
         GMM_UBM.delta(np.zeros((5, 3)))
+    with pytest.raises(_lib.SspError):
+        GMM_UBM.plp(np.zeros(16000, dtype=np.float32))                           # PLP features
+    with pytest.raises(_lib.SspError):
+        GMM_UBM.extract_feature([np.zeros(16000, dtype=np.float32)], [0], feature_type='PLP')
 
 
 def test_frame_count_and_dim_helpers_need_no_gpu():
@@ -149,3 +153,16 @@ def test_dft_tables_any_size():
         nb = L // 2 + 1
         re, im = Wt[:nb].astype(np.float64) @ x, Wt[nb:].astype(np.float64) @ x
         assert np.abs(bank @ np.abs(np.fft.fft(x)) - fold.astype(np.float64) @ np.sqrt(re * re + im * im)).max() < 1e-6
+
+
+def test_plp_front_tables_match_oracle():
+    """Bark filterbank / band count of the PLP front end against the oracle's restatement of fft2barkmx"""
+    import speech_signal_processing_amd as pkg
+    for fs in (8000, 16000, 44100):
+        t = pkg.preset_sidekit_plp(fs=fs)
+        cfg, w, fb, eye = O.sidekit_plp_tables(fs)
+        assert t.cfg.as_dict() == {k: pytest.approx(v) for k, v in cfg.items()}
+        assert t.cfg.n_filt == O.plp_num_bands(fs) == pkg.frontend.plp_num_bands(fs)
+        np.testing.assert_allclose(t.fbank, fb, rtol=1e-6, atol=1e-30)
+        np.testing.assert_allclose(t.window, w, atol=1e-7)
+        assert np.array_equal(t.dct, np.eye(t.cfg.n_filt, dtype=np.float32))

@@ -168,3 +168,58 @@ def test_dtw_path_oracle():
     assert abs(np.abs(x[p] - y[q]).sum() - d) < 1e-9 and abs(d - O.dtw_distance(x, y)) < 1e-12
     t = O.generate_template([x, y, rng.standard_normal(20)])
     assert t.shape == y.shape
+
+
+def test_plp_oracle_building_blocks():
+    """PLP restatement (parity unpinned: sidekit absent) — each block against an independent formulation."""
+    from scipy.linalg import solve_toeplitz
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(3)
+    # Levinson-Durbin = the Toeplitz normal equations; the error is r0 + a . r[1:]
+    x = rng.standard_normal(500)
+    r = np.correlate(x, x, "full")[499:499 + 13]
+    a, e = O.levinson(r, 12)
+    np.testing.assert_allclose(a, solve_toeplitz(r[:12], -r[1:13]), atol=1e-10)
+    assert abs(e - (r[0] + a @ r[1:13])) < 1e-9 * r[0]
+    # LPC -> cepstrum recursion = cepstrum of the all-pole spectrum 1 / |A(w)|^2 (c_n of ln(1/A), n >= 1)
+    poly = np.concatenate(([1.0], 0.5 * a))       # a stable polynomial
+    c = O.lpc2cep(poly[None, :] / 2.0, 13)[0]     # gain 2: c0 = ln 2
+    assert abs(c[0] - np.log(2.0)) < 1e-12
+    A = np.fft.fft(poly, 4096)
+    ceps = np.fft.ifft(-np.log(A)).real
+    np.testing.assert_allclose(c[1:], ceps[1:13], atol=1e-9)
+    # RASTA: four zero outputs, then the IIR started from the FIR-only state
+    xs = rng.standard_normal((50, 3)) + 5.0
+    y = O.rasta_filt(xs)
+    assert np.all(y[:4] == 0.0)
+    numer = np.array([0.2, 0.1, 0.0, -0.1, -0.2])
+    for b in range(3):
+        full = lfilter(numer, [1.0], xs[:, b])    # FIR part over everything
+        ref = np.zeros(50)
+        for t in range(4, 50):
+            ref[t] = full[t] + 0.94 * ref[t - 1]
+        np.testing.assert_allclose(y[:, b], ref, atol=1e-12)
+    # Bark bank: 21 bands at 16 kHz, 17 at 8 kHz, peak weight 1 inside every band, equal-loudness zero at 0 Hz
+    assert O.plp_num_bands(16000) == 21 and O.plp_num_bands(8000) == 17
+    w = O.fft2barkmx(512, 16000, 21)
+    assert w.shape == (21, 257) and np.allclose(w.max(axis=1), 1.0) and (w > 0).all()
+    eql = O.plp_equal_loudness(21, 8000.0)
+    assert eql[0] == 0.0 and np.all(np.diff(eql[:15]) > 0)
+    # autocorrelation in dolpc = real IDFT of the symmetric extension: lag 0 is the mean of the extended spectrum
+    spec = rng.uniform(0.5, 2.0, (4, 21))
+    lp = O.dolpc(spec, 12)
+    assert lp.shape == (4, 13) and np.isfinite(lp).all()
+
+
+def test_plp_oracle_shape_and_rasta_head():
+    """1 s at 16 kHz -> 98 x 13 (the only pinned fact, report/final.pdf IV-B-2); the first four frames carry the flat-spectrum
+    cepstrum because RASTA zeroes them in the log domain (rastamat behaviour)"""
+    rng = np.random.default_rng(4)
+    x = 0.3 * rng.standard_normal(16000)
+    c = O.sidekit_plp(x)[0]
+    assert c.shape == (98, 13) and np.isfinite(c).all()
+    assert np.allclose(c[:4], c[0]) and not np.allclose(c[4], c[0])
+    c2 = O.sidekit_plp(x, rasta=False)[0]
+    assert not np.allclose(c2[0], c2[1])
+    assert O.extract_feature_plp_one(x).shape == (98, 26)
+    assert O.sidekit_plp(x[:300])[0].shape == (0, 13)
