@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused fast kernel")
-    ap.add_argument("--stages", default="mfcc,gmm,gmm4,cosine,em,dnn,dvec,dtw")
+    ap.add_argument("--stages", default="mfcc,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
     ap.add_argument("--gmm4-utts", type=int, default=2000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
@@ -418,6 +418,23 @@ def main():
         _, ms = api.dtw_distances(ctx, Q, T, timing=True)
         result["dtw"] = {"metric": "DTW matcher, pairs/s (1222-element flattened MFCC sequences)", "value": nq * nt / ms * 1e3,
                          "unit": "pairs/s", "kernel_ms": ms, "cell_updates_per_s": nq * nt * L * L / ms * 1e3, "dtype": "f32"}
+
+    if "plp" in stages:
+        # PLP features (sidekit plp): Bark front end through the MFCC pass + RASTA / Levinson / cepstrum back end, on a slice of the
+        # resident audio
+        n_p = min(n_utt, 20000)
+        pplan = api.MfccPlan(ctx, pkg.preset_sidekit_plp(fs=fs))
+        pseg = api.Segments.from_lengths(ctx, np.full(n_p, n_samp, dtype=np.int64))
+        pfs = pplan.frame_segments(pseg)
+        logspec = torch.empty((pfs.total, pplan.d_out), dtype=torch.float32, device=device)
+        sl = flat[:n_p * n_samp]
+        pplan.run(sl, pseg, pfs, out=logspec)
+        api.plp_post(ctx, logspec, pfs, fs / 2.0)
+        _, ms_f = pplan.run(sl, pseg, pfs, out=logspec, timing=True)
+        _, ms_b = api.plp_post(ctx, logspec, pfs, fs / 2.0, timing=True)
+        result["plp"] = {"metric": "PLP frames/s (13-d, RASTA; Bark front end + LPC-cepstrum back end)", "value": pfs.total / (ms_f + ms_b) * 1e3,
+                         "unit": "frames/s", "front_ms": ms_f, "back_ms": ms_b, "utterances": n_p, "dtype": "f32"}
+        del logspec
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
