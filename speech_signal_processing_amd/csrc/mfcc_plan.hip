@@ -104,10 +104,11 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         lds = mfcc_fast_lds(c, tmp, ch);
         if (lds > lds_cap) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(fast): LDS footprint %zu B exceeds 160 KiB", lds);
     } else {
-        // chunked work: 4 waves per workgroup and <= 80 KiB, so two workgroups share a CU; whole-utterance work (CMVN / top_db
-        // inside the kernel): 8 waves when the utterance's rows still fit the 160 KiB, else 4
+        // chunked work: 4 waves per workgroup; the LDS cap sets how many workgroups share a CU (2 at n_fft 2048, whose registers allow
+        // no more; 3 at 1024; 4 below — measured, tools/dialect_bench.py); whole-utterance work (CMVN / top_db inside the kernel):
+        // 8 waves when the utterance's rows still fit the 160 KiB, else 4
         MfccArgs tmp = p->args;  // (the table sizes the layout depends on)
-        size_t half_cap = 80 * 1024;
+        size_t half_cap = (size_t)(c.n_fft >= 2048 ? 80 : (c.n_fft >= 1024 ? 53 : 40)) * 1024;
         if (const char* e = getenv("SSP_GENERIC_LDS_CAP_KB")) half_cap = (size_t)atoi(e) * 1024;
         auto chunk_for = [&](const ssp_mfcc_cfg& cc) {
             int k = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
