@@ -1050,3 +1050,24 @@ def test_extract_feature_plp(ssp):
     f, lab = d_vector.Data_gen(16000).extract_feature([sigs[4]], [7], feature_type='PLP')
     assert len(f) == 2 and lab == [7, 7] and f[0].shape == (98, 13)
     np.testing.assert_allclose(f[1], O.sidekit_plp(sigs[4][16000:32000])[0], atol=3e-4)
+
+
+def test_bit_reproducible_runs(ssp):
+    """the same inputs give bit-identical outputs run to run: generic kernel (incl. the two-pass top_db path, whose utterance maximum
+    is an atomic max), PLP, EM statistics (fused log-sum-exp, fixed-order float64 reduction)"""
+    pkg, api = ssp
+    from speech_signal_processing_amd import sidekit_features as SF
+    rng = np.random.default_rng(77)
+    sigs = [(0.3 * rng.standard_normal(n)).astype(np.float32) for n in (8000, 200000, 30011)]
+    for tables in (pkg.preset_librosa(16000, 13), pkg.preset_inrepo(16000, 1024, 512), pkg.preset_sidekit(delta_order=2, cmvn=1)):
+        a, _ = _run_plan(api, tables, sigs, variant=1)
+        b, _ = _run_plan(api, tables, sigs, variant=1)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    p1, _ = SF.plp_batch(sigs)
+    p2, _ = SF.plp_batch(sigs)
+    assert np.array_equal(np.asarray(p1), np.asarray(p2))
+    ctx = api.default_context()
+    X = rng.standard_normal((50000, 39)).astype(np.float32)
+    w = rng.dirichlet(5 * np.ones(64)); mu = rng.standard_normal((64, 39)); cov = rng.uniform(0.5, 2.0, (64, 39))
+    s1, s2 = api.gmm_em_stats(ctx, w, mu, cov, X), api.gmm_em_stats(ctx, w, mu, cov, X)
+    assert s1["loglik_sum"] == s2["loglik_sum"] and np.array_equal(s1["sx"], s2["sx"]) and np.array_equal(s1["nk"], s2["nk"])
