@@ -307,10 +307,13 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                 const v2f e = __builtin_elementwise_fma(zm[k2], v2f{1.f, -1.f}, zk);   // 2E = Z[k] + conj Z[256-k]
                 const v2f d = __builtin_elementwise_fma(zm[k2], v2f{-1.f, 1.f}, zk);   // 2D = Z[k] - conj Z[256-k]
                 const v2f o = cmul_negi(d, w);                                         // 2 (-i D) W^k
-                const v2f xa = e + o, xb = e - o;                                      // 2 X[k], conj(2 X[256-k])
-                const v2f sa = xa * xa, sb = xb * xb;
-                pa[k2] = sa.x + sa.y;
-                pb[k2] = sb.x + sb.y;
+                // 2 X[k] = e + o and conj(2 X[256-k]) = e - o in transposed form: R = (re, re'), I = (im, im'), so that both powers
+                // come out of one packed multiply + one packed FMA (the broadcasts are operand selects)
+                const v2f R = __builtin_elementwise_fma(xx(o), v2f{1.f, -1.f}, xx(e));
+                const v2f I = __builtin_elementwise_fma(yy(o), v2f{1.f, -1.f}, yy(e));
+                const v2f pw = __builtin_elementwise_fma(R, R, I * I);
+                pa[k2] = pw.x;
+                pb[k2] = pw.y;
                 if (POWER == 1) {
                     pa[k2] = __builtin_sqrtf(pa[k2]);
                     pb[k2] = __builtin_sqrtf(pb[k2]);
