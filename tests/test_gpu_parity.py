@@ -1071,3 +1071,40 @@ def test_bit_reproducible_runs(ssp):
     w = rng.dirichlet(5 * np.ones(64)); mu = rng.standard_normal((64, 39)); cov = rng.uniform(0.5, 2.0, (64, 39))
     s1, s2 = api.gmm_em_stats(ctx, w, mu, cov, X), api.gmm_em_stats(ctx, w, mu, cov, X)
     assert s1["loglik_sum"] == s2["loglik_sum"] and np.array_equal(s1["sx"], s2["sx"]) and np.array_equal(s1["nk"], s2["nk"])
+
+
+def test_baseline_configs0_plumbing_case(ssp):
+    """BASELINE.json configs[0] / SURVEY 8(d) cfg1, the reference's own CPU-runnable case: 100 synthetic 16 kHz 3 s utterances,
+    13-d MFCC (librosa preset: 94 frames / utterance; and the sidekit preset: 298), a 16-mix diagonal UBM + 10 speaker GMMs fitted
+    by sklearn GaussianMixture(16, 'diag', random_state=0), the full (100 x 10) score-difference matrix and its arg-max.
+    GPU features vs the float64 restatement; GPU scores vs the reference's double loop over sklearn .score()."""
+    from sklearn.mixture import GaussianMixture as SkGM
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd import GMM_UBM
+    fs, S = 16000, 10
+    sigs = [synth_audio(u, 48000, fs, S=S) for u in range(100)]
+    labels = np.array([u % S for u in range(100)])
+    # --- features, both third-party dialects of the reference
+    tl = pkg.preset_librosa(fs, 13)
+    got_l, _ = _run_plan(api, tl, sigs)
+    cfg, w, fb, dct = O.librosa_tables(fs, 13)
+    for u in (0, 17, 99):
+        ref = O.mfcc_pipeline(sigs[u], cfg, w, fb, dct)
+        assert got_l[u].shape == ref.shape == (94, 13)
+        assert np.abs(got_l[u] - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    got_s, _ = _run_plan(api, pkg.preset_sidekit(fs=fs), sigs)
+    assert all(g.shape == (298, 13) for g in got_s)
+    ref0 = O.sidekit_mfcc(sigs[3], fs=fs)[0]
+    assert np.abs(got_s[3] - ref0).max() <= 1e-4 * max(1.0, np.abs(ref0).max())
+    # --- models on the (float64) GPU features, as GMM_UBM.py:154-170 fits them
+    feats = [np.asarray(g, dtype=np.float64) for g in got_s]
+    gm = [SkGM(16, covariance_type="diag", random_state=0).fit(np.vstack([feats[u] for u in range(100) if labels[u] == s])) for s in range(S)]
+    ubm = SkGM(16, covariance_type="diag", random_state=0).fit(np.vstack(feats))
+    # --- the reference's scoring loop (GMM_UBM.py:181-197) vs one GPU launch
+    ref = np.array([[g.score(x) - ubm.score(x) for g in gm] for x in feats])
+    pred, amax = GMM_UBM.score_matrix(gm, ubm, feats)
+    assert pred.shape == (100, S)
+    assert np.abs(pred - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-4
+    assert (amax == ref.argmax(1)).all()
+    assert (amax == labels).mean() >= 0.9   # speakers differ by f0 = 90 + 3 s Hz: the recogniser works on this set
