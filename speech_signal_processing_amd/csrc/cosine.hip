@@ -259,12 +259,37 @@ __global__ __launch_bounds__(256) void cosine_reg_kernel(CosRegArgs a) {
     float ss = 0.f;
     {
         float* xs = wbuf + wave * (32 * 65);  // [32 rows][64 + 1 pad]
+        const bool vec = (d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
 #pragma unroll
         for (int kc = 0; kc < NQ / 8; ++kc) {
-            for (int i = lane; i < 32 * 64; i += 64) {
-                const int r = i >> 6, k = kc * 64 + (i & 63);
+            // 32 rows x 64 floats of this chunk = 512 float4: 8 per lane, all in flight together (a dword per iteration with a
+            // wait after each, as the first version had it, cost a memory latency 128 times per workgroup)
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = lane + 64 * u, r = idx >> 4, k = kc * 64 + 4 * (idx & 15);
                 const int64_t gc = col0 + r;
-                xs[r * 65 + (i & 63)] = (gc < a.N && k < d) ? a.X[gc * d + k] : 0.f;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gc < a.N) {
+                    const float* __restrict__ p = a.X + gc * d + k;
+                    if (vec && k + 3 < d) {
+                        v[u] = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (k < d) v[u].x = p[0];
+                        if (k + 1 < d) v[u].y = p[1];
+                        if (k + 2 < d) v[u].z = p[2];
+                        if (k + 3 < d) v[u].w = p[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = lane + 64 * u, r = idx >> 4, c = 4 * (idx & 15);
+                float* dst = xs + r * 65 + c;
+                dst[0] = v[u].x;
+                dst[1] = v[u].y;
+                dst[2] = v[u].z;
+                dst[3] = v[u].w;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -310,6 +335,8 @@ __global__ __launch_bounds__(256) void cosine_reg_kernel(CosRegArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b[q][e], acc, 0, 0, 0);
         }
+        // (running the epilogue one tile late, in the shadow of the next tile's MFMAs, measured no gain: the other workgroup's
+        // wave on the same SIMD already fills the matrix pipe while this one does its VALU work)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
