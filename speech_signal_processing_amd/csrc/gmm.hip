@@ -71,6 +71,39 @@ __device__ __forceinline__ float lse2_finish(float run_m, float run_s) {
     return (mm + __builtin_amdgcn_logf(ss)) * 0.6931471805599453f;
 }
 
+// this workgroup's frames (contiguous rows, n_floats = frames x D, a multiple of 4) into LDS: up to K float4 per thread, all in
+// flight together (a dword per loop trip with a wait behind each exposed ~D memory latencies per workgroup); zero beyond `tot`
+template <int K>
+__device__ __forceinline__ void stage_frames(float* __restrict__ xs, const float* __restrict__ src, int tot, int n_floats, int tid) {
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int n4 = n_floats >> 2;
+        float4 v[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int i4 = tid + 256 * u, i = 4 * i4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i4 < n4) {
+                if (i + 3 < tot) {
+                    v[u] = *reinterpret_cast<const float4*>(src + i);
+                } else {
+                    if (i < tot) v[u].x = src[i];
+                    if (i + 1 < tot) v[u].y = src[i + 1];
+                    if (i + 2 < tot) v[u].z = src[i + 2];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int i4 = tid + 256 * u;
+            if (i4 < n4) *reinterpret_cast<float4*>(xs + 4 * i4) = v[u];
+        }
+        for (int i4 = tid + 256 * K; i4 < n4; i4 += 256)  // (never taken while D <= 4 K)
+            for (int c = 0; c < 4; ++c) xs[4 * i4 + c] = 4 * i4 + c < tot ? src[4 * i4 + c] : 0.f;
+    } else {
+        for (int i = tid; i < n_floats; i += 256) xs[i] = i < tot ? src[i] : 0.f;
+    }
+}
+
 // NQ = k-depth / 8 of the packed image (k-depth >= 2D+1); CT = 32-frame column tiles per wave
 template <int NQ, int CT>
 __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
@@ -89,7 +122,7 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
     {
         const float* __restrict__ src = a.feats + f0 * D;
         const int tot = n_valid * D;
-        for (int i = tid; i < FRAMES_WG * D; i += 256) xs[i] = i < tot ? src[i] : 0.f;
+        stage_frames<CT * NQ / 2 + 1>(xs, src, tot, FRAMES_WG * D, tid);
     }
     stage_tile<NQ>(a.wimg, wbuf, wave, lane);  // row tile 0
     __syncthreads();
@@ -194,7 +227,7 @@ __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
     {
         const float* __restrict__ src = a.feats + f0 * D;
         const int tot = n_valid * D;
-        for (int i = tid; i < FRAMES_WG * D; i += 256) xs[i] = i < tot ? src[i] : 0.f;
+        stage_frames<CT * NK + 1>(xs, src, tot, FRAMES_WG * D, tid);
     }
     __syncthreads();
 
