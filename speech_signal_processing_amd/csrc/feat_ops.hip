@@ -16,66 +16,131 @@ __device__ __forceinline__ int find_segment(const int64_t* __restrict__ off, int
     return lo;
 }
 
+// a workgroup owns DELTA_RB consecutive rows: one binary search for the block's first row, then every element walks forward from
+// that segment (the first version searched 17 dependent levels per ELEMENT: 0.5 TB/s)
+constexpr int DELTA_RB = 64;
+
+template <int NC>  // NC > 0: compile-time half width (the reference's N = 2), all 2 N loads independent; 0: runtime N
 __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                    const int64_t* __restrict__ off, int n_seg, int dim, int N,
-                                                    float inv_den, int64_t row0, int64_t n_elem) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_elem; i += (int64_t)gridDim.x * 256) {
-        const int64_t row = row0 + i / dim;
-        const int d = (int)(i % dim);
-        const int u = find_segment(off, n_seg, row);
+                                                    const int64_t* __restrict__ off, int n_seg, int dim, int N_rt,
+                                                    float inv_den, int64_t row0, int64_t n_rows) {
+    const int N = NC > 0 ? NC : N_rt;
+    const int64_t r0 = (int64_t)blockIdx.x * DELTA_RB;
+    const int nr = (int)min<int64_t>(DELTA_RB, n_rows - r0);
+    const int base = find_segment(off, n_seg, row0 + r0);
+    for (int i = threadIdx.x; i < nr * dim; i += 256) {
+        const int r = i / dim, d = i - r * dim;
+        const int64_t row = row0 + r0 + r;
+        int u = base;
+        while (off[u + 1] <= row) ++u;  // (empty utterances are skipped too)
         const int64_t a = off[u], b = off[u + 1] - 1;  // edge padding inside the utterance (GMM_UBM.py:64)
         float acc = 0.f;
-        for (int m = 1; m <= N; ++m) {
-            const int64_t rp = row + m > b ? b : row + m, rm = row - m < a ? a : row - m;
-            acc += (float)m * (in[rp * dim + d] - in[rm * dim + d]);
+        if (NC > 0) {
+            float vp[NC > 0 ? NC : 1], vm[NC > 0 ? NC : 1];
+#pragma unroll
+            for (int m = 1; m <= NC; ++m) {
+                const int64_t rp = row + m > b ? b : row + m, rm = row - m < a ? a : row - m;
+                vp[m - 1] = in[rp * dim + d];
+                vm[m - 1] = in[rm * dim + d];
+            }
+#pragma unroll
+            for (int m = 1; m <= NC; ++m) acc += (float)m * (vp[m - 1] - vm[m - 1]);
+        } else {
+            for (int m = 1; m <= N; ++m) {
+                const int64_t rp = row + m > b ? b : row + m, rm = row - m < a ? a : row - m;
+                acc += (float)m * (in[rp * dim + d] - in[rm * dim + d]);
+            }
         }
         out[row * dim + d] = acc * inv_den;
     }
 }
 
-// one workgroup per utterance: mean, then variance about the mean (two passes), then normalise
-__global__ __launch_bounds__(256) void cmvn_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                   const int64_t* __restrict__ off, int dim) {
+// one workgroup per utterance: mean, then variance about the mean (two passes), then normalise.  Thread t owns column t % dim and
+// row phase t / dim, so a sweep of the workgroup reads whole consecutive rows (coalesced); utterances that fit the LDS budget are
+// read from HBM once.
+__global__ __launch_bounds__(256) void cmvn_kernel(const float* in, float* out,  // (in == out allowed)
+                                                   const int64_t* __restrict__ off, int dim, int lds_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);  // [4][dim] partials, then [dim] mean, [dim] inv std
+    float* red = reinterpret_cast<float*>(smem);  // [R][dim] partials
     const int u = blockIdx.x;
     const int64_t a = off[u];
     const int T = (int)(off[u + 1] - a);
     if (T == 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* mean = red + 4 * dim;
+    const int tid = threadIdx.x;
+    const int R = dim <= 256 ? 256 / dim : 1;     // row phases (dim > 256: threads stride over columns)
+    float* mean = red + R * (dim <= 256 ? dim : 256);
     float* istd = mean + dim;
-    const float* __restrict__ x = in + a * dim;
-    for (int d = wave; d < dim; d += 4) {
-        float s = 0.f;
-        for (int t = lane; t < T; t += 64) s += x[(size_t)t * dim + d];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float m = s / (float)T;
-        float v = 0.f;
-        for (int t = lane; t < T; t += 64) {
-            const float e = x[(size_t)t * dim + d] - m;
-            v = fmaf(e, e, v);
+    float* xl = istd + dim;                        // [lds_rows x dim] the utterance, when it fits
+    const float* x = in + a * dim;
+    const bool in_lds = T <= lds_rows;
+    const int tot = T * dim;
+    if (in_lds) {
+        for (int i0 = tid; i0 < tot; i0 += 256 * 8) {  // 8 loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = i0 + 256 * k < tot ? x[i0 + 256 * k] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i0 + 256 * k < tot) xl[i0 + 256 * k] = v[k];
         }
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        float sd = sqrtf(v / (float)T);
-        if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;  // sk: _handle_zeros_in_scale
-        if (lane == 0) {
-            mean[d] = m;
-            istd[d] = 1.0f / sd;
-        }
+        __syncthreads();
     }
-    __syncthreads();
-    float* __restrict__ y = out + a * dim;
-    for (int i = tid; i < T * dim; i += 256) {
+    const float* src = in_lds ? xl : x;
+    for (int c0 = 0; c0 < dim; c0 += 256) {  // one trip unless dim > 256
+        const int c = c0 + (dim <= 256 ? tid % dim : tid), ph = dim <= 256 ? tid / dim : 0;
+        const bool act = c < dim && ph < R;
+        float s = 0.f;
+        if (act)
+            for (int t = ph; t < T; t += R) s += src[(size_t)t * dim + c];
+        if (act) red[ph * (dim <= 256 ? dim : 256) + (c - c0)] = s;
+        __syncthreads();
+        if (act && ph == 0) {
+            float tot_s = 0.f;
+            for (int k = 0; k < R; ++k) tot_s += red[k * (dim <= 256 ? dim : 256) + (c - c0)];
+            mean[c] = tot_s / (float)T;
+        }
+        __syncthreads();
+        float v = 0.f;
+        if (act) {
+            const float m = mean[c];
+            for (int t = ph; t < T; t += R) {
+                const float e = src[(size_t)t * dim + c] - m;
+                v = fmaf(e, e, v);
+            }
+            red[ph * (dim <= 256 ? dim : 256) + (c - c0)] = v;
+        }
+        __syncthreads();
+        if (act && ph == 0) {
+            float tot_v = 0.f;
+            for (int k = 0; k < R; ++k) tot_v += red[k * (dim <= 256 ? dim : 256) + (c - c0)];
+            float sd = sqrtf(tot_v / (float)T);
+            if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;  // sk: _handle_zeros_in_scale
+            istd[c] = 1.0f / sd;
+        }
+        __syncthreads();
+    }
+    float* y = out + a * dim;
+    for (int i = tid; i < tot; i += 256) {
         const int d = i % dim;
-        y[i] = (x[i] - mean[d]) * istd[d];
+        y[i] = (src[i] - mean[d]) * istd[d];
     }
 }
 
-int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, hipStream_t stream) {
+static size_t cmvn_lds(int dim, int* lds_rows, int64_t max_T) {
+    const size_t fixed = ((size_t)256 + 2 * (size_t)dim) * sizeof(float);  // partials (<= 256 floats), mean, inv std
+    const size_t budget = 48 * 1024;                                       // three workgroups per CU
+    int64_t rows = fixed < budget ? (int64_t)((budget - fixed) / ((size_t)dim * sizeof(float))) : 0;
+    if (rows > max_T) rows = max_T;
+    *lds_rows = (int)rows;
+    return fixed + (size_t)rows * dim * sizeof(float);
+}
+
+int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, int64_t max_T, hipStream_t stream) {
     if (n_utt <= 0) return SSP_OK;
     if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cmvn: too many utterances");
-    hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)n_utt), dim3(256), (size_t)6 * dim * sizeof(float), stream, in, out, frame_off_dev, dim);
+    int lds_rows = 0;
+    const size_t lds = cmvn_lds(dim, &lds_rows, max_T);
+    hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)n_utt), dim3(256), lds, stream, in, out, frame_off_dev, dim, lds_rows);
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }
@@ -207,12 +272,16 @@ int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, i
     SSP_TRY(rc);
     int den = 0;
     for (int i = 1; i <= N; ++i) den += 2 * i * i;
-    const int64_t n_elem = rows * dim;
-    const int grid = (int)std::min<int64_t>(ceil_div<int64_t>(n_elem, 256), (int64_t)ctx->num_cu * 8);
+    const int64_t n_blocks = ceil_div<int64_t>(rows, DELTA_RB);
+    if (n_blocks > INT32_MAX || (int64_t)DELTA_RB * dim > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_delta: matrix too large for one launch");
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
-    hipLaunchKernelGGL(delta_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_in, d_out, frame_seg->dev.as<int64_t>(),
-                       (int)frame_seg->n, dim, N, 1.0f / (float)den, row0, n_elem);
+    if (N == 2)
+        hipLaunchKernelGGL(delta_kernel<2>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, d_in, d_out, frame_seg->dev.as<int64_t>(),
+                           (int)frame_seg->n, dim, N, 1.0f / (float)den, row0, rows);
+    else
+        hipLaunchKernelGGL(delta_kernel<0>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, d_in, d_out, frame_seg->dev.as<int64_t>(),
+                           (int)frame_seg->n, dim, N, 1.0f / (float)den, row0, rows);
     SSP_HIP(hipGetLastError());
     SSP_TRY(tm.stop(ctx->stream, kernel_ms));
     SSP_TRY(sout.back(ctx, out, bytes, where));
@@ -238,9 +307,7 @@ int ssp_cmvn(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, in
     SSP_TRY(rc);
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
-    hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)frame_seg->n), dim3(256), (size_t)6 * dim * sizeof(float), ctx->stream,
-                       d_in, d_out, frame_seg->dev.as<int64_t>(), dim);
-    SSP_HIP(hipGetLastError());
+    SSP_TRY(launch_cmvn(d_in, d_out, frame_seg->dev.as<int64_t>(), frame_seg->n, dim, frame_seg->max_len(), ctx->stream));
     SSP_TRY(tm.stop(ctx->stream, kernel_ms));
     SSP_TRY(sout.back(ctx, out, bytes, where));
     if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(ctx->stream));

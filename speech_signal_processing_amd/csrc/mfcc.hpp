@@ -84,7 +84,7 @@ struct FastArgs {
 
 int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, int n_waves, int num_cu, hipStream_t stream);
 // per-utterance CMVN over a feature matrix in global memory (feat_ops.hip; in == out allowed), any utterance length
-int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, hipStream_t stream);
+int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, int64_t max_T, hipStream_t stream);
 // second pass of the two-pass top_db path: per-utterance max of the log-mel rows, clamp at max - top_db, DCT rows -> out [F x n_ceps]
 int launch_topdb_dct(const float* logmel, const int64_t* frame_off_dev, int64_t n_utt, const MfccChunk* chunks, int n_chunks,
                      const float* utt_max, int n_filt, int n_ceps, const float* dct, float top_db, float* out, hipStream_t stream);

@@ -434,7 +434,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
         SSP_TRY(launch_topdb_dct(a.lm_out, frame_seg->dev.as<int64_t>(), frame_seg->n, a.chunks, plan->cache_n_chunks, a.utt_max,
                                  plan->cfg.n_filt, plan->cfg.n_ceps, plan->dct.as<float>(),
                                  plan->cfg.top_db, d_out, s));
-    if (plan->cache_split_cmvn) SSP_TRY(launch_cmvn(d_out, d_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->d_out, s));
+    if (plan->cache_split_cmvn) SSP_TRY(launch_cmvn(d_out, d_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->d_out, frame_seg->max_len(), s));
     SSP_TRY(tm.stop(s, kernel_ms));
     SSP_TRY(sout.back(plan->ctx, feats_out, out_bytes, where));
     if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(s));

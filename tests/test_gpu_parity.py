@@ -1108,3 +1108,27 @@ def test_baseline_configs0_plumbing_case(ssp):
     assert np.abs(pred - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-4
     assert (amax == ref.argmax(1)).all()
     assert (amax == labels).mean() >= 0.9   # speakers differ by f0 = 90 + 3 s Hz: the recogniser works on this set
+
+
+def test_delta_cmvn_ragged_batches(ssp):
+    """stand-alone delta / CMVN kernels on ragged batches: empty and one-row utterances between long ones, half widths 1..4,
+    dims that do and do not divide the workgroup, an utterance longer than the CMVN kernel's LDS rows (global-memory passes)"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    ctx = api.default_context()
+    rng = np.random.default_rng(5)
+    for dim, lens in ((13, [0, 1, 70, 0, 0, 3, 500, 64, 65, 2]), (39, [298, 1, 0, 2000]), (300, [5, 0, 17]), (7, [4000, 1])):
+        X = rng.standard_normal((sum(lens), dim)).astype(np.float32) * 3 + 1
+        seg = api.Segments.from_lengths(ctx, lens)
+        offs = np.concatenate(([0], np.cumsum(lens)))
+        for N in (1, 2, 3, 4):
+            got = np.asarray(api.delta_features(ctx, X, seg, N))
+            for u, T in enumerate(lens):
+                if T:
+                    ref = O.delta(X[offs[u]:offs[u + 1]].astype(np.float64), N)
+                    assert np.abs(got[offs[u]:offs[u + 1]] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (dim, N, u)
+        got = np.asarray(api.cmvn_features(ctx, X, seg))
+        for u, T in enumerate(lens):
+            if T:
+                ref = O.scale(X[offs[u]:offs[u + 1]].astype(np.float64))
+                assert np.abs(got[offs[u]:offs[u + 1]] - ref).max() <= 2e-4, (dim, u, T)
