@@ -376,22 +376,87 @@ static int launch_cos_reg(const CosRegArgs& a, hipStream_t s) {
     return SSP_OK;
 }
 
-// d_vector.py:310-313 — one workgroup per speaker; every thread owns output dimensions and walks the rows in order
-// (fixed summation order, float64 accumulator like numpy's mean on the reference's float64 `avg`)
+// d_vector.py:310-313 — one workgroup per speaker, rows summed IN ROW ORDER into a float64 accumulator (fixed summation order, like
+// numpy's mean on the reference's float64 `avg`).  The label array is scanned 2048 rows at a time with independent coalesced loads;
+// the matching rows are compacted, in order, into an LDS list (wave ballots + prefix counts), then every thread adds its columns of
+// the listed rows, four row loads in flight.  (The first version walked the labels one dependent load at a time: 82 ms at 1e6 rows.)
+constexpr int CEN_K = 8;  // 256-row slices per scan batch
+
 __global__ __launch_bounds__(256) void centroid_kernel(const float* __restrict__ X, const int32_t* __restrict__ labels, int64_t N, int d,
                                                        float* __restrict__ out) {
-    const int s = blockIdx.x;
-    for (int k0 = 0; k0 < d; k0 += 256) {
-        const int k = k0 + threadIdx.x;
-        double acc = 0.0;
+    __shared__ int32_t list[256 * CEN_K];  // row offsets (relative to the batch base) of this speaker, in row order
+    __shared__ int32_t wcnt[CEN_K][4];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int DM = 4;                  // columns per thread and sweep: d <= 1024 in one sweep
+    for (int k0 = 0; k0 < d; k0 += 256 * DM) {
+        double acc[DM];
+#pragma unroll
+        for (int j = 0; j < DM; ++j) acc[j] = 0.0;
         int64_t cnt = 0;
-        for (int64_t r = 0; r < N; ++r) {
-            if (labels[r] == s) {  // uniform across the workgroup
-                ++cnt;
-                if (k < d) acc += (double)X[r * d + k];
+        for (int64_t base = 0; base < N; base += 256 * CEN_K) {
+            int32_t lab[CEN_K];
+#pragma unroll
+            for (int k = 0; k < CEN_K; ++k) {
+                const int64_t r = base + 256 * k + tid;
+                lab[k] = r < N ? labels[r] : -1;
             }
+            unsigned long long bal[CEN_K];
+#pragma unroll
+            for (int k = 0; k < CEN_K; ++k) {
+                bal[k] = __ballot(lab[k] == s);
+                if (lane == 0) wcnt[k][wave] = __popcll(bal[k]);
+            }
+            __syncthreads();
+            int pos = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < CEN_K; ++k) {
+                int before = 0, all = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int c = wcnt[k][w];
+                    before += w < wave ? c : 0;
+                    all += c;
+                }
+                if (lab[k] == s) {
+                    pos = total + before + __popcll(bal[k] & ((1ull << lane) - 1ull));
+                    list[pos] = 256 * k + tid;
+                }
+                total += all;
+            }
+            __syncthreads();
+            cnt += total;
+            const float* __restrict__ xb = X + base * d;
+            int j = 0;
+            for (; j + 3 < total; j += 4) {
+                const int r0 = list[j], r1 = list[j + 1], r2 = list[j + 2], r3 = list[j + 3];
+#pragma unroll
+                for (int c = 0; c < DM; ++c) {
+                    const int col = k0 + 256 * c + tid;
+                    if (col < d) {
+                        const float v0 = xb[(size_t)r0 * d + col], v1 = xb[(size_t)r1 * d + col], v2 = xb[(size_t)r2 * d + col],
+                                    v3 = xb[(size_t)r3 * d + col];
+                        acc[c] += (double)v0;
+                        acc[c] += (double)v1;
+                        acc[c] += (double)v2;
+                        acc[c] += (double)v3;
+                    }
+                }
+            }
+            for (; j < total; ++j) {
+                const int r0 = list[j];
+#pragma unroll
+                for (int c = 0; c < DM; ++c) {
+                    const int col = k0 + 256 * c + tid;
+                    if (col < d) acc[c] += (double)xb[(size_t)r0 * d + col];
+                }
+            }
+            __syncthreads();  // the list is rewritten by the next batch
         }
-        if (k < d) out[(size_t)s * d + k] = (float)(acc / (double)cnt);
+#pragma unroll
+        for (int c = 0; c < DM; ++c) {
+            const int col = k0 + 256 * c + tid;
+            if (col < d) out[(size_t)s * d + col] = (float)(acc[c] / (double)cnt);
+        }
     }
 }
 
