@@ -99,6 +99,7 @@ struct ssp_mfcc_plan {
     ssp::DevBuf window, twiddle, filt_lo4, filt_grp, filt_wT, dct, dctT, fbank_dense;
     int32_t max_filt_len = 0;
     // cached work table for the last (sample_seg, frame_seg, variant) seen
+    uint64_t checked_sseg = 0, checked_fseg = 0;  // last (sample, frame) segment pair validated against the framing rule
     uint64_t cache_sseg = 0;  // ssp_segments::serial
     uint64_t cache_fseg = 0;
     int cache_variant = -1;
