@@ -244,10 +244,10 @@ struct CosRegArgs {
 };
 
 template <int NQ>
-__global__ __launch_bounds__(256) void cosine_reg_kernel(CosRegArgs a) {
+__global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_FLOATS = NQ * 256;
-    float* wbuf = reinterpret_cast<float*>(smem);  // [2][TILE_FLOATS]; the first bytes double as the X staging area
+    float* wbuf = reinterpret_cast<float*>(smem);  // [3][TILE_FLOATS / 2]; the first bytes double as the X staging area
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 31, h = lane >> 5;
@@ -309,34 +309,56 @@ __global__ __launch_bounds__(256) void cosine_reg_kernel(CosRegArgs a) {
     const float ix = 1.0f / sqrtf(ss);
     __syncthreads();  // staging area is about to be overwritten by tile 0
 
-    auto stage = [&](int tile, float* dst) {
-        const float* src = a.img + (size_t)tile * TILE_FLOATS;
+    // centroid tiles stream through a ring of THREE half-tile slots (k-halves of a 32-row tile, 16 KiB each at d = 256): 48 KiB per
+    // workgroup, so three workgroups share a CU and three waves a SIMD's matrix pipe (two full-tile buffers = 64 KiB allowed two)
+    constexpr int HALF = TILE_FLOATS / 2;
+    const int n_steps = 2 * a.n_tiles;
+    auto stage = [&](int step, int slot) {
+        const float* src = a.img + (size_t)step * HALF;
+        float* dst = wbuf + slot * HALF;
 #pragma unroll
-        for (int p = 0; p < NQ / 4; ++p) {
+        for (int p = 0; p < (NQ / 2 + 3) / 4; ++p) {
             const int piece = wave + 4 * p;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + piece * 256 + lane * 4), (lds_ptr_t)(dst + piece * 256), 16, 0, 0);
+            if (piece < NQ / 2)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + piece * 256 + lane * 4), (lds_ptr_t)(dst + piece * 256), 16, 0, 0);
         }
     };
-    stage(0, wbuf);
+    stage(0, 0);
+    stage(1, 1);
     __syncthreads();
 
     float best = INFINITY;
     int besti = 0x7fffffff;
     const int64_t gc = col0 + fl;
+    int slot = 0;  // slot of half-step 2 t
     for (int t = 0; t < a.n_tiles; ++t) {
-        const float* wcur = wbuf + (t & 1) * TILE_FLOATS;
-        if (t + 1 < a.n_tiles) stage(t + 1, wbuf + ((t + 1) & 1) * TILE_FLOATS);
+        const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        // ---- first k half
+        if (2 * t + 2 < n_steps) stage(2 * t + 2, s2);
+        {
+            const float* wcur = wbuf + slot * HALF;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(wcur + ((q * 2 + h) * 32 + fl) * 4);
+            for (int q = 0; q < NQ / 2; ++q) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(wcur + ((q * 2 + h) * 32 + fl) * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b[q][e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b[q][e], acc, 0, 0, 0);
+            }
         }
-        // (running the epilogue one tile late, in the shadow of the next tile's MFMAs, measured no gain: the other workgroup's
-        // wave on the same SIMD already fills the matrix pipe while this one does its VALU work)
+        __syncthreads();
+        // ---- second k half
+        if (2 * t + 3 < n_steps) stage(2 * t + 3, slot);
+        {
+            const float* wcur = wbuf + s1 * HALF;
+#pragma unroll
+            for (int q = 0; q < NQ / 2; ++q) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(wcur + ((q * 2 + h) * 32 + fl) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b[NQ / 2 + q][e], acc, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -351,6 +373,7 @@ __global__ __launch_bounds__(256) void cosine_reg_kernel(CosRegArgs a) {
             }
         }
         __syncthreads();
+        slot = s2;
     }
     const float ob = __shfl_xor(best, 32);
     const int oi = __shfl_xor(besti, 32);
@@ -366,7 +389,8 @@ __global__ __launch_bounds__(256) void cosine_reg_kernel(CosRegArgs a) {
 
 template <int NQ>
 static int launch_cos_reg(const CosRegArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)2 * NQ * 256 * sizeof(float) > (size_t)4 * 32 * 65 * 4 ? (size_t)2 * NQ * 256 * sizeof(float) : (size_t)4 * 32 * 65 * 4;
+    const size_t ring = (size_t)3 * NQ * 128 * sizeof(float), xst = (size_t)4 * 32 * 65 * 4;
+    const size_t lds = ring > xst ? ring : xst;
     const int64_t grid = ceil_div<int64_t>(a.N, 128);
     if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
     if (lds > 64 * 1024)
