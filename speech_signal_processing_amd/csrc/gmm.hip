@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
     constexpr int TILE_FLOATS = NQ * 2 * 32 * 4;
     constexpr int FRAMES_WG = 4 * CT * 32;
     float* wbuf = reinterpret_cast<float*>(smem);                   // [2][TILE_FLOATS]
-    float* xs = reinterpret_cast<float*>(smem) + 2 * TILE_FLOATS;   // [FRAMES_WG * D]
+    float* xs = reinterpret_cast<float*>(smem);                     // [FRAMES_WG * D], dead once the B operand sits in registers: the
+                                                                    // tile ring reuses its bytes (40 instead of 60 KiB at D = 39: three
+                                                                    // workgroups per CU, which the 161 registers allow)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane & 31, h = lane >> 5;
     const int D = a.D;
@@ -124,7 +126,6 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
         const int tot = n_valid * D;
         stage_frames<CT * NQ / 2 + 1>(xs, src, tot, FRAMES_WG * D, tid);
     }
-    stage_tile<NQ>(a.wimg, wbuf, wave, lane);  // row tile 0
     __syncthreads();
 
     // B operand (this wave's frames) in registers: b[ct][q][e] = aug[frame][8q + 2e + h]
@@ -142,6 +143,10 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
                 b[ct][q][e] = j < D ? v : (j < 2 * D ? v * v : (j == 2 * D ? 1.0f : 0.0f));
             }
     }
+
+    __syncthreads();  // every wave has its frames in registers: the staging bytes become the tile ring
+    stage_tile<NQ>(a.wimg, wbuf, wave, lane);  // row tile 0
+    __syncthreads();
 
     float run_m[CT], run_s[CT];
 #pragma unroll
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void gmm_utt_reduce_kernel(const float* __rest
 template <int NQ, int CT>
 static int launch_loglik(const GmmArgs& a, hipStream_t s) {
     constexpr int FRAMES_WG = 4 * CT * 32;
-    const size_t lds = (size_t)(2 * NQ * 2 * 32 * 4 + FRAMES_WG * a.D) * sizeof(float);
+    const size_t lds = std::max<size_t>((size_t)2 * NQ * 2 * 32 * 4, (size_t)FRAMES_WG * a.D) * sizeof(float);
     const int64_t grid = ceil_div<int64_t>(a.F, FRAMES_WG);
     if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many frames for one launch");
     if (lds > 64 * 1024)
