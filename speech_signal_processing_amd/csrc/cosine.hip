@@ -20,6 +20,10 @@ constexpr int BN = 128;  // embedding columns per workgroup
 constexpr int BK = 32;   // k-chunk
 constexpr int CPL = 128 * 4 + 4;  // floats per (q, h) plane of the operand image (+4 pad: conflict-free staging stores, csrc/dense.hip)
 
+struct __attribute__((packed, aligned(4))) f4u {  // 16-byte load at dword alignment (rows of any length)
+    float x, y, z, w;
+};
+
 struct CosArgs {
     const float* X;    // [N x d]
     const float* C;    // [S x d]
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restri
 // stage a [128 x BK] slab of a row-major matrix into the MFMA operand image [q=BK/8][h=2][row=128][e=4]:
 // element (row, k = 8q + 2e + h).  Returns the sum of squares of what this thread loaded (for the row norm).
 __device__ __forceinline__ float stage_slab(const float* __restrict__ A, int64_t row0, int64_t n_rows, int d, int k0,
-                                            float* __restrict__ img, int tid, bool vec) {
+                                            float* __restrict__ img, int tid) {
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -57,8 +61,9 @@ __device__ __forceinline__ float stage_slab(const float* __restrict__ A, int64_t
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gr < n_rows) {
             const float* __restrict__ p = A + gr * d + k;
-            if (vec && k + 3 < d) {
-                v = *reinterpret_cast<const float4*>(p);
+            if (k + 3 < d) {
+                const f4u t4 = *reinterpret_cast<const f4u*>(p);
+                v = make_float4(t4.x, t4.y, t4.z, t4.w);
             } else {
                 if (k < d) v.x = p[0];
                 if (k + 1 < d) v.y = p[1];
@@ -89,7 +94,6 @@ __global__ __launch_bounds__(256) void cosine_kernel(CosArgs a) {
     const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 waves, each 64 rows x 64 cols
     const int64_t col0 = (int64_t)blockIdx.x * BN;
     const int d = a.d;
-    const bool vec = (d & 3) == 0;
     const int n_kc = (d + BK - 1) / BK;
     const int n_rb = (a.S + BM - 1) / BM;
 
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(256) void cosine_kernel(CosArgs a) {
                 for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
         for (int kc = 0; kc < n_kc; ++kc) {
             __syncthreads();  // previous slab fully consumed
-            stage_slab(a.C, (int64_t)rb * BM, a.S, d, kc * BK, imgA, tid, vec);
-            const float s = stage_slab(a.X, col0, a.N, d, kc * BK, imgB, tid, vec);
+            stage_slab(a.C, (int64_t)rb * BM, a.S, d, kc * BK, imgA, tid);
+            const float s = stage_slab(a.X, col0, a.N, d, kc * BK, imgB, tid);
             if (rb == 0) xss += s;
             __syncthreads();
 #pragma unroll
@@ -259,7 +263,6 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
     float ss = 0.f;
     {
         float* xs = wbuf + wave * (32 * 65);  // [32 rows][64 + 1 pad]
-        const bool vec = (d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
 #pragma unroll
         for (int kc = 0; kc < NQ / 8; ++kc) {
             // 32 rows x 64 floats of this chunk = 512 float4: 8 per lane, all in flight together (a dword per iteration with a
@@ -272,8 +275,9 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (gc < a.N) {
                     const float* __restrict__ p = a.X + gc * d + k;
-                    if (vec && k + 3 < d) {
-                        v[u] = *reinterpret_cast<const float4*>(p);
+                    if (k + 3 < d) {
+                        const f4u t4 = *reinterpret_cast<const f4u*>(p);
+                        v[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
                     } else {
                         if (k < d) v[u].x = p[0];
                         if (k + 1 < d) v[u].y = p[1];

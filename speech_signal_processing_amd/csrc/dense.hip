@@ -25,10 +25,14 @@ struct DenseArgs {
     int32_t d_in, units, relu;
 };
 
+struct __attribute__((packed, aligned(4))) f4u {
+    float x, y, z, w;
+};
+
 // a [128 x DBK] slab of a row-major matrix goes global -> registers -> MFMA operand image [q=DBK/8][h=2] planes of [row=128][e=4]
 // (element (row, k = 8q + 2e + h)) in two steps: the loads of slab kc + 1 are issued before the MFMAs of slab kc and land under them
 __device__ __forceinline__ void dense_load(const float* __restrict__ A, int64_t row0, int64_t n_rows, int d, int k0, int tid,
-                                           bool vec, float4 (&v)[4]) {
+                                           float4 (&v)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * 256;
@@ -38,8 +42,9 @@ __device__ __forceinline__ void dense_load(const float* __restrict__ A, int64_t 
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gr < n_rows) {
             const float* __restrict__ p = A + gr * d + k;
-            if (vec && k + 3 < d) {
-                v[i] = *reinterpret_cast<const float4*>(p);
+            if (k + 3 < d) {  // one 16-byte load at dword alignment (rows of d_in = 98 x 13 = 1274 floats are only 8-byte aligned)
+                const f4u t = *reinterpret_cast<const f4u*>(p);
+                v[i] = make_float4(t.x, t.y, t.z, t.w);
             } else {
                 if (k < d) v[i].x = p[0];
                 if (k + 1 < d) v[i].y = p[1];
@@ -71,7 +76,6 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
     const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 waves, each 64 units x 64 samples
     const int64_t col0 = (int64_t)blockIdx.x * DBN;
     const int d = a.d_in;
-    const bool vec = (d & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.X) | reinterpret_cast<uintptr_t>(a.Wt)) & 15) == 0;
     const bool vst = (a.units & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0;
     const int n_kc = (d + DBK - 1) / DBK;
     const int n_rb = (a.units + DBM - 1) / DBM;
@@ -84,16 +88,16 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
         float4 va[4], vb[4];
-        dense_load(a.Wt, (int64_t)rb * DBM, a.units, d, 0, tid, vec, va);
-        dense_load(a.X, col0, a.N, d, 0, tid, vec, vb);
+        dense_load(a.Wt, (int64_t)rb * DBM, a.units, d, 0, tid, va);
+        dense_load(a.X, col0, a.N, d, 0, tid, vb);
         for (int kc = 0; kc < n_kc; ++kc) {
             __syncthreads();  // the previous slab is consumed
             dense_store(imgA, tid, va);
             dense_store(imgB, tid, vb);
             __syncthreads();
             if (kc + 1 < n_kc) {  // next slab: in flight during this slab's MFMAs (one LDS buffer: occupancy stays)
-                dense_load(a.Wt, (int64_t)rb * DBM, a.units, d, (kc + 1) * DBK, tid, vec, va);
-                dense_load(a.X, col0, a.N, d, (kc + 1) * DBK, tid, vec, vb);
+                dense_load(a.Wt, (int64_t)rb * DBM, a.units, d, (kc + 1) * DBK, tid, va);
+                dense_load(a.X, col0, a.N, d, (kc + 1) * DBK, tid, vb);
             }
 #pragma unroll
             for (int q = 0; q < DBK / 8; ++q) {
