@@ -135,10 +135,18 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    # SSP_BENCH_REHEARSE=1: every rank on device 0 over gloo — rehearses the multi-rank control flow on a one-GPU box (numbers are
+    # meaningless there); the driver's runs use one GPU per rank over RCCL
+    rehearse = bool(os.environ.get("SSP_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import speech_signal_processing_amd as pkg
     from speech_signal_processing_amd import api
@@ -185,7 +193,7 @@ def main():
     achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "mfcc_hbm_traffic.json")
-    if os.path.exists(pmc_file):
+    if os.path.exists(pmc_file) and n_utt == 100000 and n_samp == 48000:  # the PMC passes were taken on exactly this workload
         try:
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         except Exception:

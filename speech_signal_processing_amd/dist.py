@@ -48,6 +48,9 @@ def all_gather_rows(local, group=None):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
+    home = local.device
+    if dist.get_backend(group) == "gloo" and local.is_cuda:  # (CPU rehearsals of the multi-rank path: gloo moves host tensors)
+        local = local.cpu()
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
@@ -57,7 +60,7 @@ def all_gather_rows(local, group=None):
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0).to(home)
 
 
 def max_over_ranks(value: float, device=None) -> float:
@@ -65,6 +68,6 @@ def max_over_ranks(value: float, device=None) -> float:
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
