@@ -1132,3 +1132,23 @@ def test_delta_cmvn_ragged_batches(ssp):
             if T:
                 ref = O.scale(X[offs[u]:offs[u + 1]].astype(np.float64))
                 assert np.abs(got[offs[u]:offs[u + 1]] - ref).max() <= 2e-4, (dim, u, T)
+
+
+def test_centroids_shapes_and_order(ssp):
+    """centroid kernel across scan-batch boundaries (2048 rows), wide rows (> 1024 columns: second column sweep), one speaker,
+    a speaker whose rows all sit in the last partial batch; float64 row-order sums are bit-reproducible"""
+    pkg, api = ssp
+    ctx = api.default_context()
+    rng = np.random.default_rng(8)
+    for N, d, S in ((2048, 8, 3), (2049, 1100, 2), (6000, 256, 1), (4100, 33, 5)):
+        X = (rng.standard_normal((N, d)) * 2 + 0.5).astype(np.float32)
+        lab = rng.integers(0, S, N)
+        if S == 5:
+            lab[lab == 4] = 0
+            lab[4097:] = 4           # speaker 4 only in the last partial batch
+        got = np.asarray(api.centroids(ctx, X, lab, S))
+        again = np.asarray(api.centroids(ctx, X, lab, S))
+        assert np.array_equal(got, again, equal_nan=True)
+        for s in range(S):
+            ref = X[lab == s].astype(np.float64).mean(axis=0)
+            np.testing.assert_allclose(got[s], ref, rtol=0, atol=1e-6, err_msg=str((N, d, S, s)))
