@@ -163,8 +163,10 @@ __global__ __launch_bounds__(64) void gmm_em_lsesum_kernel(const float* __restri
 template <int NCT, bool FUSE>
 __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
     extern __shared__ float sm[];
-    const int D = a.D, W = 2 * D + 1, XS = D | 1, KS = (W + 1) / 2;  // KS k-steps of 2 over [x, x^2, 1] (+ a zero pad column)
-    float* xs = sm;                    // [64 frames][XS]
+    const int D = a.D, W = 2 * D + 1, KS = (W + 1) / 2;  // KS k-steps of 2 over [x, x^2, 1] (+ a zero pad column)
+    const int XS = (2 * KS) | 1;       // odd row stride of the augmented frame tile
+    float* xs = sm;                    // [64 frames][XS]  aug = [x, x^2, 1, 0]: the B operand of both GEMMs, read as it stands (forming
+                                       // x^2 / the constants per MFMA put branches and a dependent LDS read into the inner loops)
     float* wsT = xs + EM_TF * XS;      // [2 KS][64 mix]   parameter chunk, k-major: the A operand of GEMM1
     float* rs = wsT + 2 * KS * EM_KC;  // [64 frames][65]  responsibilities: the A operand of GEMM2
     float* ex = rs + EM_TF * 65;       // [2 mixture halves][64 frames][2]  (max, sum) exchange of the fused log-sum-exp
@@ -175,6 +177,10 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
     for (int i = tid; i < 2 * KS * EM_KC; i += 256) {
         const int k = i / EM_KC, m = i - k * EM_KC;
         wsT[i] = k < W ? a.par[(size_t)(kc + m) * W + k] : 0.f;
+    }
+    for (int i = tid; i < EM_TF * (2 * KS - 2 * D); i += 256) {  // the constant columns [1, 0...] of every row, written once
+        const int r = i / (2 * KS - 2 * D), c = i - r * (2 * KS - 2 * D);
+        xs[r * XS + 2 * D + c] = c == 0 ? 1.f : 0.f;
     }
     const int r1 = wave >> 1, c1 = wave & 1;  // GEMM1 tile of this wave
     f32x16 acc2[2][NCT];
@@ -210,7 +216,9 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
             const int i = tid + u * 256;
             if (i < EM_TF * D) {
                 const int r = i / D, c = i - r * D;
-                xs[r * XS + c] = xpre[u];
+                const float v = xpre[u];
+                xs[r * XS + c] = v;
+                xs[r * XS + D + c] = v * v;
             }
         }
         const float l = lpre;
@@ -221,15 +229,20 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
         const float* xrow = xs + (32 * c1 + fl) * XS;
-        for (int s2 = 0; s2 < KS; ++s2) {
-            const int k = 2 * s2 + h;
-            const float av = wsT[k * EM_KC + 32 * r1 + fl];
-            float bv;
-            if (k < D) bv = xrow[k];
-            else if (k < 2 * D) { const float t = xrow[k - D]; bv = t * t; }
-            else bv = k == 2 * D ? 1.f : 0.f;
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc1, 0, 0, 0);
+        const float* wcol = wsT + h * EM_KC + 32 * r1 + fl;
+        int s2 = 0;
+        for (; s2 + 3 < KS; s2 += 4) {  // four k-steps' operands in flight
+            float av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                av[u] = wcol[(2 * (s2 + u)) * EM_KC];
+                bv[u] = xrow[2 * (s2 + u) + h];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc1, 0, 0, 0);
         }
+        for (; s2 < KS; ++s2)
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[(2 * s2) * EM_KC], xrow[2 * s2 + h], acc1, 0, 0, 0);
         // ---- responsibilities of this lane's frame; accumulator i = mixture 32 r1 + (i & 3) + 8 (i >> 2) + 4 h
         const int fr = 32 * c1 + fl;
         if (FUSE) {
@@ -270,11 +283,7 @@ __global__ __launch_bounds__(256) void gmm_em_acc_mfma_kernel(EmArgs a) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
                 const int col = 32 * c + fl;
-                float t = 0.f;
-                if (col < D) t = xr[col];
-                else if (col < 2 * D) { t = xr[col - D]; t = t * t; }
-                else if (col == 2 * D) t = 1.f;
-                bv[c] = t;
+                bv[c] = col < 2 * KS ? xr[col] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -393,12 +402,18 @@ extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double
     const int XS = D | 1;
     const size_t lds1 = ((size_t)EM_TF * XS + (size_t)EM_KC * W + 512) * sizeof(float);
     const size_t lds2 = ((size_t)EM_TF * XS + (size_t)EM_KC * W + (size_t)EM_TF * 65) * sizeof(float);
-    const size_t lds3 = ((size_t)EM_TF * XS + (size_t)(W + 1) * EM_KC + (size_t)EM_TF * 65 + 256) * sizeof(float);
+    const size_t lds3 = ((size_t)EM_TF * ((W + 1) | 1) + (size_t)(W + 1) * EM_KC + (size_t)EM_TF * 65 + 256) * sizeof(float);
     const bool fuse = mfma && Kp == EM_KC && !getenv("SSP_EM_NO_FUSE");  // K <= 64: log-sum-exp inside the accumulation kernel
     if (lds1 > 64 * 1024)
         SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_lse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     if (lds2 > 64 * 1024)
         SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_em_acc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    if (mfma && lds3 > 64 * 1024) {
+        const void* ks[6] = {reinterpret_cast<const void*>(gmm_em_acc_mfma_kernel<1, true>), reinterpret_cast<const void*>(gmm_em_acc_mfma_kernel<2, true>),
+                             reinterpret_cast<const void*>(gmm_em_acc_mfma_kernel<3, true>), reinterpret_cast<const void*>(gmm_em_acc_mfma_kernel<1, false>),
+                             reinterpret_cast<const void*>(gmm_em_acc_mfma_kernel<2, false>), reinterpret_cast<const void*>(gmm_em_acc_mfma_kernel<3, false>)};
+        for (const void* k : ks) SSP_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    }
     // the per-frame log-sum-exp of the MFMA path comes from the scoring kernel (csrc/gmm.hip: fp32 MFMA, score_samples of ONE model)
     ssp_gmm* scorer = nullptr;
     ssp_segments* seg = nullptr;

@@ -1152,3 +1152,23 @@ def test_centroids_shapes_and_order(ssp):
         for s in range(S):
             ref = X[lab == s].astype(np.float64).mean(axis=0)
             np.testing.assert_allclose(got[s], ref, rtol=0, atol=1e-6, err_msg=str((N, d, S, s)))
+
+
+@pytest.mark.parametrize("K,D", [(3, 1), (64, 47), (70, 47), (17, 33), (5, 60)])
+def test_gmm_em_stats_shapes(ssp, K, D):
+    """EM statistics at the edges of the kernel families: D = 47 (widest MFMA case, > 64 KiB of LDS), K just over one 64-mixture
+    chunk (separate log-sum-exp pass), tiny D, D = 60 (VALU kernels); frame count not a multiple of the 64-frame tile"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(100 * K + D)
+    n = 5000 + 37
+    mu = rng.standard_normal((K, D)) * 1.5
+    X = (mu[rng.integers(0, K, n)] + rng.standard_normal((n, D))).astype(np.float32)
+    w = rng.dirichlet(5 * np.ones(K))
+    cov = rng.uniform(0.5, 2.0, (K, D))
+    st = api.gmm_em_stats(api.default_context(), w, mu, cov, X)
+    nk, sx, sxx, ll = O.gmm_em_stats(w, mu, cov, X.astype(np.float64))
+    assert abs(st["loglik_sum"] - ll) <= 2e-5 * abs(ll)
+    assert np.allclose(st["nk"], nk, rtol=2e-4, atol=2e-4 * nk.max())
+    assert np.allclose(st["sx"], sx, rtol=2e-4, atol=2e-4 * np.abs(sx).max())
+    assert np.allclose(st["sxx"], sxx, rtol=2e-4, atol=2e-4 * np.abs(sxx).max())
