@@ -66,7 +66,7 @@ __device__ __forceinline__ void dense_store(float* __restrict__ img, int tid, co
     }
 }
 
-__global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
+__global__ __launch_bounds__(256, 2) void dense_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SLAB = (DBK / 8) * 2 * DPL;
     float* imgA = reinterpret_cast<float*>(smem);  // weights (units)
@@ -87,18 +87,19 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
-        float4 va[4], vb[4];
+        // global -> register prefetch: the weights (L2 resident) one slab ahead, the samples (HBM, a TLB miss away) TWO slabs ahead —
+        // one slab of MFMAs (~2 us) did not cover their latency (PMC: matrix pipe 48 % busy, waves waiting on memory)
+        float4 va[4], vb0[4], vb1[4];
         dense_load(a.Wt, (int64_t)rb * DBM, a.units, d, 0, tid, va);
-        dense_load(a.X, col0, a.N, d, 0, tid, vb);
-        for (int kc = 0; kc < n_kc; ++kc) {
+        dense_load(a.X, col0, a.N, d, 0, tid, vb0);
+        dense_load(a.X, col0, a.N, d, DBK, tid, vb1);  // (beyond d_in: zeros)
+        auto slab = [&](int kc, float4 (&vb)[4]) {
             __syncthreads();  // the previous slab is consumed
             dense_store(imgA, tid, va);
             dense_store(imgB, tid, vb);
             __syncthreads();
-            if (kc + 1 < n_kc) {  // next slab: in flight during this slab's MFMAs (one LDS buffer: occupancy stays)
-                dense_load(a.Wt, (int64_t)rb * DBM, a.units, d, (kc + 1) * DBK, tid, va);
-                dense_load(a.X, col0, a.N, d, (kc + 1) * DBK, tid, vb);
-            }
+            if (kc + 1 < n_kc) dense_load(a.Wt, (int64_t)rb * DBM, a.units, d, (kc + 1) * DBK, tid, va);
+            if (kc + 2 < n_kc) dense_load(a.X, col0, a.N, d, (kc + 2) * DBK, tid, vb);
 #pragma unroll
             for (int q = 0; q < DBK / 8; ++q) {
                 f32x4 av[2], bv[2];
@@ -116,6 +117,10 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
                         for (int ct = 0; ct < 2; ++ct)
                             acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rt][e], bv[ct][e], acc[rt][ct], 0, 0, 0);
             }
+        };
+        for (int kc = 0; kc < n_kc; kc += 2) {
+            slab(kc, vb0);
+            if (kc + 1 < n_kc) slab(kc + 1, vb1);
         }
         // epilogue: accumulator register i of a lane = unit (i & 3) + 8 (i >> 2) + 4 h of the 32-unit tile, sample fl
 #pragma unroll
