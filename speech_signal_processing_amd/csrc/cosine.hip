@@ -220,7 +220,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // centroid image: [tile][q][h][row 32][e 4] = c_hat[tile*32 + row][8q + 2e + h]  (unit-norm rows, zero padded)
-__global__ __launch_bounds__(256) void cos_pack_kernel(const float* __restrict__ C, int S, int d, int nq, float* __restrict__ img) {
+__global__ __launch_bounds__(256) void cos_pack_kernel(const float* __restrict__ C, int S, int d, int nq, float* __restrict__ img,
+                                                       int normalize) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n_rows = ((S + 31) / 32) * 32;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void cos_pack_kernel(const float* __restrict__
     if (row < S)
         for (int k = lane; k < d; k += 64) ss = fmaf(C[(size_t)row * d + k], C[(size_t)row * d + k], ss);
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    const float inv = 1.0f / sqrtf(ss);
+    const float inv = normalize ? 1.0f / sqrtf(ss) : 1.0f;
     float* tile = img + (size_t)(row >> 5) * nq * 256;
     for (int k = lane; k < nq * 8; k += 64) {
         const float v = (row < S && k < d) ? C[(size_t)row * d + k] * inv : 0.f;
@@ -240,14 +241,18 @@ __global__ __launch_bounds__(256) void cos_pack_kernel(const float* __restrict__
 struct CosRegArgs {
     const float* X;
     const float* img;
-    float* dist;
+    const float* bias;  // DENSE mode: nullable [S]
+    int32_t relu;       // DENSE mode
+    float* dist;        // [N x S]: cosine distances (nullable) or, in DENSE mode, the layer output
     int32_t* argmin;
     float* minval;
     int64_t N;
     int32_t d, S, n_tiles;
 };
 
-template <int NQ>
+// DENSE: the same streaming GEMM as a fully connected layer (rows = units of an un-normalised packed weight image, epilogue = bias +
+// ReLU + 16-byte stores of Y[sample][unit]) — ssp_dense_forward for d_in <= 256, i.e. the hidden layers of the d-vector network
+template <int NQ, bool DENSE>
 __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_FLOATS = NQ * 256;
@@ -363,22 +368,50 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
                 for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b[NQ / 2 + q][e], acc, 0, 0, 0);
             }
         }
+        if (DENSE) {
+            if (gc < a.N) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (row < a.S) {
-                float dv = 1.0f - acc[i] * ix;
-                dv = fminf(fmaxf(dv, 0.0f), 2.0f);
-                if (a.dist && gc < a.N) a.dist[gc * a.S + row] = dv;
-                if (dv < best || (dv == best && row < besti)) {
-                    best = dv;
-                    besti = row;
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const int row = t * 32 + 8 * i4 + 4 * h;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float y = acc[i4 * 4 + e];
+                        if (row + e < a.S) {
+                            if (a.bias) y += a.bias[row + e];
+                            if (a.relu) y = fmaxf(y, 0.f);
+                        }
+                        v[e] = y;
+                    }
+                    float* yp = a.dist + gc * a.S + row;
+                    if ((a.S & 3) == 0 && row + 3 < a.S && (reinterpret_cast<uintptr_t>(a.dist) & 15) == 0) {
+                        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (row + e < a.S) yp[e] = v[e];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (row < a.S) {
+                    float dv = 1.0f - acc[i] * ix;
+                    dv = fminf(fmaxf(dv, 0.0f), 2.0f);
+                    if (a.dist && gc < a.N) a.dist[gc * a.S + row] = dv;
+                    if (dv < best || (dv == best && row < besti)) {
+                        best = dv;
+                        besti = row;
+                    }
                 }
             }
         }
         __syncthreads();
         slot = s2;
     }
+    if (DENSE) return;
     const float ob = __shfl_xor(best, 32);
     const int oi = __shfl_xor(besti, 32);
     if (ob < best || (ob == best && oi < besti)) {
@@ -391,15 +424,15 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
     }
 }
 
-template <int NQ>
+template <int NQ, bool DENSE = false>
 static int launch_cos_reg(const CosRegArgs& a, hipStream_t s) {
     const size_t ring = (size_t)3 * NQ * 128 * sizeof(float), xst = (size_t)4 * 32 * 65 * 4;
     const size_t lds = ring > xst ? ring : xst;
     const int64_t grid = ceil_div<int64_t>(a.N, 128);
     if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
     if (lds > 64 * 1024)
-        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_reg_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(cosine_reg_kernel<NQ>, dim3((unsigned)grid), dim3(256), lds, s, a);
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_reg_kernel<NQ, DENSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((cosine_reg_kernel<NQ, DENSE>), dim3((unsigned)grid), dim3(256), lds, s, a);
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }
@@ -488,6 +521,23 @@ __global__ __launch_bounds__(256) void centroid_kernel(const float* __restrict__
     }
 }
 
+// fully connected layer through the register-resident streaming GEMM (d_in <= 256): called by ssp_dense_forward (dense.hip)
+int launch_dense_reg(ssp_ctx* ctx, const float* dX, int64_t N, int d_in, const float* dW, const float* dB, int units, int relu, float* dY,
+                     hipStream_t s) {
+    const int nq = d_in <= 64 ? 8 : (d_in <= 128 ? 16 : (d_in <= 192 ? 24 : 32));
+    const int n_tiles = (units + 31) / 32;
+    DevBuf& img = ctx->scratch[0];
+    SSP_TRY(img.reserve((size_t)n_tiles * nq * 256 * sizeof(float)));
+    hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dW, units, d_in, nq, img.as<float>(), 0);
+    CosRegArgs ra{dX, img.as<float>(), dB, relu, dY, nullptr, nullptr, N, d_in, units, n_tiles};
+    switch (nq) {
+        case 8: return launch_cos_reg<8, true>(ra, s);
+        case 16: return launch_cos_reg<16, true>(ra, s);
+        case 24: return launch_cos_reg<24, true>(ra, s);
+        default: return launch_cos_reg<32, true>(ra, s);
+    }
+}
+
 }  // namespace ssp
 
 using namespace ssp;
@@ -546,9 +596,9 @@ int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, cons
         const int nq = d <= 64 ? 8 : (d <= 128 ? 16 : (d <= 192 ? 24 : 32));
         const int n_tiles = (S + 31) / 32;
         SSP_TRY(img.alloc((size_t)n_tiles * nq * 256 * sizeof(float)));
-        CosRegArgs ra{dX, img.as<float>(), dD, dA, dM, N, d, S, n_tiles};
+        CosRegArgs ra{dX, img.as<float>(), nullptr, 0, dD, dA, dM, N, d, S, n_tiles};
         SSP_TRY(tm.start(kernel_ms != nullptr, s));
-        hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>());
+        hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>(), 1);
         SSP_HIP(hipGetLastError());
         switch (nq) {
             case 8: SSP_TRY(launch_cos_reg<8>(ra, s)); break;

@@ -3,9 +3,14 @@
 // (units x d_in) . (d_in x samples) fp32 MFMA GEMM, output units as the MFMA rows and samples as the columns (the layout
 // of the cosine scorer, csrc/cosine.hip, whose operand image this kernel shares), bias + ReLU fused into the epilogue, four
 // consecutive units per 16-byte store.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace ssp {
+
+int launch_dense_reg(ssp_ctx* ctx, const float* dX, int64_t N, int d_in, const float* dW, const float* dB, int units, int relu, float* dY,
+                     hipStream_t s);  // cosine.hip
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -180,6 +185,15 @@ extern "C" int ssp_dense_forward(ssp_ctx* ctx, const float* X, int64_t N, int32_
     SSP_TRY(rc);
     float* dY = (float*)sy.out(Y, (size_t)N * units * sizeof(float), where, &rc);
     SSP_TRY(rc);
+    if (d_in <= 256 && !getenv("SSP_DENSE_NO_REG")) {  // samples held in registers, weight tiles streamed (cosine.hip): the network's hidden layers
+        Timer tr;
+        SSP_TRY(tr.start(kernel_ms != nullptr, s));
+        SSP_TRY(launch_dense_reg(ctx, dX, N, d_in, dW, dB, units, relu ? 1 : 0, dY, s));
+        SSP_TRY(tr.stop(s, kernel_ms));
+        SSP_TRY(sy.back(ctx, Y, (size_t)N * units * sizeof(float), where));
+        if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(s));
+        return SSP_OK;
+    }
     DenseArgs a{dX, dW, dB, dY, N, d_in, units, relu ? 1 : 0};
     constexpr size_t lds = (size_t)2 * (DBK / 8) * 2 * DPL * sizeof(float);
     Timer tm;
