@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
     ap.add_argument("--seconds", type=float, default=3.0)
-    ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused fast kernel")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused workgroup kernel | 3 fused wave-stream kernel")
     ap.add_argument("--stages", default="mfcc,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
     ap.add_argument("--gmm4-utts", type=int, default=2000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

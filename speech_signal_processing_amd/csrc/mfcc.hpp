@@ -82,6 +82,16 @@ struct FastArgs {
     int32_t n_chunks;  // log(max(v + log_add, log_max)) * log_k  (floor_mode / log_mode, branch free)
 };
 
+// wave-stream kernel (mfcc_stream.hip): every wave walks its own chunk; DCT / delta / delta-delta on the matrix cores
+struct StreamArgs {
+    const float* dctA;        // [KS][64] DCT matrix as the MFMA A operand: lane (ceps = l & 15, kq = l >> 4), k-step s <-> filter KS kq + s
+    int32_t* work_counter;    // next chunk to claim (zeroed before every launch)
+    int32_t n_chunks;
+    int32_t wave_bytes;       // LDS per wave: 4 frame images + sample stage + cepstrum ring
+    int32_t stage_bytes;      // sample stage (whole 1-KiB DMA pieces + a trailing 512-B half piece)
+    int32_t table_bytes;      // workgroup-shared DCT operand table in front of the wave regions
+};
+
 int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, int n_waves, int num_cu, hipStream_t stream);
 // per-utterance CMVN over a feature matrix in global memory (feat_ops.hip; in == out allowed), any utterance length
 int launch_cmvn(const float* in, float* out, const int64_t* frame_off_dev, int64_t n_utt, int dim, int64_t max_T, hipStream_t stream);
@@ -102,7 +112,8 @@ struct ssp_mfcc_plan {
     uint64_t checked_sseg = 0, checked_fseg = 0;  // last (sample, frame) segment pair validated against the framing rule
     uint64_t cache_sseg = 0;  // ssp_segments::serial
     uint64_t cache_fseg = 0;
-    int cache_variant = -1;
+    int cache_variant = -1;   // kernel the cached work table was laid out for (1 generic | 2 workgroup-fused | 3 wave-stream)
+    int cache_request = -1;   // variant argument that table answers (0 = auto: cache_variant is what auto resolved to)
     bool cache_split_cmvn = false;  // CMVN as a second kernel (an utterance exceeds one workgroup's chunk)
     bool cache_split_topdb = false; // top_db as a second kernel (log-mel rows through a global scratch)
     ssp::DevBuf lm_scratch, umax_scratch;
@@ -117,6 +128,9 @@ struct ssp_mfcc_plan {
     int64_t fast_max_samples = 0;  // longest utterance of the cached work table (32-bit offsets in the fast kernel)
     ssp::FastArgs fast{};
     ssp::DevBuf f_tw16, f_wpost, f_melw, f_mello, f_melid, f_dct, f_pcw, f_pcofs, f_pcmask, f_pcfid, f_scratch, f_counter;
+    // wave-stream kernel
+    bool stream_ready = false;
+    ssp::DevBuf s_dctA;
 };
 
 namespace ssp {
@@ -125,4 +139,7 @@ int build_fast_tables(ssp_mfcc_plan* plan);
 size_t mfcc_fast_lds(const ssp_mfcc_cfg& cfg, FastArgs& f, int chunk_frames);
 int mfcc_fast_max_chunk(const ssp_mfcc_cfg& cfg, const FastArgs& f);  // most frames one workgroup can take at once
 int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, int chunk_frames, hipStream_t stream);
+bool mfcc_stream_supported(const ssp_mfcc_plan* plan);  // cfg covered by the wave-stream kernel (alignment of a batch is checked per run)
+int build_stream_tables(ssp_mfcc_plan* plan);
+int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, hipStream_t stream);
 }  // namespace ssp

@@ -87,7 +87,19 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     const size_t lds_cap = 160 * 1024;
     int ch, nw = 4;
     size_t lds = 0;
-    if (variant == 2) {
+    // a failed build must not leave a half-written layout behind a valid cache key (the next run of the cached segment pair would launch
+    // with it): the key is dropped first and only restored at the end
+    p->cache_sseg = p->cache_fseg = 0;
+    p->cache_variant = p->cache_request = -1;
+    if (variant == 3) {
+        // wave-stream kernel: a chunk is a run of frames one WAVE walks alone (no LDS bound); whole utterances up to 512 frames, longer ones
+        // in 512-frame chunks with a recomputed 4-frame halo.  CMVN needs the whole utterance: always the stand-alone kernel afterwards.
+        for (int64_t u = 0; u < sseg->n; ++u)
+            if (sseg->host[u] & 3) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): utterance %lld does not start on a 16-byte boundary", (long long)u);
+        ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
+        split_cmvn = c.cmvn != 0;
+        whole = false;
+    } else if (variant == 2) {
         // persistent workgroups with a fixed LDS footprint; a chunk's cepstra (+ delta halo) and a block of output rows
         // share the wave regions in the delta tail, which bounds the chunk: whole utterances up to 512 frames, else chunks
         FastArgs tmp = p->fast;
@@ -302,6 +314,7 @@ int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* win
     if (rc == SSP_OK && mfcc_fast_supported(*cfg)) {
         const int frc = build_fast_tables(p);  // a filterbank the fused kernel cannot lay out only disables that kernel
         if (frc != SSP_OK && frc != SSP_ERR_UNSUPPORTED) rc = frc;
+        if (frc == SSP_OK && mfcc_stream_supported(p)) rc = build_stream_tables(p);
     }
     if (rc != SSP_OK) {
         delete p;
@@ -370,7 +383,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     SSP_TRY(use_ctx(plan->ctx));
     if (sample_seg->n != frame_seg->n) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: sample/frame segment counts differ");
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: where");
-    if (variant < 0 || variant > 2) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: variant");
+    if (variant < 0 || variant > 3) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: variant");
     const int64_t total_frames = frame_seg->total();
     const int64_t n_samp_total = sample_seg->host.back();
     if (kernel_ms) *kernel_ms = 0.f;
@@ -396,14 +409,26 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     }
     if (v == 2 && !(mfcc_fast_supported(plan->cfg) && plan->fast_ready))
         SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the fused fast kernel does not cover this cfg");
-    if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_variant != v) {
+    // (16-byte sample DMA: the batch's base address and every utterance start must sit on 16-byte boundaries)
+    const bool stream_ok = plan->stream_ready && mfcc_stream_supported(plan) && (where == SSP_HOST || (reinterpret_cast<uintptr_t>(samples) & 15) == 0);
+    if (v == 3 && !stream_ok) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the wave-stream kernel does not cover this cfg");
+    if (variant == 0 && v == 2 && stream_ok) v = 3;
+    // the work table is cached per (segment pair, REQUESTED variant): an auto request that fell back to another kernel is remembered
+    // as such instead of being rebuilt (chunk table upload + stream sync) on every call
+    if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_request != variant) {
         int brc = build_work(plan, sample_seg, frame_seg, v);
+        if (brc == SSP_ERR_UNSUPPORTED && variant == 0 && v == 3) {  // auto: unaligned utterance starts go to the workgroup kernel
+            v = 2;
+            brc = build_work(plan, sample_seg, frame_seg, v);
+        }
         if (brc == SSP_ERR_UNSUPPORTED && variant == 0 && v == 2) {  // auto: a batch the fused kernel cannot lay out goes to the generic one
             v = 1;
             brc = build_work(plan, sample_seg, frame_seg, v);
         }
         SSP_TRY(brc);
+        plan->cache_request = variant;
     }
+    v = plan->cache_variant;
 
     hipStream_t s = plan->ctx->stream;
     Staged sin, sout;
@@ -432,7 +457,9 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     a.chunks = plan->chunks.as<MfccChunk>();
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, s));
-    if (v == 2)
+    if (v == 3)
+        SSP_TRY(launch_mfcc_stream(a, plan, plan->cache_n_chunks, s));
+    else if (v == 2)
         SSP_TRY(launch_mfcc_fast(a, plan, plan->cache_n_chunks, plan->cache_chunk_frames, s));
     else
         SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, plan->cache_waves, plan->ctx->num_cu, s));

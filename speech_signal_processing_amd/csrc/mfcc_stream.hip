@@ -1,0 +1,560 @@
+// mfcc_stream512_kernel — the throughput kernel of the fused MFCC pass for n_fft == 512 dialects with 13 cepstra, <= 48 filters and
+// N = 2 regression deltas (the reference's sidekit call sites GMM_UBM.py:89 / d_vector.py:91 and its own utils/processing.py:110-144).
+//
+// Every WAVE is an independent stream: it claims a chunk (a run of consecutive frames of one utterance) from a global counter and
+// walks it four frames ("quad") at a time, 16 lanes per frame, with no workgroup barrier, no global scratch and no separate delta
+// pass.  Front end per quad = mfcc_fused512_kernel's (mfcc_fast.hip): LDS-DMA sample stage, pre-emphasis + window, radix-16 x
+// radix-16 FFT through a swizzled LDS transpose, split step, register-resident piece filterbank, hardware log.
+// Back end on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32):
+//   * DCT per quad: C[ceps][frame] = DCT[ceps][filter] . LM^T[filter][frame]; the log-mel rows are the B operand straight from
+//     the frame images, the DCT matrix is the A operand (KS VGPRs); the cepstra of the quad's frames go to a 24-frame ring in
+//     wave-private LDS (64 B per frame)
+//   * every 4th quad (16 new frames): delta = T . c and delta-delta = T . delta as banded "time" products, T[t][t'] = regression
+//     weight of frame t' in delta[t] INCLUDING the reference's edge padding (GMM_UBM.py:64 pads with the first / last row, so
+//     weights that fall outside [0, T) fold onto frame 0 / T-1; the A operands are generated from lane ids).  The accumulator
+//     layout of one product (frames = rows in registers, cepstra = columns on lanes) is exactly the B-operand layout of the next
+//     one, so c -> delta -> delta-delta chains without any data movement.  Rows [16 b - 4, 16 b + 12) x (c, delta, delta-delta)
+//     leave with bounds-checked 4-byte buffer stores (13 store instructions per 16 frames).
+// HBM sees every sample once and every feature once; nothing else.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+#include "mfcc.hpp"
+#include "cplx.hpp"
+
+namespace ssp {
+
+namespace {
+constexpr int ZROW = 128;          // bytes per 16-complex row of a frame's transpose image (chunks XOR-swizzled, see mfcc_fast.hip)
+constexpr int ZFRAME = 16 * ZROW;  // 2048 B per frame
+constexpr int LM_OFF = 1792;       // log-mel row of frame g sits at LM_OFF - 64 g inside its image (behind the P row)
+constexpr int RING_FRAMES = 24;    // cepstrum ring: the 16 newest frames + 8 of history (delta-delta reaches back 4 + 4)
+constexpr int RING_ROW = 64;       // bytes per ring row: 16 cepstral slots (13 used)
+constexpr int STREAM_WAVES = 4;
+
+__device__ __forceinline__ float stream_log(const FastArgs& f, float v) {
+    return __builtin_amdgcn_logf(fmaxf(v + f.log_add, f.log_max)) * f.log_k;
+}
+
+// weight of frame tp in delta[t] for the N = 2 regression with edge replication (GMM_UBM.py:53-69): sum over u in [t-2, t+2] with
+// clamp(u, 0, T-1) == tp of (u - t) * inv_denom;  half_inv = inv_denom / 2.  All quantities are small integers held in floats.
+__device__ __forceinline__ float delta_weight(float t, float tp, float Tm1, float half_inv) {
+    const float lo = tp <= 0.f ? -1.0e6f : tp;
+    const float hi = tp >= Tm1 ? 1.0e6f : tp;
+    const float a = fmaxf(lo, t - 2.f), b = fminf(hi, t + 2.f);
+    const float cnt = fmaxf(b - a + 1.f, 0.f);
+    const float w = cnt * (a + b - 2.f * t) * half_inv;
+    return (tp < 0.f || tp > Tm1) ? 0.f : w;
+}
+}  // namespace
+
+// NZ / POWER / PRE / MELV as in mfcc_fused512_kernel; KS = 4-filter k-steps of the DCT product (n_filt <= 4 KS); NS = DPP scan
+// steps of the piece filterbank (a filter's pieces span <= 2^NS lanes)
+template <int NZ, int POWER, int PRE, int MELV, int KS, int NS>
+__global__ __launch_bounds__(64 * STREAM_WAVES, 3) void mfcc_stream512_kernel(MfccArgs a, FastArgs f, StreamArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    constexpr int nc = 13;
+    constexpr int mel_ns = NS;
+
+    char* zbuf = smem + wave * sa.wave_bytes;            // 4 frame images
+    float* stage = reinterpret_cast<float*>(zbuf + 4 * ZFRAME);
+    char* ring = zbuf + 4 * ZFRAME + sa.stage_bytes;     // [RING_FRAMES][16] floats
+
+    // ---- lane-resident tables (as mfcc_fast.hip): window taps, twiddles, piece filterbank
+    v2f wreg[NZ];
+#pragma unroll
+    for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
+    // Register diet (168 VGPRs = three waves per SIMD, and 52 KiB of LDS per workgroup = three workgroups per CU, leave no room for
+    // tables anywhere else): twiddles W_256^(k1 j) are resident for k1 <= 8 and W^(k1 j) = W^((k1 - 8) j) W^(8 j) above; split twiddles
+    // W_512^(j + 16 i) for i < 4 and times W_8 above; that pays for the DCT matrix as resident MFMA A operand
+    // (lane (ceps = j, kq = g), k-step s <-> filter KS g + s)
+    v2f twr[8], wpr[4];
+#pragma unroll
+    for (int k1 = 1; k1 <= 8; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
+    float dA[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) dA[s] = sa.dctA[s * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);
+    v4f mw[MELV];
+    int mofs[MELV];
+#pragma unroll
+    for (int i = 0; i < MELV; ++i) {
+        mw[i] = *reinterpret_cast<const v4f*>(f.pc_w + ((size_t)lane * MELV + i) * 4);
+        mofs[i] = f.pc_ofs[lane * MELV + i];
+    }
+    const v2f mk01 = *reinterpret_cast<const v2f*>(f.pc_mask + lane * 4);
+    const v2f mk23 = NS > 2 ? *reinterpret_cast<const v2f*>(f.pc_mask + lane * 4 + 2) : v2f{0.f, 0.f};
+    const int mfid = f.pc_fid[lane];
+
+    const int hop = a.hop;
+    const float pre = PRE ? a.preemph : 0.f;
+    const float npre = -pre;
+    const int n_piece = (f.slen + 255) >> 8;
+    const bool has_half = (f.slen & 255) != 0 && (f.slen & 255) <= 128;
+    const int n_full = has_half ? n_piece - 1 : n_piece;
+    const int dord = a.delta_order;
+    const int Dd = a.d_out;
+    const float half_inv = 0.5f * a.delta_inv_denom;
+    const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)stage);
+
+#ifdef SSP_S_CLOCK  // diagnostic build: shader clock (s_memtime) against the 100 MHz constant clock (s_memrealtime) over the kernel's life
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (;;) {
+        int cidx = 0;
+        if (lane == 0) cidx = atomicAdd(sa.work_counter, 1);
+        cidx = __builtin_amdgcn_readfirstlane(cidx);
+        if (cidx >= sa.n_chunks) break;
+        const MfccChunk ch = a.chunks[cidx];
+        const int64_t s0 = a.sample_off[ch.utt];
+        const int64_t N = a.sample_off[ch.utt + 1] - s0;
+        const int64_t f0 = a.frame_off[ch.utt];
+        const int T = __builtin_amdgcn_readfirstlane((int)(a.frame_off[ch.utt + 1] - f0));
+        const int t0 = __builtin_amdgcn_readfirstlane(ch.t0), n = __builtin_amdgcn_readfirstlane(ch.n);
+        const int H = 2 * dord;
+        const int ta = max(t0 - H, 0), tb = min(t0 + n + H, T);
+        const int R = tb - ta;                     // frames computed (relative index r = t - ta)
+        const int nquads = (R + 3) >> 2;
+        const int E = t0 + n - ta;                 // emitted frames end (relative)
+        const int n_steps = (E + 4 + 15) >> 4;     // step b emits rows [16 b - 4, 16 b + 12)
+        const int Q = 4 * n_steps;
+        const float Tm1 = (float)(T - 1);
+
+        const uint64_t xaddr = reinterpret_cast<uint64_t>(a.samples + s0);
+        const uint32_t xlo = __builtin_amdgcn_readfirstlane((uint32_t)xaddr), xhi = __builtin_amdgcn_readfirstlane((uint32_t)(xaddr >> 32));
+        const int xbytes = __builtin_amdgcn_readfirstlane((int)(N * 4));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<float*>(((uint64_t)xhi << 32) | xlo), 0, xbytes, 0x00020000);
+        const uint64_t oaddr = reinterpret_cast<uint64_t>(a.out + (size_t)f0 * Dd);
+        const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t)oaddr), ohi = __builtin_amdgcn_readfirstlane((uint32_t)(oaddr >> 32));
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<float*>(((uint64_t)ohi << 32) | olo), 0, __builtin_amdgcn_readfirstlane(T * Dd * 4), 0x00020000);
+
+        // sample DMA of quad q: slen floats from (ta + 4 q) hop, 1-KiB pieces (instruction offsets advance the global and the
+        // LDS address together), a trailing half piece on lanes 0..31; outside [0, N) reads as zero
+        auto prefetch = [&](int q) {
+            const int vo = (ta + 4 * q) * hop * 4 + lane * 16;
+            const lds_ptr_t lp = (lds_ptr_t)(uintptr_t)stage_lds;
+            if (n_full > 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lp, 16, vo, 0, 0, 0);
+            if (n_full > 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lp, 16, vo, 0, 1024, 0);
+            if (n_full > 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lp, 16, vo, 0, 2048, 0);
+            if (n_full > 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lp, 16, vo, 0, 3072, 0);
+            if (n_full > 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(stage_lds + 4096), 16, vo + 4096, 0, 0, 0);
+            if (has_half && lane < 32)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(stage_lds + n_full * 1024), 16, vo + n_full * 1024, 0, 0, 0);
+        };
+
+        // zero the cepstrum ring: frames before the chunk's first one must read as finite values (their weights are zero)
+        {
+            v4f z4 = v4f{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<v4f*>(ring + lane * 16) = z4;
+            if (lane < (RING_FRAMES * RING_ROW - 1024) / 16) *reinterpret_cast<v4f*>(ring + 1024 + lane * 16) = z4;
+        }
+        prefetch(0);
+        int stores_pending = 0;  // buffer stores issued behind the DMA that is waited for at the top of the next iteration
+
+        for (int q = 0; q < Q; ++q) {
+            if (q < nquads) {
+                const int t = ta + 4 * q + g;  // this lane group's frame
+                v2f z[16];
+                v2f pf[NZ];
+                v2f pm[PRE ? NZ : 1];
+                // the quad's DMA has landed; the stores of a preceding step were issued behind it and may still be in flight
+                if (stores_pending == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (stores_pending == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (stores_pending == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                stores_pending = 0;
+                // the stage comes to registers in two halves (the first is windowed into z while the second is in flight: all of it
+                // at once is the register peak of the kernel)
+                constexpr int NH = (NZ + 1) / 2;
+                const float* sp = stage + g * hop + 2 * j;
+#pragma unroll
+                for (int n1 = 0; n1 < NH; ++n1) {
+                    pf[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1);
+                    if (PRE) pm[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1 - 2);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (PRE) pm[0].y = (j == 0) ? pf[0].x : pm[0].y;     // y[0] = x[0] - a x[0]
+#pragma unroll
+                for (int n1 = 0; n1 < NH; ++n1) {
+                    v2f y = pf[n1];
+                    if (PRE) {
+                        const float xm1 = pm[n1].y, x0 = y.x, x1 = y.y;
+                        y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
+                    }
+                    z[n1] = y * wreg[n1];
+                }
+#pragma unroll
+                for (int n1 = NH; n1 < NZ; ++n1) {
+                    pf[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1);
+                    if (PRE) pm[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1 - 2);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is in registers: the next quad may overwrite it
+#ifndef SSP_S_NODMA
+                prefetch(q + 1);                                     // flies under this whole iteration (past the end: zeros)
+#endif
+#pragma unroll
+                for (int n1 = NH; n1 < 16; ++n1) {
+                    if (n1 < NZ) {
+                        v2f y = pf[n1 < NZ ? n1 : 0];
+                        if (PRE) {
+                            const float xm1 = pm[n1 < NZ ? n1 : 0].y, x0 = y.x, x1 = y.y;
+                            y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
+                        }
+                        z[n1] = y * wreg[n1 < NZ ? n1 : 0];
+                    } else {
+                        z[n1] = v2f{0.f, 0.f};
+                    }
+                }
+                // ---- FFT16 over n1, twiddle W_256^(n2 k1)
+                fft16(z);
+#pragma unroll
+                for (int k1 = 1; k1 < 16; ++k1) {
+                    z[k1] = cmul(z[k1], twr[(k1 - 1) & 7]);
+                    if (k1 > 8) z[k1] = cmul(z[k1], twr[7]);
+                }
+                // ---- transpose through LDS (rows of 128 B, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
+                char* zf = zbuf + g * ZFRAME;
+                {
+                    int wb0 = ((j >> 1) << 4) | ((j & 1) << 3);
+                    asm volatile("" : "+v"(wb0));
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        char* wp = zf + (wb0 ^ (m << 4));
+                        *reinterpret_cast<v2f*>(wp + (2 * m) * ZROW) = z[2 * m];
+                        *reinterpret_cast<v2f*>(wp + (2 * m + 1) * ZROW) = z[2 * m + 1];
+                    }
+                    int rb0 = j * ZROW + (((j >> 1) & 7) << 4);
+                    asm volatile("" : "+v"(rb0));
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const v4f r = *reinterpret_cast<const v4f*>(zf + (rb0 ^ (c << 4)));
+                        z[2 * c] = v2f{r.x, r.y};
+                        z[2 * c + 1] = v2f{r.z, r.w};
+                    }
+                }
+                // ---- FFT16 over n2: lane j = k1, register = k2
+                fft16(z);
+                // ---- split step of the real FFT (partners from lane 16 - j by two DPP row permutes), power / magnitude -> P row
+                {
+                    float* P = reinterpret_cast<float*>(zf);
+                    float* Pm = P + 144 - j;
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) {
+                        // partner Z[256 - k] from lane 16 - j (lane 0: its own register 16 - k2): row_mirror, then row_shr:1 with `old`
+                        const float sx = z[15 - k2].x, sy = z[15 - k2].y;
+                        const v2f own = z[(16 - k2) & 15];
+                        const float ox = own.x, oy = own.y;
+                        float mx = __builtin_amdgcn_update_dpp(sx, sx, 0x140 /*row_mirror*/, 0xF, 0xF, true);
+                        float my = __builtin_amdgcn_update_dpp(sy, sy, 0x140 /*row_mirror*/, 0xF, 0xF, true);
+                        mx = __builtin_amdgcn_update_dpp(ox, mx, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+                        my = __builtin_amdgcn_update_dpp(oy, my, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+                        const v2f zmk = v2f{mx, my};
+                        const v2f zk = z[k2];
+                        v2f w = wpr[k2 & 3];
+                        if (k2 >= 4) w = cmulc(w, 0.70710678118654752f, -0.70710678118654752f);  // W_512^64 = W_8
+                        const v2f e = __builtin_elementwise_fma(zmk, v2f{1.f, -1.f}, zk);
+                        const v2f d = __builtin_elementwise_fma(zmk, v2f{-1.f, 1.f}, zk);
+                        const v2f o = cmul_negi(d, w);
+                        const v2f Rr = __builtin_elementwise_fma(xx(o), v2f{1.f, -1.f}, xx(e));
+                        const v2f Ii = __builtin_elementwise_fma(yy(o), v2f{1.f, -1.f}, yy(e));
+                        const v2f pw = __builtin_elementwise_fma(Rr, Rr, Ii * Ii);
+                        float pa = pw.x, pb = pw.y;
+                        if (POWER == 1) {
+                            pa = __builtin_sqrtf(pa);
+                            pb = __builtin_sqrtf(pb);
+                        }
+                        P[j + 16 * k2] = pa;
+                        Pm[16 * (7 - k2)] = pb;
+                    }
+                    const v2f s8 = z[8] * z[8];
+                    float p128 = 4.f * (s8.x + s8.y);
+                    if (POWER == 1) p128 = __builtin_sqrtf(p128);
+                    if (j == 0) P[128] = p128;
+                }
+                // ---- piece filterbank + log: all 64 lanes on one frame at a time (see mfcc_fast.hip step 7)
+#ifndef SSP_S_NOMEL
+                {
+                    float* lm = reinterpret_cast<float*>(zf + LM_OFF - 64 * g);
+                    if (j < f.lm_pad) lm[a.n_filt + j] = 0.f;
+                    float sfr[4];
+#pragma unroll
+                    for (int fr = 0; fr < 4; ++fr) {
+                        const char* pr = zbuf + fr * ZFRAME;
+                        v4f acc = *reinterpret_cast<const v4f*>(pr + mofs[0]) * mw[0];
+#pragma unroll
+                        for (int i = 1; i < MELV; ++i) acc = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(pr + mofs[i]), mw[i], acc);
+                        const v2f h = v2f{acc.x, acc.y} + v2f{acc.z, acc.w};
+                        sfr[fr] = h.x + h.y;
+                    }
+                    v2f s01 = v2f{sfr[0], sfr[1]}, s23 = v2f{sfr[2], sfr[3]};
+#define SSP_SCAN_STEP(CTRL, MK)                                                                             \
+                    {                                                                                           \
+                        const float a0 = s01.x, a1 = s01.y, a2 = s23.x, a3 = s23.y;                             \
+                        const float b0 = __builtin_amdgcn_update_dpp(a0, a0, CTRL, 0xF, 0xF, true);           \
+                        const float b1 = __builtin_amdgcn_update_dpp(a1, a1, CTRL, 0xF, 0xF, true);           \
+                        const float b2 = __builtin_amdgcn_update_dpp(a2, a2, CTRL, 0xF, 0xF, true);           \
+                        const float b3 = __builtin_amdgcn_update_dpp(a3, a3, CTRL, 0xF, 0xF, true);           \
+                        s01 = __builtin_elementwise_fma(v2f{b0, b1}, MK, s01);                                  \
+                        s23 = __builtin_elementwise_fma(v2f{b2, b3}, MK, s23);                                  \
+                    }
+                    if (mel_ns > 0) SSP_SCAN_STEP(0x101 /*row_shl:1*/, xx(mk01))
+                    if (mel_ns > 1) SSP_SCAN_STEP(0x102 /*row_shl:2*/, yy(mk01))
+                    if (mel_ns > 2) SSP_SCAN_STEP(0x104 /*row_shl:4*/, xx(mk23))
+                    if (mel_ns > 3) SSP_SCAN_STEP(0x108 /*row_shl:8*/, yy(mk23))
+#undef SSP_SCAN_STEP
+                    if (mfid >= 0) {
+                        float* lmf = reinterpret_cast<float*>(zbuf + LM_OFF) + mfid;
+                        lmf[0 * (ZFRAME - 64) / 4] = stream_log(f, s01.x);
+                        lmf[1 * (ZFRAME - 64) / 4] = stream_log(f, s01.y);
+                        lmf[2 * (ZFRAME - 64) / 4] = stream_log(f, s23.x);
+                        lmf[3 * (ZFRAME - 64) / 4] = stream_log(f, s23.y);
+                    }
+                }
+#endif
+                // ---- DCT on the matrix cores: C[ceps][frame] over the quad's 4 frames (columns 4..15 repeat them)
+#ifndef SSP_S_NODCT
+                {
+                    // (lane-derived addresses are recomputed from an opaque copy of the lane id: hoisted out of the loop they would
+                    //  sit in registers the FFT phases need)
+                    int ol = lane;
+                    asm volatile("" : "+v"(ol));
+                    const int g = ol >> 4, j = ol & 15;
+                    const char* lmrow = zbuf + (j & 3) * (ZFRAME - 64) + LM_OFF + g * (KS * 4);
+                    float lb[KS];
+#pragma unroll
+                    for (int s = 0; s < KS; s += 2) {
+                        const v2f v = *reinterpret_cast<const v2f*>(lmrow + 4 * s);
+                        lb[s] = v.x;
+                        lb[s + 1] = v.y;
+                    }
+                    v4f cq = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) cq = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[s], lb[s], cq, 0, 0, 0);
+                    // lane (g, j): cepstra 4 g .. 4 g + 3 of frame ta + 4 q + j (j < 4); frames past the chunk's last one store zeros
+                    if (j < 4) {
+                        const bool ok = ta + 4 * q + j < tb;
+                        const v4f cv = ok ? cq : v4f{0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<v4f*>(ring + (((q % 6) * 4 + j) * RING_ROW) + g * 16) = cv;
+                    }
+                }
+#endif
+            } else {
+                // virtual quad behind the chunk's last frame: its ring rows must read as finite values
+                int ol = lane;
+                asm volatile("" : "+v"(ol));
+                const int g = ol >> 4, j = ol & 15;
+                if (j < 4) *reinterpret_cast<v4f*>(ring + (((q % 6) * 4 + j) * RING_ROW) + g * 16) = v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#ifdef SSP_S_NOSTEP
+            continue;
+#endif
+            if ((q & 3) != 3) continue;
+            // ================= time step b: rows [16 b - 4, 16 b + 12) of (c, delta, delta-delta) leave =================
+            {
+                const int b = q >> 2;
+                const int rb = 16 * b;
+                int ol = lane;
+                asm volatile("" : "+v"(ol));
+                const int g = ol >> 4, j = ol & 15;
+                // B operands: cepstra of ring frames rb - 8 + 4 s + g, column j (lane (g, j)), s = 0..5
+                float cb[6];
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    const int m = (rb + 16 + 4 * s) % RING_FRAMES;  // (rb - 8 + 4 s) mod 24, a multiple of 4
+                    cb[s] = *reinterpret_cast<const float*>(ring + (m + g) * RING_ROW + j * 4);
+                }
+                const float tg = (float)(ta + rb);  // utterance frame index of relative frame rb
+                // A operands = regression weights of frame (tg + tpr) in delta[tg + tr].  Steps whose 24-frame window lies strictly
+                // inside the utterance (all but the first and the last one or two) take them from the lane-constant distance
+                // d = tpr - tr: d / denom for |d| <= 2; at the utterance ends the edge-replicated form folds the outside weights
+                // onto frame 0 / T - 1.
+                const bool interior = ta + rb - 8 >= 1 && ta + rb + 16 <= T - 2;  // wave-uniform
+                const float inv = 2.f * half_inv;
+                auto W = [&](float tr, float tpr) -> float {
+                    if (interior) {
+                        const float d = tpr - tr;
+                        return __builtin_fabsf(d) <= 2.f ? d * inv : 0.f;
+                    }
+                    return delta_weight(tg + tr, tg + tpr, Tm1, half_inv);
+                };
+                const float fj = (float)j, fg = (float)g;
+                // rows leave with bounds-checked 4-byte buffer stores; a lane that has nothing to store aims out of bounds.  The
+                // instruction count per step is fixed (the wait at the top of the next quad counts them)
+                const int Fo = ta + rb - 4 + 4 * g;  // first output frame of this lane group (registers r = 0..3 follow)
+                const bool full = ta + rb - 4 >= t0 && ta + rb + 12 <= t0 + n;  // wave-uniform: every row of the window is emitted
+                const int lane_off = j < nc ? (Fo * Dd + j) * 4 : 0x7ffffff0;
+                auto put = [&](int rrel, int blk, float v, bool lane_on) {
+                    // row Fo + rrel, block blk (0 cepstra | 1 delta | 2 delta-delta)
+                    int off;
+                    if (full) {
+                        off = lane_on ? lane_off + (rrel * Dd + blk * nc) * 4 : 0x7ffffff0;
+                    } else {
+                        const int F = Fo + rrel;
+                        off = (lane_on && F >= t0 && F < t0 + n) ? lane_off + (rrel * Dd + blk * nc) * 4 : 0x7ffffff0;
+                    }
+#ifdef SSP_S_NOSTORE  // ablation: the products stay live, nothing leaves
+                    asm volatile("" ::"v"(v), "v"(off));
+#else
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off, 0, 0);
+#endif
+                };
+                // cepstra of the output rows straight from the ring
+                {
+                    const int m4 = (rb + 20) % RING_FRAMES;  // (rb - 4) mod 24
+                    int slot = m4 + 4 * g;
+                    slot = slot >= RING_FRAMES ? slot - RING_FRAMES : slot;
+                    const float* cr = reinterpret_cast<const float*>(ring + slot * RING_ROW + j * 4);
+                    const v4f o0 = v4f{cr[0], cr[16], cr[32], cr[48]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) put(r, 0, o0[r], true);
+                }
+                if (dord >= 1) {
+                    // delta tile 0: rows i = j <-> frame rb - 6 + i; contraction over ring frames rb - 8 + 4 s + g, s = 0..4
+                    v4f d0 = v4f{0.f, 0.f, 0.f, 0.f}, d1 = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W(fj - 6.f, fg + (float)(4 * s - 8)), cb[s], d0, 0, 0, 0);
+                    // delta tile 1: rows i = 0, 4, 8, 12 <-> frames rb + 10 + i / 4 (the other rows are zero); s = 4, 5
+                    const float fr1 = (float)(j >> 2) + 10.f;
+#pragma unroll
+                    for (int s = 4; s < 6; ++s) {
+                        float w = W(fr1, fg + (float)(4 * s - 8));
+                        w = (j & 3) == 0 ? w : 0.f;
+                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, cb[s], d1, 0, 0, 0);
+                    }
+                    // delta rows leave from their own layout: tile 0 register r <-> frame rb - 6 + 4 g + r = row Fo + r - 2 (the first two
+                    // belong to the previous step's window), tile 1 register 0 <-> frame rb + 10 + g = row Fo + 14 - 3 g (g < 2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) put(r - 2, 1, d0[r], r >= 2 || g > 0);
+                    put(14 - 3 * g, 1, d1[0], g < 2);
+                    if (dord >= 2) {
+                        // delta-delta: rows i = j <-> frame rb - 4 + i; B = delta tile 0 register s (frame rb - 6 + 4 g + s) and
+                        // delta tile 1 register 0 (frame rb + 10 + g)
+                        v4f dd = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) dd = __builtin_amdgcn_mfma_f32_16x16x4f32(W(fj - 4.f, 4.f * fg + (float)(s - 6)), d0[s], dd, 0, 0, 0);
+                        dd = __builtin_amdgcn_mfma_f32_16x16x4f32(W(fj - 4.f, fg + 10.f), d1[0], dd, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) put(r, 2, dd[r], true);
+                    }
+                }
+                stores_pending = dord >= 2 ? 13 : (dord == 1 ? 9 : 4);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetch (zeros) and every store have completed
+    }
+#ifdef SSP_S_CLOCK
+    if (tid == 0) {
+        const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(reinterpret_cast<unsigned long long*>(sa.work_counter + 2), ck1 - ck0);
+        atomicAdd(reinterpret_cast<unsigned long long*>(sa.work_counter + 4), rt1 - rt0);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool mfcc_stream_supported(const ssp_mfcc_plan* p) {
+    const ssp_mfcc_cfg& c = p->cfg;
+    const FastArgs& f = p->fast;
+    if (!(mfcc_fast_supported(c) && p->fast_ready)) return false;
+    if (getenv("SSP_MFCC_NO_STREAM")) return false;
+    const int ks = (c.n_filt + 3) / 4;
+    return f.melv >= 2 && f.melv <= 5 && c.n_ceps == 13 && ks <= 6 && (c.hop & 3) == 0 && (c.delta_order == 0 || c.delta_N == 2);
+}
+
+static int stream_ks(const ssp_mfcc_cfg& c) {
+    const int ks = (c.n_filt + 3) / 4;
+    (void)ks;
+    return 6;  // (wider filterbanks need a DCT table that no longer fits three workgroups per CU: they stay on the workgroup kernel)
+}
+
+int build_stream_tables(ssp_mfcc_plan* p) {
+    const ssp_mfcc_cfg& c = p->cfg;
+    const int KS = stream_ks(c);
+    // A operand of the DCT product: lane (ceps = l & 15, kq = l >> 4), k-step s <-> filter KS kq + s
+    std::vector<float> dcth((size_t)c.n_ceps * c.n_filt), dA((size_t)KS * 64, 0.f);
+    SSP_HIP(hipMemcpy(dcth.data(), p->dct.p, dcth.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int s = 0; s < KS; ++s)
+        for (int l = 0; l < 64; ++l) {
+            const int q = l & 15, jf = KS * (l >> 4) + s;
+            if (q < c.n_ceps && jf < c.n_filt) dA[(size_t)s * 64 + l] = dcth[(size_t)q * c.n_filt + jf];
+        }
+    SSP_TRY(p->s_dctA.alloc(dA.size() * sizeof(float)));
+    SSP_HIP(hipMemcpy(p->s_dctA.p, dA.data(), dA.size() * sizeof(float), hipMemcpyHostToDevice));
+    p->stream_ready = true;
+    return SSP_OK;
+}
+
+int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStream_t stream) {
+    if (n_chunks <= 0) return SSP_OK;
+    FastArgs f = p->fast;
+    const ssp_mfcc_cfg& c = p->cfg;
+    StreamArgs sa{};
+    const int KS = stream_ks(c);
+    // padded filter slots of the log-mel rows (up to 4 KS) must read as finite zeros
+    f.lm_pad = 4 * KS - c.n_filt;
+    if (f.lm_pad > 16) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): %d filters leave more than 16 padded slots", c.n_filt);
+    sa.dctA = p->s_dctA.as<float>();
+    // the trailing half piece of the sample stage only writes 512 B
+    const int n_piece = (f.slen + 255) >> 8;
+    const bool has_half = (f.slen & 255) != 0 && (f.slen & 255) <= 128;
+    sa.stage_bytes = has_half ? (n_piece - 1) * 1024 + 512 : n_piece * 1024;
+    sa.wave_bytes = 4 * ZFRAME + sa.stage_bytes + RING_FRAMES * RING_ROW;
+    sa.table_bytes = 0;
+    sa.n_chunks = n_chunks;
+    SSP_TRY(p->f_counter.reserve(64));
+    sa.work_counter = p->f_counter.as<int32_t>();
+    const size_t lds = (size_t)sa.table_bytes + (size_t)STREAM_WAVES * sa.wave_bytes;
+    if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): LDS footprint %zu B exceeds 160 KiB", lds);
+    if ((int64_t)p->fast_max_samples * 4 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): utterance too long for 32-bit offsets");
+    const int nz = c.win_len <= 416 ? 13 : 16, pw = c.spec_power, pr = c.preemph_mode ? 1 : 0;
+    bool launched = false;
+#define SSP_STREAM_CASE(NZ_, PW_, PR_, MV_, KS_)                                                                      \
+    if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && f.melv == MV_ && KS == KS_) {                               \
+        auto* kfn = f.mel_ns <= 2 ? mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 2> : mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 4>;                                                     \
+        if (lds > 64 * 1024)                                                                                            \
+            SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        int per_cu = 0;                                                                                                 \
+        SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * STREAM_WAVES, lds));                    \
+        const int grid = std::min((n_chunks + STREAM_WAVES - 1) / STREAM_WAVES, std::max(1, per_cu) * p->ctx->num_cu);    \
+        SSP_HIP(hipMemsetAsync(sa.work_counter, 0, 64, stream));                                                        \
+        if (getenv("SSP_DEBUG")) fprintf(stderr, "[ssp] mfcc stream: grid %d (%d per CU), lds %zu\n", grid, per_cu, lds); \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * STREAM_WAVES), lds, stream, args, f, sa);                         \
+        launched = true;                                                                                                \
+    }
+#ifdef SSP_FAST_MINIMAL
+    SSP_STREAM_CASE(13, 2, 1, 3, 6)
+#else
+#define SSP_STREAM_MV(NZ_, PW_, PR_)                                                                                    \
+    SSP_STREAM_CASE(NZ_, PW_, PR_, 2, 6) SSP_STREAM_CASE(NZ_, PW_, PR_, 3, 6) SSP_STREAM_CASE(NZ_, PW_, PR_, 4, 6)
+    SSP_STREAM_MV(13, 2, 1)
+    SSP_STREAM_MV(13, 2, 0)
+    SSP_STREAM_MV(13, 1, 0)
+    SSP_STREAM_MV(16, 2, 1)
+    SSP_STREAM_MV(16, 2, 0)
+    SSP_STREAM_MV(16, 1, 0)
+#undef SSP_STREAM_MV
+#endif
+#undef SSP_STREAM_CASE
+    if (!launched) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): no kernel instance for this cfg");
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
+}
+
+}  // namespace ssp
+
+#ifdef SSP_S_CLOCK
+extern "C" int ssp_debug_clock(ssp_mfcc_plan* p, unsigned long long* out2) {
+    unsigned long long h[8];
+    if (hipMemcpy(h, p->f_counter.p, 64, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    out2[0] = h[1];
+    out2[1] = h[2];
+    return 0;
+}
+#endif

@@ -118,6 +118,67 @@ def test_sidekit_preset_vs_oracle(ssp, delta_order, cmvn, variant):
         assert_feat_close(got[u], ref, what=f"utt {u} order {delta_order} cmvn {cmvn}")
 
 
+# variant 3 = wave-stream kernel (DCT / delta / delta-delta on the matrix cores): 16-byte sample DMA, so every utterance must start
+# on a 16-byte boundary (lengths in multiples of 4 samples); batches that do not go to the workgroup kernel in auto mode
+STREAM_LENS = [48000, 16000, 400, 560, 720, 1040, 1044, 3000, 4800, 8000, 100004, 20000, 404, 880, 2960, 5200, 399 + 1, 82320, 163840 + 400]
+
+
+@pytest.mark.parametrize("delta_order,cmvn", [(0, 0), (1, 0), (2, 0), (2, 1)])
+def test_stream_kernel_vs_oracle(ssp, delta_order, cmvn):
+    """Ragged batch through the wave-stream kernel: 1-frame utterances, every length class of the 16-frame time steps, utterances cut
+    into 512-frame chunks with a recomputed halo (623 and 1025+ frames), CMVN through the stand-alone kernel."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    sigs = [synth_audio(u, n, 16000) for u, n in enumerate(STREAM_LENS)]
+    tables = pkg.preset_sidekit(delta_order=delta_order, cmvn=cmvn)
+    got, fseg = _run_plan(api, tables, sigs, variant=3)
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=delta_order, cmvn=cmvn)
+    worst = 0.0
+    for u, s in enumerate(sigs):
+        ref = O.mfcc_pipeline(s, cfg, w, fb, dct)
+        assert_feat_close(got[u], ref, tol=2e-4 if cmvn else FEAT_TOL, what=f"stream utt {u} len {len(s)} order {delta_order} cmvn {cmvn}")
+        if ref.size:
+            worst = max(worst, np.abs(got[u] - ref).max() / max(1.0, np.abs(ref).max()))
+    print("stream kernel: worst relative error %.2e" % worst)
+
+
+def test_stream_kernel_matches_workgroup_kernel_and_auto(ssp):
+    pkg, api = ssp
+    sigs = [synth_audio(u, n, 16000) for u, n in enumerate(STREAM_LENS[:12])]
+    tables = pkg.preset_sidekit(delta_order=2)
+    g3, _ = _run_plan(api, tables, sigs, variant=3)
+    g2, _ = _run_plan(api, tables, sigs, variant=2)
+    g0, _ = _run_plan(api, tables, sigs, variant=0)
+    for a3, a2, a0 in zip(g3, g2, g0):
+        assert np.array_equal(a3, a0)  # auto = the stream kernel on aligned batches
+        if a3.size:
+            assert np.abs(a3 - a2).max() <= 1e-4 * max(1.0, np.abs(a2).max())
+    # utterances that do not start on 16-byte boundaries: the stream kernel refuses, auto falls back to the workgroup kernel
+    odd = [synth_audio(u, 16000 + 37 * u, 16000) for u in range(5)]
+    with pytest.raises(Exception):
+        _run_plan(api, tables, odd, variant=3)
+    f0, _ = _run_plan(api, tables, odd, variant=0)
+    f2, _ = _run_plan(api, tables, odd, variant=2)
+    for a0, a2 in zip(f0, f2):
+        assert np.array_equal(a0, a2)
+
+
+@pytest.mark.parametrize("nwin,shift", [(0.032, 0.016), (0.025, 0.005), (0.02, 0.01)])
+def test_stream_kernel_other_geometries(ssp, nwin, shift):
+    """Other framings on the stream kernel: a full 512-sample window with hop 256 (five DMA pieces per quad), hop 80 (three whole
+    pieces), a 320-sample window; and a dialect it does not cover (in-repo: 40 filters) answering UNSUPPORTED for an explicit request."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    sigs = [synth_audio(u, n, 16000) for u, n in enumerate([16000, 48000, 512, 1024, 4444 * 4, 100000])]
+    tables = pkg.preset_sidekit(nwin=nwin, shift=shift, delta_order=2)
+    got, _ = _run_plan(api, tables, sigs, variant=3)
+    cfg, w, fb, dct = O.sidekit_tables(nwin=nwin, shift=shift, delta_order=2)
+    for u, s in enumerate(sigs):
+        assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"stream {nwin}/{shift} utt {u}")
+    with pytest.raises(Exception):
+        _run_plan(api, pkg.preset_inrepo(16000, 512, 256), [synth_audio(0, 16000, 16000)], variant=3)
+
+
 def test_sidekit_shape_fact(ssp):
     """report/final.pdf IV-B-2: 1 s @ 16 kHz -> 98 x 13."""
     pkg, api = ssp

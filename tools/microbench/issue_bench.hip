@@ -1,0 +1,246 @@
+// Issue-cost microbenchmark for gfx950: cycles per wave-instruction per SIMD at 1..4 waves per SIMD for the instruction kinds the
+// fused MFCC kernel is built from (plain / packed fp32 VALU, DPP moves, transcendental, LDS reads / writes, fp32 MFMA beside VALU).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/microbench/issue_bench tools/microbench/issue_bench.hip && tools/microbench/issue_bench
+// Every kernel runs ITERS iterations of a body of REP independent instructions (8 accumulator chains) in inline asm; lane 0 of
+// every wave stores its s_memtime span; the host reports  span / (REP * ITERS * waves_per_simd)  = cycles per instruction per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+constexpr int ITERS = 2000;
+
+#define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+enum Op { FMA, PKFMA, PKADD, PKMUL, ADD, MUL, DPPMOV, DPPADD, FMAC, LOGF, PKFMA_SEL, MIX_PK_PLAIN, DSR64, DSR128, DSW64, DSW32, DSR32,
+          MFMA16, MFMA16_V4, MFMA16_V8, MFMA16_V12, MFMA4, MFMA4_V2, PKFMA_DEP, FMA_DEP, BPERM, MFMA16_PK2, MFMA16_PK4, MFMA16_PK6, NOPS };
+static const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_add_f32", "v_mul_f32", "v_mov_b32_dpp row_mirror",
+                              "v_add_f32_dpp row_mirror", "v_fmac_f32", "v_log_f32", "v_pk_fma_f32 op_sel", "pk_fma + fma alternating (per pair)",
+                              "ds_read_b64", "ds_read_b128", "ds_write_b64", "ds_write_b32", "ds_read_b32",
+                              "mfma_16x16x4_f32 alone", "mfma_16x16x4 + 4 v_fma (per group)", "mfma_16x16x4 + 8 v_fma (per group)", "mfma_16x16x4 + 12 v_fma (per group)",
+                              "mfma_4x4x1_16b_f32 alone", "mfma_4x4x1 + 2 v_fma (per group)", "v_pk_fma_f32 dependent chain", "v_fma_f32 dependent chain",
+                              "ds_bpermute_b32", "mfma_16x16x4 + 2 v_pk_fma (per group)", "mfma_16x16x4 + 4 v_pk_fma (per group)", "mfma_16x16x4 + 6 v_pk_fma (per group)"};
+// instructions per body (for reporting): groups count as 1
+static int body_count(int op) { return 32; }
+
+template <int OP>
+__global__ __launch_bounds__(256) void bench(unsigned long long* spans, float* sink, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[4096];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = (float)i * 1e-3f;
+    __syncthreads();
+    v2f a[8], b = v2f{1.0001f, 0.9999f}, c = v2f{1e-7f, -1e-7f};
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = v2f{1.f + i + lane, 2.f + i}; s[i] = 1.f + i + lane * 0.5f; }
+    v4f q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    v4f acc4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc4[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    const unsigned ldsaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + (lane * 16) % 8192;
+    const unsigned ldsaddr8 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + lane * 8;
+    const unsigned ldsaddr4 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + lane * 4;
+    const int bp = ((lane * 7) & 63) * 4;
+    unsigned long long t0, t1;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (OP == FMA) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(s[i]) : "v"(b.x), "v"(c.x));
+                R8(X)
+#undef X
+            } else if constexpr (OP == PKFMA) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                R8(X)
+#undef X
+            } else if constexpr (OP == PKFMA_SEL) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(a[i]) : "v"(b), "v"(c));
+                R8(X)
+#undef X
+            } else if constexpr (OP == PKADD) {
+#define X(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                R8(X)
+#undef X
+            } else if constexpr (OP == PKMUL) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                R8(X)
+#undef X
+            } else if constexpr (OP == ADD) {
+#define X(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(s[i]) : "v"(c.x));
+                R8(X)
+#undef X
+            } else if constexpr (OP == MUL) {
+#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(s[i]) : "v"(b.x));
+                R8(X)
+#undef X
+            } else if constexpr (OP == DPPMOV) {
+#define X(i) asm volatile("v_mov_b32_dpp %0, %1 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(s[i]) : "v"(s[(i + 1) & 7]));
+                R8(X)
+#undef X
+            } else if constexpr (OP == DPPADD) {
+#define X(i) asm volatile("v_add_f32_dpp %0, %1, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(s[i]) : "v"(c.x));
+                R8(X)
+#undef X
+            } else if constexpr (OP == FMAC) {
+#define X(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(s[i]) : "v"(b.x), "v"(c.x));
+                R8(X)
+#undef X
+            } else if constexpr (OP == LOGF) {
+#define X(i) asm volatile("v_log_f32 %0, %0" : "+v"(s[i]));
+                R8(X)
+#undef X
+            } else if constexpr (OP == MIX_PK_PLAIN) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %2, %3\n\tv_fma_f32 %1, %1, %4, %5" : "+v"(a[i]), "+v"(s[i]) : "v"(b), "v"(c), "v"(b.x), "v"(c.x));
+                R8(X)
+#undef X
+            } else if constexpr (OP == PKFMA_DEP) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(b), "v"(c));
+                R8(X)
+#undef X
+            } else if constexpr (OP == FMA_DEP) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(s[0]) : "v"(b.x), "v"(c.x));
+                R8(X)
+#undef X
+            } else if constexpr (OP == DSR64) {
+#define X(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[i]) : "v"(ldsaddr8), "n"(i * 512));
+                R8(X)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (OP == DSR32) {
+#define X(i) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(s[i]) : "v"(ldsaddr4), "n"(i * 256));
+                R8(X)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (OP == DSR128) {
+#define X(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[i]) : "v"(ldsaddr), "n"(i * 1024));
+                R8(X)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (OP == DSW64) {
+#define X(i) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ldsaddr8), "v"(a[i]), "n"(i * 512) : "memory");
+                R8(X)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (OP == DSW32) {
+#define X(i) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(ldsaddr4), "v"(s[i]), "n"(i * 256) : "memory");
+                R8(X)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (OP == BPERM) {
+#define X(i) asm volatile("ds_bpermute_b32 %0, %1, %0" : "+v"(s[i]) : "v"(bp));
+                R8(X)
+#undef X
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if constexpr (OP == MFMA16 || OP == MFMA16_V4 || OP == MFMA16_V8 || OP == MFMA16_V12 || OP == MFMA16_PK2 || OP == MFMA16_PK4 || OP == MFMA16_PK6) {
+                // 8 groups per r: one MFMA (4 independent accumulators round robin) + n plain VALU
+#define VF(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(s[i]) : "v"(b.x), "v"(c.x));
+#define VP(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define X(i)                                                                                                   \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc4[i & 3]) : "v"(b.x), "v"(c.y));             \
+    if constexpr (OP == MFMA16_V4 || OP == MFMA16_V8 || OP == MFMA16_V12) { VF(0) VF(1) VF(2) VF(3) }            \
+    if constexpr (OP == MFMA16_V8 || OP == MFMA16_V12) { VF(4) VF(5) VF(6) VF(7) }                               \
+    if constexpr (OP == MFMA16_V12) { VF(0) VF(1) VF(2) VF(3) }                                                  \
+    if constexpr (OP == MFMA16_PK2 || OP == MFMA16_PK4 || OP == MFMA16_PK6) { VP(0) VP(1) }                      \
+    if constexpr (OP == MFMA16_PK4 || OP == MFMA16_PK6) { VP(2) VP(3) }                                          \
+    if constexpr (OP == MFMA16_PK6) { VP(4) VP(5) }
+                R8(X)
+#undef X
+            } else if constexpr (OP == MFMA4 || OP == MFMA4_V2) {
+#define X(i)                                                                                                   \
+    asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc4[i & 3]) : "v"(b.x), "v"(c.y));           \
+    if constexpr (OP == MFMA4_V2) { VF(0) VF(1) }
+                R8(X)
+#undef X
+#undef VF
+#undef VP
+            }
+        }
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) keep += a[i].x + a[i].y + s[i] + q[i].x + q[i].w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) keep += acc4[i].x + acc4[i].y;
+    if (keep == 123.456f) sink[threadIdx.x] = keep + lds[lane];
+    if (lane == 0) spans[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int OP>
+int run(int ncu, unsigned long long* d_spans, float* d_sink) {
+    printf("%-44s", names[OP]);
+    for (int wps = 1; wps <= 4; ++wps) {
+        const int grid = ncu * wps;
+        bench<OP><<<grid, 256>>>(d_spans, d_sink, 10);  // warm
+        CK(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0));
+        bench<OP><<<grid, 256>>>(d_spans, d_sink, ITERS);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> h(grid * 4);
+        CK(hipMemcpy(h.data(), d_spans, h.size() * 8, hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        const double med = (double)h[h.size() / 2];
+        const double per = med / ((double)body_count(OP) * ITERS * wps);
+        // wall-derived clock estimate: cycles / time
+        printf("  w%d %6.2f (%.2f GHz)", wps, per, med / (ms * 1e6));
+    }
+    printf("\n");
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t p;
+    CK(hipGetDeviceProperties(&p, 0));
+    const int ncu = p.multiProcessorCount;
+    printf("%s, %d CUs; cycles per instruction (or per group) per SIMD, at 1..4 waves per SIMD (s_memtime span; 100 MHz const clock? see GHz column)\n", p.gcnArchName, ncu);
+    unsigned long long* d_spans;
+    float* d_sink;
+    CK(hipMalloc(&d_spans, ncu * 4 * 4 * 8));
+    CK(hipMalloc(&d_sink, 4096));
+    run<FMA>(ncu, d_spans, d_sink);
+    run<PKFMA>(ncu, d_spans, d_sink);
+    run<PKFMA_SEL>(ncu, d_spans, d_sink);
+    run<PKADD>(ncu, d_spans, d_sink);
+    run<PKMUL>(ncu, d_spans, d_sink);
+    run<ADD>(ncu, d_spans, d_sink);
+    run<MUL>(ncu, d_spans, d_sink);
+    run<FMAC>(ncu, d_spans, d_sink);
+    run<DPPMOV>(ncu, d_spans, d_sink);
+    run<DPPADD>(ncu, d_spans, d_sink);
+    run<LOGF>(ncu, d_spans, d_sink);
+    run<MIX_PK_PLAIN>(ncu, d_spans, d_sink);
+    run<PKFMA_DEP>(ncu, d_spans, d_sink);
+    run<FMA_DEP>(ncu, d_spans, d_sink);
+    run<DSR32>(ncu, d_spans, d_sink);
+    run<DSR64>(ncu, d_spans, d_sink);
+    run<DSR128>(ncu, d_spans, d_sink);
+    run<DSW32>(ncu, d_spans, d_sink);
+    run<DSW64>(ncu, d_spans, d_sink);
+    run<BPERM>(ncu, d_spans, d_sink);
+    run<MFMA16>(ncu, d_spans, d_sink);
+    run<MFMA16_V4>(ncu, d_spans, d_sink);
+    run<MFMA16_V8>(ncu, d_spans, d_sink);
+    run<MFMA16_V12>(ncu, d_spans, d_sink);
+    run<MFMA16_PK2>(ncu, d_spans, d_sink);
+    run<MFMA16_PK4>(ncu, d_spans, d_sink);
+    run<MFMA16_PK6>(ncu, d_spans, d_sink);
+    run<MFMA4>(ncu, d_spans, d_sink);
+    run<MFMA4_V2>(ncu, d_spans, d_sink);
+    return 0;
+}
