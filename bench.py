@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the MFCC -> GMM-UBM / d-vector scoring hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N ranks itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Headline (`value`): MFCC frames/s on BASELINE.json configs[1] — 100k x 3 s synthetic 16 kHz utterances per GPU,
@@ -79,6 +79,53 @@ def cpu_baseline_mfcc(n_utt, n_samp, fs, budget_s=15.0):
             "host_cores": os.cpu_count()}
 
 
+def cpu_baseline_mfcc_loop(n_samp, fs, budget_s=6.0):
+    """the reference's own per-frame Python loop (utils/processing.py:129-143, restated as oracle.MFCC_loop) on the
+    in-repo dialect, one thread."""
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(3)
+    x = np.clip(0.3 * np.sin(2 * np.pi * 120 * np.arange(n_samp) / fs) + 0.05 * rng.standard_normal(n_samp), -1, 1)
+    frames, utts, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        frames += O.MFCC_loop(x, fs=fs, frameSize=512, step=256).shape[0]
+        utts += 1
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d utterances x %d samples, oracle.ref_cpu.MFCC_loop = the per-frame Python loop of utils/processing.py:129-143 "
+                      "(in-repo dialect, %d Hz, 512/256, 13-d), 1 thread, %.1f s" % (utts, n_samp, fs, dt)}
+
+
+def cpu_baseline_gmm_loop(D, K, S, budget_s=8.0):
+    """the reference's scoring loop itself, GMM_UBM.py:190-193 — `GMM[i].score(x_j) - UBM.score(x_j)` per (speaker,
+    utterance) with sklearn GaussianMixture objects (the library the reference calls), the UBM rescored once per speaker."""
+    from sklearn.mixture import GaussianMixture
+    rng = np.random.default_rng(4)
+
+    def make(mu):
+        g = GaussianMixture(n_components=K, covariance_type="diag")
+        g.weights_, g.means_, g.covariances_ = w, mu, cov
+        g.precisions_cholesky_ = 1.0 / np.sqrt(cov)
+        return g
+    w = rng.dirichlet(5 * np.ones(K))
+    mu0 = rng.standard_normal((K, D))
+    cov = rng.uniform(0.5, 2, (K, D))
+    UBM = make(mu0)
+    GMM = [make(mu0 + 0.3 * rng.standard_normal((K, D))) for _ in range(S)]
+    X = [rng.standard_normal((298, D)) for _ in range(4)]
+    n_utt, t0 = 0, time.perf_counter()
+    pred = np.zeros((1, S))
+    while time.perf_counter() - t0 < budget_s:
+        x = X[n_utt % 4]
+        for i in range(S):
+            pred[0, i] = GMM[i].score(x) - UBM.score(x)
+        n_utt += 1
+    dt = time.perf_counter() - t0
+    return {"value": n_utt * 298 * (S + 1) / dt, "unit": "frame-scores/s", "cores": 1, "kind": "reference",
+            "sample": "%d utterances of 298 x %d frames through the loop of GMM_UBM.py:190-193 with sklearn GaussianMixture.score "
+                      "(K=%d, %d speakers, the UBM rescored per speaker; counted as %d useful model scores per frame), "
+                      "single process, BLAS threads = host default, %.1f s" % (n_utt, D, K, S, S + 1, dt)}
+
+
 def cpu_baseline_gmm(D, K, n_models, budget_s=8.0):
     from oracle import ref_cpu as O
     rng = np.random.default_rng(1)
@@ -91,8 +138,9 @@ def cpu_baseline_gmm(D, K, n_models, budget_s=8.0):
         O.gmm_score(w, mu, cov, X)  # one (speaker, utterance) score call, as the loop at GMM_UBM.py:183-185
         n += 298
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frame-scores/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "per-(model, utterance) score() calls on 298x%d frames, K=%d, numpy float64 (BLAS threads = host default), %.1f s" % (D, K, dt)}
+    return {"value": n / dt, "unit": "frame-scores/s", "cores": 1, "kind": "port",
+            "sample": "per-(model, utterance) score() calls on 298x%d frames, K=%d, numpy float64, one process (BLAS threads = host "
+                      "default), %.1f s" % (D, K, dt), "host_cores": os.cpu_count()}
 
 
 def cpu_baseline_cosine(d, S, budget_s=5.0):
@@ -110,6 +158,24 @@ def cpu_baseline_cosine(d, S, budget_s=5.0):
             "sample": "scipy.spatial.distance.cosine per pair (the reference's own call, d_vector.py:317), d=%d, %.1f s" % (d, dt)}
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` outside a torch.distributed launch: this process never touches the GPU (no HIP call, no
+    torch.cuda) — it starts `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a CHILD process (one rank per
+    GPU, RCCL), passes its output through and exits with its code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SSP_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,11 +184,13 @@ def main():
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused workgroup kernel | 3 fused wave-stream kernel")
-    ap.add_argument("--stages", default="mfcc,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
-    ap.add_argument("--gmm4-utts", type=int, default=2000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU)")
+    ap.add_argument("--stages", default="mfcc,inrepo,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
+    ap.add_argument("--gmm4-utts", type=int, default=12000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU; SURVEY.md 8(d) asks for >= 12000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -191,7 +259,8 @@ def main():
     elapsed = max_over_ranks(time.perf_counter() - t0, device)
     total_frames = n_frames * world * args.steps
     value = total_frames / elapsed
-    ms_kernel = float(np.mean(kernel_ms))
+    ms_kernel = float(np.median(kernel_ms))
+    per_rank_ms = all_gather_rows(torch.tensor([[float(np.median(kernel_ms))]], dtype=torch.float64, device=device)).flatten().tolist()
     bytes_per_frame = tables.cfg.hop * 4 + plan.d_out * 4            # 160*4 read + 39*4 written
     algo_bytes = n_utt * n_samp * 4 + n_frames * plan.d_out * 4      # exact per launch: every sample read once, every feature written once
     achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9
@@ -202,6 +271,21 @@ def main():
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # second bound of the same kernel: VALU issue.  cycles per quad (4 frames) = instruction census of the shipped kernel x the issue
+    # costs measured by tools/microbench/issue_bench (profiles/mfcc_valu_lds_pmc.json); peak = every SIMD issuing every cycle at 2.4 GHz
+    valu = None
+    census_file = os.path.join(ROOT, "profiles", "mfcc_valu_lds_pmc.json")
+    if os.path.exists(census_file):
+        try:
+            cj = json.load(open(census_file))
+            cyc = float(cj["valu_issue_cycles_per_quad"])
+            peak = 256 * 4 * 2.4e9
+            ach = (n_frames / 4.0) * cyc / (ms_kernel * 1e-3)
+            valu = {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G issue-cycles/s", "frac": ach / peak,
+                    "issue_cycles_per_quad": cyc, "floor_ms_at_2.4GHz": (n_frames / 4.0) * cyc / peak * 1e3,
+                    "sustained_clock_ghz": cj.get("sustained_clock_ghz"), "source": "profiles/mfcc_valu_lds_pmc.json"}
+        except Exception:
+            valu = None
     result = {
         "metric": "MFCC frames/s (fused framing+preemph+window+rFFT+mel+log+DCT+delta+delta-delta, 39-d)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,12 +294,51 @@ def main():
         "config": {"workload": "configs[1]: %d x %.0f s synthetic 16 kHz utterances per GPU, 39-dim MFCC (+delta+delta-delta), "
                                "win 400 / hop 160 / nfft 512, 24 mel filters" % (n_utt, args.seconds),
                    "utterances_per_gpu": n_utt, "frames_per_gpu": n_frames, "d_out": plan.d_out,
-                   "kernel_variant": args.variant, "parallelism": "utterance-sharded x%d" % world},
+                   "kernel_variant": args.variant, "parallelism": "utterance-sharded x%d" % world,
+                   "world_size_observed": (dist.get_world_size() if world > 1 else 1),
+                   "backend": (dist.get_backend() if world > 1 else None), "kernel_ms_per_rank": per_rank_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "mfcc fused pass", "kernel_ms": ms_kernel, "algorithmic_bytes_per_launch": algo_bytes,
-                     "bytes_per_frame": bytes_per_frame},
+                     "kernel": "mfcc_stream512_kernel" if args.variant in (0, 3) else "mfcc fused pass", "kernel_ms": ms_kernel,
+                     "kernel_ms_stat": "median of the timed launches (hipEvents on the launch stream)",
+                     "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame},
+        "roofline_valu": valu,
     }
+
+    # ------------------------------------------------------------------ the reference-pinned dialect: in-repo MFCC (utils/processing.py:19-144)
+    if "inrepo" in stages:
+        result["mfcc_inrepo"] = {}
+        for tag, ifs in (("16k", 16000), ("8k", 8000)):
+            itab = pkg.preset_inrepo(ifs, 512, 256)
+            iplan = api.MfccPlan(ctx, itab)
+            # the same resident samples, read as `seconds` of audio at the dialect's rate (8 kHz: 200k utterances of 24000 samples)
+            i_samp = int(round(args.seconds * ifs))
+            i_utt = (n_utt * n_samp) // i_samp
+            iseg = api.Segments.from_lengths(ctx, np.full(i_utt, i_samp, dtype=np.int64))
+            ifseg = iplan.frame_segments(iseg)
+            ifeat = torch.empty((ifseg.total, iplan.d_out), dtype=torch.float32, device=device)
+            iplan.run(flat[: i_utt * i_samp], iseg, ifseg, out=ifeat)
+            ims = []
+            barrier()
+            torch.cuda.synchronize()
+            t0i = time.perf_counter()
+            for _ in range(max(2, min(args.steps, 5))):
+                _, ms = iplan.run(flat[: i_utt * i_samp], iseg, ifseg, out=ifeat, timing=True)
+                ims.append(ms)
+            torch.cuda.synchronize()
+            barrier()
+            i_elapsed = max_over_ranks(time.perf_counter() - t0i, device)
+            i_ms = float(np.median(ims))
+            i_bytes = i_utt * i_samp * 4 + ifseg.total * iplan.d_out * 4
+            result["mfcc_inrepo"][tag] = {
+                "metric": "in-repo MFCC frames/s (utils/processing.py:110-144: Hamming, |FFT|/L, 40 talkbox filters, log10, DCT-II, 13-d), "
+                          "arithmetic pinned to the reference's own outputs (tests/golden/mfcc_inrepo.npz)",
+                "value": ifseg.total * world * len(ims) / i_elapsed, "unit": "frames/s", "sample_rate": ifs, "frame": "512/256",
+                "utterances_per_gpu": i_utt, "frames_per_gpu": int(ifseg.total), "dtype": "f32",
+                "roofline": {"bound": "hbm", "achieved": i_bytes / (i_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": i_bytes / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "mfcc_fused512_kernel",
+                             "kernel_ms": i_ms, "algorithmic_bytes_per_launch": i_bytes, "bytes_per_frame": 256 * 4 + 13 * 4}}
+            del iplan, ifeat
 
     # ------------------------------------------------------------------ GMM-UBM scoring stage (configs[2])
     if "gmm" in stages:
@@ -312,7 +435,8 @@ def main():
                          "tflops": flop4 / (r4["kernel_ms"] * 1e-3) / 1e12, "gathered_rows": int(gathered.shape[0])}
         result["gmm_cfg3_shape"] = {
             "metric": "GMM frame-scores/s at the configs[3] shape (K=512, 1251 speakers + UBM, D=%d), sample of %d utterances per GPU" % (D, u4),
-            "frames_per_gpu": f4, "full_config_utterances_per_gpu": 150000,
+            "frames_per_gpu": f4, "full_config_utterances_per_gpu": 150000, "fraction_of_full_config": u4 / 150000.0,
+            "measured_s_for_this_sample": {t: out4[t]["kernel_ms"] * 1e-3 for t in out4},
             "extrapolated_full_config_s_per_gpu": {t: 150000.0 / u4 * out4[t]["kernel_ms"] * 1e-3 for t in out4}, **out4}
         del scorer4, r4
 
@@ -344,7 +468,7 @@ def main():
             "unit": "pair-scores/s", "ms_per_step": c_elapsed / c_steps * 1e3, "steps": c_steps, "dtype": "f32",
             "argmin_accuracy": acc,
             "roofline": {"bound": "mfma", "achieved": flop / (c_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": flop / (c_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "cosine_kernel",
+                         "frac": flop / (c_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "cosine_reg_kernel<32, false> (d <= 256: embeddings register-resident, centroid tiles by LDS-DMA)",
                          "kernel_ms": c_ms, "algorithmic_flop_per_launch": flop},
         }
 
@@ -451,6 +575,8 @@ def main():
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_mfcc(20000, n_samp, fs)
+        if "mfcc_inrepo" in result:
+            result["mfcc_inrepo"]["cpu_baseline_reference_loop"] = cpu_baseline_mfcc_loop(n_samp, fs)
         try:  # best-effort CPU figure: the same oracle in 16 worker processes (a child process: no fork from this GPU process)
             import subprocess
             out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_parallel_baseline.py"), "16", "8"],
@@ -460,8 +586,14 @@ def main():
             result["cpu_baseline_parallel"] = {"error": repr(e)}
         if "gmm" in result:
             result["gmm"]["cpu_baseline"] = cpu_baseline_gmm(plan.d_out, 64, 51)
+            result["gmm"]["cpu_baseline_reference_loop"] = cpu_baseline_gmm_loop(plan.d_out, 64, 50)
         if "cosine" in result:
             result["cosine"]["cpu_baseline"] = cpu_baseline_cosine(256, 1251)
+    try:  # how the shipped libsspgpu.so came to be (speech_signal_processing_amd/build.py records it)
+        result["build"] = {k: v for k, v in json.load(open(os.path.join(ROOT, "speech_signal_processing_amd", "build_info.json"))).items()
+                           if k in ("build_mode", "compiled_sources", "lib_bytes")}
+    except Exception:
+        result["build"] = None
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -18,7 +18,7 @@ OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 SOURCES = ["ctx.hip", "mfcc.hip", "mfcc_fast.hip", "mfcc_stream.hip", "mfcc_plan.hip", "feat_ops.hip", "gmm.hip", "gmm_em.hip", "cosine.hip", "dense.hip", "dtw.hip", "plp.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-munsafe-fp-atomics"] + os.environ.get("SSP_EXTRA_FLAGS", "").split()
+         "-fno-gpu-rdc", "-munsafe-fp-atomics", "-Wno-pass-failed"] + os.environ.get("SSP_EXTRA_FLAGS", "").split()
 
 
 def _deps():
@@ -49,21 +49,46 @@ def _compile(src: str) -> str:
     return obj
 
 
+INFO = os.path.join(HERE, "build_info.json")  # what the last build() call did (git-ignored; read back by bench.py)
+
+
+def _record(mode: str, compiled) -> None:
+    import json
+    import time
+    try:
+        with open(INFO, "w") as f:
+            json.dump({"build_mode": mode, "compiled_sources": list(compiled), "time": time.time(),
+                       "lib_bytes": os.path.getsize(LIB) if os.path.exists(LIB) else 0, "hipcc": HIPCC, "flags": FLAGS}, f)
+    except OSError:
+        pass
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile (hipcc, gfx950) what is out of date and link libsspgpu.so.  SSP_FORCE_BUILD=1 (or force=True) recompiles every
+    source.  Records in build_info.json whether the call compiled ("compiled" / "forced") or found the shipped library up to date
+    ("reused")."""
+    force = force or bool(os.environ.get("SSP_FORCE_BUILD"))
     if not force and not needs_build():
+        _record("reused", [])
+        if verbose:
+            print("reused", LIB)
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
     if force:
         for f in os.listdir(OBJ_DIR):
             os.remove(os.path.join(OBJ_DIR, f))
+    before = {s: os.path.getmtime(os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")) if os.path.exists(os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")) else 0.0
+              for s in SOURCES}
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(_compile, SOURCES))
+    compiled = [s for s, o in zip(SOURCES, objs) if os.path.getmtime(o) > before[s]]
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    _record("forced" if force else "compiled", compiled)
     if verbose:
-        print("built", LIB)
+        print("built", LIB, "(%d of %d sources compiled)" % (len(compiled), len(SOURCES)))
     return LIB
 
 

@@ -160,7 +160,6 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, 3) void mfcc_stream512_kernel(Mf
 
         for (int q = 0; q < Q; ++q) {
             if (q < nquads) {
-                const int t = ta + 4 * q + g;  // this lane group's frame
                 v2f z[16];
                 v2f pf[NZ];
                 v2f pm[PRE ? NZ : 1];
