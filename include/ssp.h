@@ -78,6 +78,9 @@ const char* ssp_last_error(void);
  * stream) and all work is enqueued on it;  borrow_stream == 0: the library creates and owns a stream. */
 int ssp_ctx_create(int device, void* stream, int borrow_stream, ssp_ctx** out);
 int ssp_ctx_destroy(ssp_ctx* ctx);
+/* test aid: fill the LDS of every CU with one 32-bit pattern (e.g. a NaN), so that a kernel reading LDS it never wrote shows up
+ * deterministically in the parity tests instead of depending on what the previous kernel left behind */
+int ssp_debug_poison_lds(ssp_ctx* ctx, uint32_t pattern);
 int ssp_ctx_sync(ssp_ctx* ctx);
 
 /* ---- segments: per-utterance offsets (host metadata -> device-resident) ------------- */

@@ -38,6 +38,7 @@ SIGNATURES = {
     "ssp_last_error": (C.c_char_p, []),
     "ssp_ctx_create": (C.c_int, [C.c_int, _P, C.c_int, C.POINTER(_P)]),
     "ssp_ctx_destroy": (C.c_int, [_P]),
+    "ssp_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
     "ssp_ctx_sync": (C.c_int, [_P]),
     "ssp_segments_create": (C.c_int, [_P, _I64P, C.c_int64, C.POINTER(_P)]),
     "ssp_segments_destroy": (C.c_int, [_P]),

@@ -5,6 +5,8 @@ results stay on the device).  PyTorch is used only for device memory and streams
 """
 from __future__ import annotations
 
+import contextlib
+
 import ctypes as C
 from typing import Optional, Sequence
 
@@ -52,6 +54,22 @@ class Context:
 
     def sync(self):
         _lib.check(self._lib.ssp_ctx_sync(self._h))
+
+    @contextlib.contextmanager
+    def _ordered(self, where):
+        """Stream ordering around a call that takes device pointers.  A context that BORROWS torch's stream needs none (the kernels
+        are queued behind the producers of their inputs and ahead of the consumers of their outputs).  A context that owns its
+        stream is ordered against nothing torch does, so device-pointer calls on it wait for torch's current stream first and are
+        complete when they return."""
+        own = where == _lib.DEVICE and self.stream is None
+        if own:
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
+        try:
+            yield
+        finally:
+            if own:
+                self.sync()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -181,8 +199,9 @@ class MfccPlan:
         if owhere != where or okeep is not out:
             raise ValueError("out must be a contiguous float32 array of the same kind as samples")
         ms = C.c_float(0.0)
-        _lib.check(self._lib.ssp_mfcc_run(self._h, sample_seg._h, frame_seg._h, ptr, optr, where, int(variant),
-                                           C.byref(ms) if timing else None))
+        with self.ctx._ordered(where):
+            _lib.check(self._lib.ssp_mfcc_run(self._h, sample_seg._h, frame_seg._h, ptr, optr, where, int(variant),
+                                               C.byref(ms) if timing else None))
         return (out, ms.value) if timing else out
 
     def close(self):
@@ -209,7 +228,8 @@ def enframe(ctx: Context, samples, frame_size: int, step: int, window):
         raise ValueError("window must have frame_size taps")
     out = ctx._empty((frame_size, n_frames), where)
     optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
-    _lib.check(ctx._lib.ssp_enframe(ctx._h, ptr, n, int(frame_size), int(step), w.ctypes.data, optr, where, None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_enframe(ctx._h, ptr, n, int(frame_size), int(step), w.ctypes.data, optr, where, None))
     return out
 
 
@@ -224,8 +244,9 @@ def cepstrum(ctx: Context, X, fbank, dct, log_mode: int, floor_mode: int, eps: f
         raise ValueError("fbank must be (n_filt, bins) and dct (n_ceps, n_filt)")
     out = ctx._empty((int(keep.shape[0]), dc.shape[0]), where)
     optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
-    _lib.check(ctx._lib.ssp_cepstrum(ctx._h, ptr, int(keep.shape[0]), int(keep.shape[1]), fb.ctypes.data, fb.shape[0], dc.ctypes.data,
-                                     dc.shape[0], int(log_mode), int(floor_mode), float(eps), optr, where, None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_cepstrum(ctx._h, ptr, int(keep.shape[0]), int(keep.shape[1]), fb.ctypes.data, fb.shape[0], dc.ctypes.data,
+                                         dc.shape[0], int(log_mode), int(floor_mode), float(eps), optr, where, None))
     return out
 
 
@@ -236,7 +257,8 @@ def spectrum_abs(ctx: Context, reim, n_bins: int, scale: float = 1.0, power: int
         raise ValueError("reim must be (rows, 2 * n_bins)")
     out = ctx._empty((int(keep.shape[0]), int(n_bins)), where)
     optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
-    _lib.check(ctx._lib.ssp_spectrum_abs(ctx._h, ptr, int(keep.shape[0]), int(n_bins), float(scale), int(power), optr, where, None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_spectrum_abs(ctx._h, ptr, int(keep.shape[0]), int(n_bins), float(scale), int(power), optr, where, None))
     return out
 
 
@@ -247,7 +269,8 @@ def delta_features(ctx: Context, feats, frame_seg: Segments, N: int = 2, timing:
     out = ctx._empty(tuple(keep.shape), where)
     ms = C.c_float(0.0)
     optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
-    _lib.check(ctx._lib.ssp_delta(ctx._h, ptr, frame_seg._h, int(keep.shape[1]), int(N), optr, where, C.byref(ms) if timing else None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_delta(ctx._h, ptr, frame_seg._h, int(keep.shape[1]), int(N), optr, where, C.byref(ms) if timing else None))
     return (out, ms.value) if timing else out
 
 
@@ -258,7 +281,8 @@ def cmvn_features(ctx: Context, feats, frame_seg: Segments, timing: bool = False
     out = ctx._empty(tuple(keep.shape), where)
     ms = C.c_float(0.0)
     optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
-    _lib.check(ctx._lib.ssp_cmvn(ctx._h, ptr, frame_seg._h, int(keep.shape[1]), optr, where, C.byref(ms) if timing else None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_cmvn(ctx._h, ptr, frame_seg._h, int(keep.shape[1]), optr, where, C.byref(ms) if timing else None))
     return (out, ms.value) if timing else out
 
 
@@ -272,8 +296,9 @@ def plp_post(ctx: Context, logspec, frame_seg: Segments, fmax_hz: float, plp_ord
     out = ctx._empty((int(keep.shape[0]), int(plp_order)), where)
     ms = C.c_float(0.0)
     optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
-    _lib.check(ctx._lib.ssp_plp_post(ctx._h, ptr, frame_seg._h, int(keep.shape[1]), float(fmax_hz), int(plp_order), int(bool(rasta)),
-                                     float(lift), optr, where, C.byref(ms) if timing else None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_plp_post(ctx._h, ptr, frame_seg._h, int(keep.shape[1]), float(fmax_hz), int(plp_order), int(bool(rasta)),
+                                         float(lift), optr, where, C.byref(ms) if timing else None))
     return (out, ms.value) if timing else out
 
 
@@ -295,9 +320,10 @@ def gmm_em_stats(ctx: "Context", weights, means, covars, feats, timing: bool = F
     sxx = np.empty((K, D), dtype=np.float64)
     ll = C.c_double(0.0)
     ms = C.c_float(0.0)
-    _lib.check(ctx._lib.ssp_gmm_em_stats(ctx._h, K, D, w.ctypes.data, mu.ctypes.data, cv.ctypes.data, ptr, int(keep.shape[0]),
-                                          nk.ctypes.data, sx.ctypes.data, sxx.ctypes.data, C.byref(ll), where,
-                                          C.byref(ms) if timing else None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_gmm_em_stats(ctx._h, K, D, w.ctypes.data, mu.ctypes.data, cv.ctypes.data, ptr, int(keep.shape[0]),
+                                              nk.ctypes.data, sx.ctypes.data, sxx.ctypes.data, C.byref(ll), where,
+                                              C.byref(ms) if timing else None))
     res = {"nk": nk, "sx": sx, "sxx": sxx, "loglik_sum": ll.value}
     if timing:
         res["kernel_ms"] = ms.value
@@ -355,8 +381,9 @@ class GmmScorer:
                 return None
             return x.data_ptr() if where == _lib.DEVICE else x.ctypes.data
         ms = C.c_float(0.0)
-        _lib.check(self._lib.ssp_gmm_score(self._h, ptr, frame_seg._h, p(ll), p(sc), p(am), where, int(precision),
-                                            C.byref(ms) if timing else None))
+        with self.ctx._ordered(where):
+            _lib.check(self._lib.ssp_gmm_score(self._h, ptr, frame_seg._h, p(ll), p(sc), p(am), where, int(precision),
+                                                C.byref(ms) if timing else None))
         if loglik:
             res["loglik"] = ll
         if scores:
@@ -395,7 +422,8 @@ def centroids(ctx: Context, X, labels, num: int):
         raise ValueError("one label per row of X")
     out = ctx._empty((int(num), int(keep.shape[1])), where)
     optr = out.data_ptr() if where == _lib.DEVICE else out.ctypes.data
-    _lib.check(ctx._lib.ssp_centroids(ctx._h, ptr, lptr, int(keep.shape[0]), int(keep.shape[1]), int(num), optr, where, None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_centroids(ctx._h, ptr, lptr, int(keep.shape[0]), int(keep.shape[1]), int(num), optr, where, None))
     return out
 
 
@@ -459,8 +487,9 @@ def dense_forward(ctx: Context, X, Wt, bias=None, relu: bool = False, timing: bo
     Y = ctx._empty((N, units), where)
     yp = Y.data_ptr() if where == _lib.DEVICE else Y.ctypes.data
     ms = C.c_float(0.0)
-    _lib.check(ctx._lib.ssp_dense_forward(ctx._h, xp, N, d_in, wp, bp, units, 1 if relu else 0, yp, where,
-                                           C.byref(ms) if timing else None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_dense_forward(ctx._h, xp, N, d_in, wp, bp, units, 1 if relu else 0, yp, where,
+                                               C.byref(ms) if timing else None))
     return (Y, ms.value) if timing else Y
 
 
@@ -484,7 +513,8 @@ def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True
             return None
         return x.data_ptr() if where == _lib.DEVICE else x.ctypes.data
     ms = C.c_float(0.0)
-    _lib.check(ctx._lib.ssp_cosine_identify(ctx._h, xp, N, d, cp, S, p(dm), p(am), p(mv), where, C.byref(ms) if timing else None))
+    with ctx._ordered(where):
+        _lib.check(ctx._lib.ssp_cosine_identify(ctx._h, xp, N, d, cp, S, p(dm), p(am), p(mv), where, C.byref(ms) if timing else None))
     res = {}
     if dist:
         res["dist"] = dm

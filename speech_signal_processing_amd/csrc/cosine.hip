@@ -166,10 +166,14 @@ __global__ __launch_bounds__(256) void cosine_kernel(CosArgs a) {
                     const int row = rb * BM + wr * 64 + rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                     if (row < a.S) {
                         float dv = 1.0f - acc[rt][ct][i] * a.inc[row] * ix;
-                        dv = fminf(fmaxf(dv, 0.0f), 2.0f);
+                        // clip to [0, 2] like scipy, but a NaN (zero-norm embedding, empty speaker's centroid) stays a NaN: as the
+                        // arg-min key it orders first, like numpy's argmin (d_vector.py:319)
+                        const bool fin = dv == dv;
+                        dv = fin ? fminf(fmaxf(dv, 0.0f), 2.0f) : dv;
                         if (a.dist && gc < a.N) a.dist[gc * a.S + row] = dv;
-                        if (dv < best[ct] || (dv == best[ct] && row < besti[ct])) {
-                            best[ct] = dv;
+                        const float key = fin ? dv : -INFINITY;
+                        if (key < best[ct] || (key == best[ct] && row < besti[ct])) {
+                            best[ct] = key;
                             besti[ct] = row;
                         }
                     }
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void cosine_kernel(CosArgs a) {
             i0 = i1;
         }
         if (a.argmin) a.argmin[gc] = i0 == 0x7fffffff ? 0 : i0;
-        if (a.minval) a.minval[gc] = b0;
+        if (a.minval) a.minval[gc] = b0 == -INFINITY ? __builtin_nanf("") : b0;
     }
 }
 
@@ -399,10 +403,12 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
                 const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (row < a.S) {
                     float dv = 1.0f - acc[i] * ix;
-                    dv = fminf(fmaxf(dv, 0.0f), 2.0f);
+                    const bool fin = dv == dv;  // a NaN stays a NaN and orders first (see cosine_kernel)
+                    dv = fin ? fminf(fmaxf(dv, 0.0f), 2.0f) : dv;
                     if (a.dist && gc < a.N) a.dist[gc * a.S + row] = dv;
-                    if (dv < best || (dv == best && row < besti)) {
-                        best = dv;
+                    const float key = fin ? dv : -INFINITY;
+                    if (key < best || (key == best && row < besti)) {
+                        best = key;
                         besti = row;
                     }
                 }
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
     }
     if (h == 0 && gc < a.N) {
         if (a.argmin) a.argmin[gc] = besti == 0x7fffffff ? 0 : besti;
-        if (a.minval) a.minval[gc] = best;
+        if (a.minval) a.minval[gc] = best == -INFINITY ? __builtin_nanf("") : best;  // (distances are >= 0: -inf is the NaN key)
     }
 }
 

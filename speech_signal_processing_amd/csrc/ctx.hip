@@ -47,9 +47,30 @@ int segments_make(ssp_ctx* ctx, const int64_t* offsets, int64_t n, ssp_segments*
     return SSP_OK;
 }
 
+// fills the whole LDS of the CU it lands on with one 32-bit pattern (test aid: a kernel that reads LDS it never wrote then reads
+// this pattern — e.g. a NaN — instead of whatever the previous kernel left behind)
+__global__ __launch_bounds__(256) void poison_lds_kernel(uint32_t pattern, uint32_t* sink) {
+    extern __shared__ uint32_t lds_all[];
+    const int n = 160 * 1024 / 4;
+    for (int i = threadIdx.x; i < n; i += 256) lds_all[i] = pattern;
+    __syncthreads();
+    if (lds_all[(threadIdx.x * 97) % n] != pattern) sink[0] = 1;  // (keeps the stores alive)
+}
+
 }  // namespace ssp
 
 extern "C" {
+
+int ssp_debug_poison_lds(ssp_ctx* ctx, uint32_t pattern) {
+    SSP_TRY(ssp::use_ctx(ctx));
+    SSP_TRY(ctx->scratch[5].reserve(16));
+    SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ssp::poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // one workgroup owns a CU's whole LDS: a few rounds over the CUs reach every one of them
+    hipLaunchKernelGGL(ssp::poison_lds_kernel, dim3(4 * ctx->num_cu), dim3(256), 160 * 1024, ctx->stream, pattern, ctx->scratch[5].as<uint32_t>());
+    SSP_HIP(hipGetLastError());
+    SSP_HIP(hipStreamSynchronize(ctx->stream));
+    return SSP_OK;
+}
 
 int ssp_abi_version(void) { return SSP_ABI_VERSION; }
 

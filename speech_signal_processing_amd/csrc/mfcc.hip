@@ -131,6 +131,9 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
 #endif
 
     v2f* buf = reinterpret_cast<v2f*>(smem) + (size_t)wave * (M + (M >> 4));  // wave-private, M padded complex points
+    // the pad slots (one per 16 points) are never written by the FFT, and the filterbank's 16-byte reads run past bin M over them
+    // under zero weights: whatever a previous kernel left in LDS (a NaN, an infinity) must not be there
+    for (int i = lane; i < M + (M >> 4); i += 64) buf[i] = v2f{0.f, 0.f};
     float* logmel = reinterpret_cast<float*>(smem + a.lds_logmel_off) + wave * a.n_filt;
     float* ceps = reinterpret_cast<float*>(smem + a.lds_ceps_off);
     float* dlt = reinterpret_cast<float*>(smem + a.lds_dlt_off);

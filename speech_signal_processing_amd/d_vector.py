@@ -62,6 +62,64 @@ class DenseNet:
         return h if is_t else h.cpu().numpy()
 
 
+# ---- model registry: the reference addresses its networks by name — load_model('feature/d_vector/d_vector_{}.h5'.format(model_name)),
+# d_vector.py:297,329,347.  Keras / h5py are not part of this path: a DenseNet is registered under the name (or saved next to where
+# the .h5 would be, as d_vector_{name}.npz) and `model_name=` resolves to it.
+_MODELS = {}
+MODEL_DIR = os.path.join('feature', 'd_vector')
+
+
+def register_model(name, net):
+    """Make ``net`` (a DenseNet, or any object with .predict) the model that ``model_name=name`` refers to."""
+    _MODELS[str(name)] = net
+
+
+def save_model(net: "DenseNet", name, model_dir=None):
+    """Store a DenseNet's weights as {model_dir}/d_vector_{name}.npz (the .h5's place, d_vector.py:297)."""
+    model_dir = MODEL_DIR if model_dir is None else model_dir
+    os.makedirs(model_dir, exist_ok=True)
+    arrs = {}
+    for i, (Wt, bt, relu) in enumerate(net.layers):
+        arrs["W%d" % i] = Wt.cpu().numpy().T
+        arrs["b%d" % i] = np.zeros(0, np.float32) if bt is None else bt.cpu().numpy()
+        arrs["a%d" % i] = np.array(1 if relu else 0)
+    np.savez(os.path.join(model_dir, "d_vector_%s.npz" % name), **arrs)
+
+
+def load_model(name, model_dir=None):
+    """The network ``model_name`` refers to: a registered one, else {model_dir}/d_vector_{name}.npz; OSError when neither exists (as
+    keras.models.load_model raises for a missing file)."""
+    name = str(name)
+    if name in _MODELS:
+        return _MODELS[name]
+    path = os.path.join(MODEL_DIR if model_dir is None else model_dir, "d_vector_%s.npz" % name)
+    if not os.path.exists(path):
+        raise OSError("no d-vector model %r: register_model(%r, net) or save one as %s" % (name, name, path))
+    z = np.load(path)
+    n = len([k for k in z.files if k.startswith("W")])
+    net = DenseNet([(z["W%d" % i], z["b%d" % i] if z["b%d" % i].size else None, 'relu' if int(z["a%d" % i]) else 'linear') for i in range(n)])
+    _MODELS[name] = net
+    return net
+
+
+_UNSET = object()
+
+
+def _resolve_model(model_name, spk_model, default_name):
+    """spk_model= (an object) wins; an explicit model_name= must resolve (OSError otherwise, like the reference); with neither given the
+    reference's default name is tried and, when no such model exists, the inputs are taken to be embeddings already."""
+    if spk_model is not None:
+        return spk_model
+    if model_name is _UNSET:
+        try:
+            return load_model(default_name)
+        except OSError:
+            return None
+    if model_name is None:
+        return None
+    return model_name if hasattr(model_name, "predict") else load_model(model_name)
+
+
 class Data_gen:
     """Feature front end of d_vector.Data_gen: 1-second chunks -> sidekit mfcc(x, fs)[0] -> (98, 13) (d_vector.py:80-98)."""
 
@@ -135,19 +193,25 @@ class nn_model:
             with open(self.store, 'wb') as f:
                 pkl.dump(self.d_vector, f)
 
-    def test(self, X_train, Y_train, X_val, Y_val, spk_model=None):
-        """d_vector.py:296-320: (with ``spk_model``: X = spk_model.predict(X), d_vector.py:298-299) per-speaker centroids
-        of X_train (one-hot Y_train), cosine distance of every X_val row to every centroid, accuracy of the arg-min."""
+    def test(self, X_train, Y_train, X_val, Y_val, model_name=_UNSET, spk_model=None):
+        """d_vector.py:296-320, same positional signature: X = spkModel.predict(X) with the network ``model_name`` names (default
+        'nn'; see _resolve_model), per-speaker centroids of X_train (one-hot Y_train), cosine distance of every X_val row to every
+        centroid, accuracy of the arg-min.  The centroids stay available as ``self.centroids_`` (float64 (num, d) like the reference's
+        ``avg``, d_vector.py:310)."""
+        spk_model = _resolve_model(model_name, spk_model, 'nn')
         if spk_model is not None:
             X_train, X_val = spk_model.predict(X_train), spk_model.predict(X_val)
         num = Y_train.shape[1]
         lab = np.argmax(Y_train, axis=1)  # decoding the one-hot labels is index bookkeeping, not arithmetic
         avg = np.asarray(api.centroids(api.default_context(), np.asarray(X_train, dtype=np.float32), lab, num))
+        self.centroids_ = avg.astype(np.float64)
         pred = identify(np.asarray(X_val, dtype=np.float32), avg)
         return (np.argmax(Y_val, axis=1) == pred).sum() / X_val.shape[0]
 
-    def enroll(self, X_train, name, spk_model=None):
-        """d_vector.py:322-344: store the mean embedding under ``name`` (overwrites, like the reference)."""
+    def enroll(self, X_train, name, model_name=_UNSET, spk_model=None):
+        """d_vector.py:322-344, same positional signature (default model 'lstm'): store the mean embedding under ``name`` (overwrites,
+        like the reference)."""
+        spk_model = _resolve_model(model_name, spk_model, 'lstm')
         if spk_model is not None:
             X_train = spk_model.predict(X_train)
         self._load()
@@ -157,8 +221,12 @@ class nn_model:
         self.d_vector[name] = np.asarray(api.centroids(api.default_context(), X, np.zeros(len(X), np.int32), 1))[0]
         self._save()
 
-    def eval(self, target, spk_model=None):
-        """d_vector.py:346-361: linear scan in dict order; the minimum is kept only while < 1; returns the name or None."""
+    def eval(self, target, model_name=_UNSET, spk_model=None):
+        """d_vector.py:346-361, same positional signature (default model 'lstm'): the distances to every enrolled vector come from the
+        GPU scorer; the decision is the reference's own scan in dict order — the running minimum starts at 1 and only a strictly
+        smaller distance replaces it, so a NaN distance (zero-norm embedding or enrolment) is never selected and ties keep the first
+        name.  Returns the name or None."""
+        spk_model = _resolve_model(model_name, spk_model, 'lstm')
         if spk_model is not None:
             target = spk_model.predict(np.asarray(target, dtype=np.float32).reshape(1, -1))
         self._load()
@@ -167,6 +235,10 @@ class nn_model:
         names = list(self.d_vector.keys())
         C = np.stack([self.d_vector[n] for n in names]).astype(np.float32)
         r = api.cosine_identify(api.default_context(), np.asarray(target, dtype=np.float32).reshape(1, -1), C,
-                                dist=False, argmin=True, minval=True)
-        mn = float(np.asarray(r["min"])[0])
-        return names[int(np.asarray(r["argmin"])[0])] if mn < 1 else None
+                                dist=True, argmin=False, minval=False)
+        dist = np.asarray(r["dist"], dtype=np.float64).reshape(-1)
+        min_distance, target_name = 1, None
+        for name, dv in zip(names, dist):
+            if min_distance > dv:
+                min_distance, target_name = dv, name
+        return target_name

@@ -79,7 +79,7 @@ def MFCC(raw_signal, fs=8000, frameSize=512, step=256):
     kernel for power-of-two frame sizes, a DFT-matrix product on the matrix cores for any other size)."""
     x = np.ascontiguousarray(np.asarray(raw_signal).reshape(-1), dtype=np.float32)
     L = int(frameSize)
-    if L < 64 or L > 4096 or (L & (L - 1)):
+    if L < 64 or L > 2048 or (L & (L - 1)):  # (the fused plans cover power-of-two frames up to 2048, ssp_mfcc_plan_create)
         return _mfcc_any_size(x, int(fs), L, int(step))
     plan = _plan(int(fs), int(frameSize), int(step), 13, False)
     seg = api.Segments.from_lengths(plan.ctx, [x.shape[0]])
@@ -91,7 +91,7 @@ def MFCC_batch(signals, fs=8000, frameSize=512, step=256):
     """Batched form of MFCC(): list of 1-D signals -> list of (frames_i, 13) float64 (one kernel launch)."""
     sig = [np.asarray(s, dtype=np.float32).reshape(-1) for s in signals]
     L = int(frameSize)
-    if L < 64 or L > 4096 or (L & (L - 1)):
+    if L < 64 or L > 2048 or (L & (L - 1)):  # (the fused plans cover power-of-two frames up to 2048, ssp_mfcc_plan_create)
         return [_mfcc_any_size(s, int(fs), L, int(step)) for s in sig]
     plan = _plan(int(fs), int(frameSize), int(step), 13, False)
     seg = api.Segments.from_lengths(plan.ctx, [s.shape[0] for s in sig])

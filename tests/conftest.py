@@ -31,3 +31,19 @@ def synth_audio(utt, n, fs, S=10):
     x = 0.3 * sum(np.sin(2 * np.pi * h * f0 * t) / h for h in range(1, 6)) * (0.6 + 0.4 * np.sin(2 * np.pi * 3 * t))
     x = x + 0.05 * rng.standard_normal(n)
     return np.clip(x, -1, 1).astype(np.float32)
+
+
+@pytest.fixture(autouse=True)
+def _poison_lds(request):
+    """Before every GPU test the LDS of every CU is filled with NaNs (ssp_debug_poison_lds): a kernel that reads LDS it never wrote then
+    fails its parity test every time, instead of only when the previous kernel happened to leave a NaN or an infinity behind."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    try:
+        from speech_signal_processing_amd import api, _lib
+        ctx = api.default_context(torch_stream=False)
+        _lib.check(_lib.load().ssp_debug_poison_lds(ctx._h, 0x7FC00000))
+    except Exception as e:  # pragma: no cover - no GPU / library: the test itself reports that
+        print("LDS poison skipped:", repr(e))
+    yield

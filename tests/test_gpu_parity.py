@@ -16,6 +16,18 @@ pytestmark = pytest.mark.gpu
 FEAT_TOL = 1e-4
 
 
+OBSERVED = {}
+
+
+def observe(key, err, bound):
+    """Relaxed bounds (anything above 1e-4) log the largest error seen per key; run with -s to read them (bounds are kept <= 2x these)."""
+    cur = OBSERVED.get(key, (0.0, bound))
+    if err > cur[0]:
+        OBSERVED[key] = (float(err), bound)
+        print("[observed] %s: %.3e (bound %.1e)" % (key, err, bound))
+    return err
+
+
 def assert_feat_close(got, ref, tol=FEAT_TOL, what=""):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
@@ -28,6 +40,8 @@ def assert_feat_close(got, ref, tol=FEAT_TOL, what=""):
     if r.size == 0:
         return
     err = np.abs(g - r).max()
+    if tol != FEAT_TOL:  # relaxed bound: log what was observed (the bound must stay within 2x of it)
+        print("[observed] %s: max err / max(1, max|ref|) = %.3e (bound %.1e)" % (what, err / max(1.0, np.abs(r).max()), tol))
     assert err <= tol * max(1.0, np.abs(r).max()), "%s: max abs err %.3e (ref max %.3e)" % (what, err, np.abs(r).max())
     rms = np.sqrt(np.mean(r * r))
     assert np.allclose(g, r, rtol=tol, atol=tol * max(rms, 1e-30)), "%s: allclose(rtol=1e-4, atol=1e-4*rms) failed, max err %.3e rms %.3e" % (what, err, rms)
@@ -136,7 +150,7 @@ def test_stream_kernel_vs_oracle(ssp, delta_order, cmvn):
     worst = 0.0
     for u, s in enumerate(sigs):
         ref = O.mfcc_pipeline(s, cfg, w, fb, dct)
-        assert_feat_close(got[u], ref, tol=2e-4 if cmvn else FEAT_TOL, what=f"stream utt {u} len {len(s)} order {delta_order} cmvn {cmvn}")
+        assert_feat_close(got[u], ref, what=f"stream utt {u} len {len(s)} order {delta_order} cmvn {cmvn}")
         if ref.size:
             worst = max(worst, np.abs(got[u] - ref).max() / max(1.0, np.abs(ref).max()))
     print("stream kernel: worst relative error %.2e" % worst)
@@ -315,7 +329,7 @@ def test_cmvn_long_utterances(ssp, variant):
     cfg, w, fb, dct = O.sidekit_tables(delta_order=1, cmvn=1)
     for u, s_ in enumerate(sigs):
         ref = O.mfcc_pipeline(s_, cfg, w, fb, dct)
-        assert_feat_close(got[u], ref, tol=2e-4, what=f"long cmvn utt {u} variant {variant}")
+        assert_feat_close(got[u], ref, what=f"long cmvn utt {u} variant {variant}")
         assert abs(got[u].mean()) < 1e-4 and abs(got[u].std(0).mean() - 1) < 1e-3
 
 
@@ -329,8 +343,8 @@ def test_librosa_long_utterance_two_pass_top_db(ssp):
     got, _ = _run_plan(api, pkg.preset_librosa(8000, 13), sigs, variant=0)
     cfg, w, fb, dct = O.librosa_tables(8000, 13)
     for u, s_ in enumerate(sigs):
-        assert_feat_close(got[u], O.mfcc_pipeline(s_, cfg, w, fb, dct), tol=2e-4, what=f"librosa long utt {u}")
-    assert_feat_close(MFCC_DTW.MFCC_lib(sigs[0]), O.librosa_mfcc_flat(sigs[0]), tol=2e-4, what="MFCC_lib long")
+        assert_feat_close(got[u], O.mfcc_pipeline(s_, cfg, w, fb, dct), what=f"librosa long utt {u}")
+    assert_feat_close(MFCC_DTW.MFCC_lib(sigs[0]), O.librosa_mfcc_flat(sigs[0]), what="MFCC_lib long")
 
 
 def test_fast_kernel_long_utterance_chunking(ssp):
@@ -475,7 +489,8 @@ def test_gmm_cfg3_shape_vs_oracle(ssp, precision):
     assert np.abs(r["scores"] - ref_scores).max() <= 1e-4 * np.abs(ref_scores).max()
     np.testing.assert_allclose(r["scores"], ref_scores, rtol=1e-4)
     assert (np.asarray(r["argmax"]) == ref_am).all()
-    assert np.abs(got_pred - ref_pred).max() < 2e-3
+    observe("cfg3 score differences (abs)", np.abs(got_pred - ref_pred).max(), 1e-4)  # observed 1.4e-5 (fp32) / 4.9e-5 (bf16x3) on |score| <= 60
+    assert np.abs(got_pred - ref_pred).max() < 1e-4
     ll_ref = O.gmm_score_samples(w, mus[3], cov, np.vstack(feats))
     np.testing.assert_allclose(r["loglik"][3], ll_ref, rtol=1e-4, atol=1e-4)
 
@@ -499,6 +514,53 @@ def test_gmm_cfg4_shape_512_mixtures(ssp, precision):
     ref = np.array([[O.gmm_score(w, m, cov, f) for m in mus] for f in feats])
     np.testing.assert_allclose(r["scores"], ref, rtol=1e-4)
     np.testing.assert_allclose(r["loglik"][2], O.gmm_score_samples(w, mus[2], cov, np.vstack(feats)), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_gmm_configs3_model_count_vs_oracle(ssp, precision):
+    """configs[3] at its real model shape — 1251 speaker models + UBM, K = 512 mixtures, D = 39 — on a small ragged batch
+    (the reference loop it replaces: GMM_UBM.py:181-197); every one of the 1252 x U scores and the arg-max against the oracle."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(33)
+    K, D, S = 512, 39, 1251
+    w = rng.dirichlet(5 * np.ones(K))
+    mu = rng.standard_normal((K, D))
+    cov = rng.uniform(0.5, 2.0, (K, D))
+    mus = np.empty((S + 1, K, D))
+    mus[0] = mu
+    for i in range(S):
+        mus[i + 1] = mu + 0.3 * rng.standard_normal((K, D))
+    lens = np.array([1, 7, 33, 64, 2, 19])
+    spk = [5, 1250, 0, 700, 33, 1249]
+    feats = []
+    for n, sidx in zip(lens, spk):
+        comp = rng.choice(K, size=n, p=w)
+        feats.append((mus[1 + sidx][comp] + np.sqrt(cov[comp]) * rng.standard_normal((n, D))).astype(np.float32))
+    ctx = api.default_context()
+    sc = api.GmmScorer(ctx, np.broadcast_to(w, (S + 1, K)), mus, np.broadcast_to(cov, (S + 1, K, D)), has_ubm=True)
+    r = sc.score(np.vstack(feats), api.Segments.from_lengths(ctx, lens), precision=precision)
+    # oracle, vectorised over the models (same float64 arithmetic as O.gmm_score per model)
+    prec = 1.0 / cov
+    lognorm = np.log(w) + 0.5 * np.log(prec).sum(1) - 0.5 * D * np.log(2 * np.pi)
+    ref = np.empty((len(lens), S + 1))
+    for u, f in enumerate(feats):
+        x = f.astype(np.float64)
+        for m in range(S + 1):
+            d = x[:, None, :] - mus[m][None]
+            lp = lognorm[None] - 0.5 * (d * d * prec[None]).sum(2)
+            mx = lp.max(1, keepdims=True)
+            ref[u, m] = (mx[:, 0] + np.log(np.exp(lp - mx).sum(1))).mean()
+    assert abs(ref[2, 3] - O.gmm_score(w, mus[3], cov, feats[2])) < 1e-9  # the vectorised form is the oracle's
+    got = np.asarray(r["scores"], dtype=np.float64)
+    assert got.shape == (len(lens), S + 1)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    print("configs[3] shape, precision %d: max rel err %.2e, min top-2 margin %.3e" % (precision, err, np.sort(ref[:, 1:] - ref[:, :1], axis=1)[:, -1].min() - np.sort(ref[:, 1:] - ref[:, :1], axis=1)[:, -2].max()))
+    assert err <= 1e-4
+    ref_am = (ref[:, 1:] - ref[:, :1]).argmax(1)
+    margin = np.sort(ref[:, 1:], axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 1e-3 * np.abs(ref).max()   # rows whose float64 top-2 margin an fp32 path can resolve
+    assert (np.asarray(r["argmax"])[safe] == ref_am[safe]).all() and safe.sum() >= 3
 
 
 def test_gmm_bounded_scratch_batches(ssp, monkeypatch):
@@ -739,6 +801,109 @@ def test_nn_model_test_enroll_eval(ssp):
     assert m.eval(-m.d_vector["spk0"] - m.d_vector["spk1"] - m.d_vector["spk2"]) is None  # every distance >= 1
 
 
+def test_cosine_nan_rules_match_scipy_and_the_reference_scan(ssp):
+    """A zero-norm embedding / an empty speaker's centroid gives scipy.spatial.distance.cosine = NaN.  The kernels keep the NaN
+    (no clamp to 0 = 'perfect match'), arg-min orders it first like numpy.argmin (d_vector.py:319), and nn_model.eval's scan
+    (d_vector.py:352-358) never selects it."""
+    pkg, api = ssp
+    from speech_signal_processing_amd import d_vector
+    rng = np.random.default_rng(8)
+    for d in (256, 320):  # register-resident kernel and the tiled one
+        Cn = rng.standard_normal((7, d)).astype(np.float32)
+        Cn[3] = np.nan                      # numpy's mean of an empty slice
+        X = rng.standard_normal((5, d)).astype(np.float32)
+        X[2] = 0.0                          # zero-norm embedding
+        r = api.cosine_identify(api.default_context(), X, Cn, dist=True, argmin=True, minval=True)
+        dist = np.asarray(r["dist"])
+        assert np.isnan(dist[:, 3]).all() and np.isnan(dist[2]).all()
+        ok = np.ones_like(dist, dtype=bool)
+        ok[:, 3] = False
+        ok[2] = False
+        ref = 1.0 - (X @ np.nan_to_num(Cn).T) / (np.linalg.norm(X, axis=1)[:, None] * np.linalg.norm(np.nan_to_num(Cn), axis=1)[None] + 1e-30)
+        np.testing.assert_allclose(dist[ok], ref[ok], atol=3e-6)
+        with np.errstate(invalid="ignore"):
+            assert (np.asarray(r["argmin"]) == np.argmin(dist, axis=1)).all()      # numpy: the first NaN wins
+        assert np.isnan(np.asarray(r["min"])).all()
+    m = d_vector.nn_model()
+    m.d_vector = {"zero": np.zeros(16, np.float32), "a": np.ones(16, np.float32), "b": -np.ones(16, np.float32)}
+    assert m.eval(np.ones(16, np.float32), model_name=None) == "a"                  # the NaN entry comes first and is skipped
+    assert m.eval(np.zeros(16, np.float32), model_name=None) is None                # every distance NaN: no match
+    m.d_vector = {"far": -np.ones(16, np.float32)}
+    assert m.eval(np.ones(16, np.float32), model_name=None) is None                 # distance 2 >= 1
+
+
+def test_nn_model_model_name_surface(ssp, tmp_path):
+    """The reference's positional / keyword surface: test(X_train, Y_train, X_val, Y_val, model_name), enroll(X, name, model_name),
+    eval(target, model_name) (d_vector.py:296,322,346) — model_name resolves through the registry or a saved d_vector_{name}.npz;
+    an unknown explicit name raises OSError like keras' load_model."""
+    pkg, api = ssp
+    from speech_signal_processing_amd import d_vector
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(12)
+    layers = [((rng.standard_normal((40, 32)) / 6).astype(np.float32), rng.standard_normal(32).astype(np.float32) * 0.1, 'relu'),
+              ((rng.standard_normal((32, 16)) / 5).astype(np.float32), None, 'linear')]
+    net = d_vector.DenseNet(layers)
+    d_vector.register_model('nn', net)
+    S, N = 5, 400
+    lab = rng.integers(0, S, N)
+    protos = rng.standard_normal((S, 40)).astype(np.float32) * 2
+    X = (protos[lab] + 0.3 * rng.standard_normal((N, 40))).astype(np.float32)
+    Y = np.eye(S)[lab]
+    m = d_vector.nn_model(store=str(tmp_path / "d_vector.pkl"))
+    acc_pos = m.test(X[::2], Y[::2], X[1::2], Y[1::2], 'nn')                          # positional, as the reference is called
+    acc_kw = m.test(X[::2], Y[::2], X[1::2], Y[1::2], model_name='nn')
+    acc_default = m.test(X[::2], Y[::2], X[1::2], Y[1::2])                          # reference default model_name='nn'
+    emb = O.dense_net_forward(X, layers)
+    avg = np.stack([emb[::2][lab[::2] == s].mean(0) for s in range(S)])
+    ref_acc = (O.identify(emb[1::2], avg) == lab[1::2]).mean()
+    assert acc_pos == acc_kw == acc_default == ref_acc
+    assert m.centroids_.dtype == np.float64 and m.centroids_.shape == (S, 16)
+    np.testing.assert_allclose(m.centroids_, avg, atol=1e-5)
+    with pytest.raises(OSError):
+        m.test(X[::2], Y[::2], X[1::2], Y[1::2], model_name='no_such_model')
+    d_vector.save_model(net, 'lstm', model_dir=str(tmp_path))
+    d_vector._MODELS.pop('lstm', None)
+    old_dir, d_vector.MODEL_DIR = d_vector.MODEL_DIR, str(tmp_path)
+    try:
+        m.enroll(X[lab == 0], 'spk0', 'lstm')                                        # loads d_vector_lstm.npz from MODEL_DIR
+        m.enroll(X[lab == 1], 'spk1', model_name='lstm')
+        assert m.eval(X[lab == 1][:1], 'lstm') == 'spk1' and m.eval(X[lab == 0][:1]) == 'spk0'
+    finally:
+        d_vector.MODEL_DIR = old_dir
+        d_vector._MODELS.pop('lstm', None)
+        d_vector._MODELS.pop('nn', None)
+
+
+def test_own_stream_context_orders_against_torch(ssp):
+    """A Context that owns its stream (default_context()) given torch CUDA tensors: the call waits for torch's stream first and is
+    complete when it returns, so producer -> library -> consumer chains on torch's stream give the same numbers as the borrowed-stream
+    context."""
+    import torch
+    pkg, api = ssp
+    own = api.Context(0)                      # library-owned non-blocking stream
+    tor = api.Context.for_torch(0)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    for rep in range(3):
+        x = torch.randn((20000, 1274), generator=gen, device="cuda")
+        w = torch.randn((256, 1274), generator=gen, device="cuda") / 36
+        y = x * 1.5 + 0.25                    # producer on torch's stream, consumed right away by the library call
+        a = api.dense_forward(own, y, w, None, relu=True)
+        got = (a * 2).sum().item()            # consumer on torch's stream
+        b = api.dense_forward(tor, y, w, None, relu=True)
+        assert got == (b * 2).sum().item()
+    own.close()
+
+
+def test_inrepo_mfcc_frame_4096_takes_the_dft_path(ssp):
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd.utils import processing as P
+    x = synth_audio(3, 20000, 16000)
+    got = P.MFCC(x, fs=16000, frameSize=4096, step=2048)
+    assert_feat_close(got, O.MFCC(x, fs=16000, frameSize=4096, step=2048), what="frameSize 4096")
+
+
 def test_centroids_vs_numpy_float64(ssp):
     """d_vector.py:310-313: avg[i] = X_train[label == i].mean(axis=0) (float64 accumulator); an unused label gives NaN."""
     pkg, api = ssp
@@ -938,6 +1103,34 @@ def test_full_size_cfg1_mfcc_replication(ssp):
     assert bool((out2 == out).all()), "two launches on the same input differ"
 
 
+@pytest.mark.parametrize("fs", [16000, 8000])
+def test_full_size_inrepo_mfcc_replication_vs_reference_golden(golden, ssp, fs):
+    """The reference-pinned dialect at bench size (bench.py stage `inrepo`): 100k x 48000 samples resident, in-repo MFCC 512/256, 13-d.
+    Utterance u = base[u % 8]; base[0] is the golden `utt3s16k` signal, whose rows are compared with the REFERENCE's own output
+    (utils.processing.MFCC run by tests/golden/make_golden.py); the other seven against the oracle; all copies bit-identical."""
+    import torch
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    g = golden("mfcc_inrepo")
+    R, n_utt, n = 8, 100000, 48000
+    base = np.stack([g["x_utt3s16k"].astype(np.float32)] + [synth_audio(u, n, 16000) for u in range(1, R)])
+    ctx = api.Context.for_torch(0)
+    audio = torch.from_numpy(base).cuda().repeat(n_utt // R, 1)
+    plan = api.MfccPlan(ctx, pkg.preset_inrepo(fs, 512, 256))
+    seg = api.Segments.from_lengths(ctx, np.full(n_utt, n, dtype=np.int64))
+    fseg = plan.frame_segments(seg)
+    out = plan.run(audio.view(-1), seg, fseg)
+    torch.cuda.synchronize()
+    T = fseg.total // n_utt
+    assert T == 188 and out.shape == (n_utt * T, 13)
+    blocks = out.view(n_utt // R, R * T * 13)
+    assert bool((blocks == blocks[0]).all()), "copies of the same utterance differ inside one launch"
+    got = out[: R * T].cpu().numpy()
+    assert_feat_close(got[:T], g[f"mfcc_utt3s16k_{fs}_512_256"], what=f"full-size in-repo {fs}: golden utt3s16k vs the reference's output")
+    for u in range(1, R):
+        assert_feat_close(got[u * T:(u + 1) * T], O.MFCC(base[u], fs=fs, frameSize=512, step=256), what="full-size in-repo utt %d" % u)
+
+
 def test_full_size_cfg2_gmm_replication(ssp):
     import torch
     pkg, api = ssp
@@ -1050,8 +1243,10 @@ def test_generic_kernel_config_sweep(ssp, n_fft):
                 continue
             scale = max(1.0, np.abs(ref[fin]).max())
             err = np.abs(got[u][fin] - ref[fin]).max() / scale
-            # cmvn divides by a per-column std that can be tiny next to the column's magnitude: looser bound there
-            assert err <= (2e-3 if cfg.cmvn else 2e-4), (case, u, lens[u], err, cfg)
+            # observed on MI355X over this sweep: <= 2.5e-6 without and <= 9.4e-6 with CMVN (whose division by a small per-column std
+            # amplifies); the bound is the north-star tolerance
+            observe("generic sweep n_fft %d %s" % (n_fft, "cmvn" if cfg.cmvn else "plain"), err, FEAT_TOL)
+            assert err <= FEAT_TOL, (case, u, lens[u], err, cfg)
 
 
 @pytest.mark.parametrize("fs", [16000, 8000])
@@ -1073,7 +1268,8 @@ def test_plp_vs_oracle(ssp, fs, rasta):
         assert got.shape == ref.shape, (u, got.shape, ref.shape)
         if ref.size:
             assert np.isfinite(got).all()
-            assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), (u, np.abs(got - ref).max())
+            observe("plp fs %d rasta %d" % (fs, rasta), np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), FEAT_TOL)  # observed <= 9.5e-7
+            assert np.abs(got - ref).max() <= FEAT_TOL * max(1.0, np.abs(ref).max()), (u, np.abs(got - ref).max())
     one = SF.plp(sigs[0], fs=fs, rasta=rasta)
     assert isinstance(one, list) and len(one) == 4 and one[0].dtype == np.float64
     np.testing.assert_allclose(one[0], feats[:fseg.offsets[1]], atol=1e-6)
@@ -1089,7 +1285,8 @@ def test_plp_other_orders_and_rates(ssp):
         got = SF.plp(x, fs=fs, plp_order=order)[0]
         ref = O.sidekit_plp(x, fs=fs, plp_order=order)[0]
         assert got.shape == ref.shape == ((2 * fs - int(round(0.025 * fs))) // int(0.01 * fs) + 1, order)
-        assert np.abs(got - ref).max() <= 3e-4 * max(1.0, np.abs(ref).max()), (fs, order, np.abs(got - ref).max())
+        observe("plp fs %d order %d" % (fs, order), np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), FEAT_TOL)  # observed <= 5.6e-7
+        assert np.abs(got - ref).max() <= FEAT_TOL * max(1.0, np.abs(ref).max()), (fs, order, np.abs(got - ref).max())
     with pytest.raises(Exception):
         SF.plp(synth_audio(0, 8000, 8000), fs=8000, plp_order=30)   # order beyond the 17 bands
 
@@ -1105,12 +1302,13 @@ def test_extract_feature_plp(ssp):
     for u, s in enumerate(sigs):
         ref = O.extract_feature_plp_one(s)
         assert feature[u].shape == ref.shape and feature[u].shape[1] == 26
-        assert np.abs(feature[u] - ref).max() <= 2e-3, (u, np.abs(feature[u] - ref).max())
+        observe("extract_feature PLP (abs, scaled features)", np.abs(feature[u] - ref).max(), FEAT_TOL)  # observed 1.9e-5 on unit-variance columns
+        assert np.abs(feature[u] - ref).max() <= FEAT_TOL, (u, np.abs(feature[u] - ref).max())
     with pytest.raises(NameError):
         GMM_UBM.extract_feature(sigs, [0] * 5, feature_type='LPC')
     f, lab = d_vector.Data_gen(16000).extract_feature([sigs[4]], [7], feature_type='PLP')
     assert len(f) == 2 and lab == [7, 7] and f[0].shape == (98, 13)
-    np.testing.assert_allclose(f[1], O.sidekit_plp(sigs[4][16000:32000])[0], atol=3e-4)
+    np.testing.assert_allclose(f[1], O.sidekit_plp(sigs[4][16000:32000])[0], atol=1e-4)
 
 
 def test_bit_reproducible_runs(ssp):
@@ -1192,7 +1390,7 @@ def test_delta_cmvn_ragged_batches(ssp):
         for u, T in enumerate(lens):
             if T:
                 ref = O.scale(X[offs[u]:offs[u + 1]].astype(np.float64))
-                assert np.abs(got[offs[u]:offs[u + 1]] - ref).max() <= 2e-4, (dim, u, T)
+                assert observe('cmvn_features (abs, unit-variance columns)', np.abs(got[offs[u]:offs[u + 1]] - ref).max(), 1e-4) <= 1e-4, (dim, u, T)
 
 
 def test_centroids_shapes_and_order(ssp):
@@ -1230,6 +1428,8 @@ def test_gmm_em_stats_shapes(ssp, K, D):
     st = api.gmm_em_stats(api.default_context(), w, mu, cov, X)
     nk, sx, sxx, ll = O.gmm_em_stats(w, mu, cov, X.astype(np.float64))
     assert abs(st["loglik_sum"] - ll) <= 2e-5 * abs(ll)
-    assert np.allclose(st["nk"], nk, rtol=2e-4, atol=2e-4 * nk.max())
-    assert np.allclose(st["sx"], sx, rtol=2e-4, atol=2e-4 * np.abs(sx).max())
-    assert np.allclose(st["sxx"], sxx, rtol=2e-4, atol=2e-4 * np.abs(sxx).max())
+    observe("em stats K %d D %d (rel to max)" % (K, D), max(np.abs(st["nk"] - nk).max() / nk.max(), np.abs(st["sx"] - sx).max() / np.abs(sx).max(),
+                                                          np.abs(st["sxx"] - sxx).max() / np.abs(sxx).max()), 1e-4)
+    assert np.allclose(st["nk"], nk, rtol=1e-4, atol=1e-4 * nk.max())
+    assert np.allclose(st["sx"], sx, rtol=1e-4, atol=1e-4 * np.abs(sx).max())
+    assert np.allclose(st["sxx"], sxx, rtol=1e-4, atol=1e-4 * np.abs(sxx).max())
