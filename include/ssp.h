@@ -156,9 +156,13 @@ int ssp_gmm_destroy(ssp_gmm* gmm);
  * = score_samples per model); scores_out (nullable): float[n_utt x n_models] mean log-likelihood
  * (= GaussianMixture.score); argmax_out (nullable): int32[n_utt] = argmax_i(score_i - score_ubm)
  * over speaker models (index 0 = first speaker model); precision: 0 fp32 MFMA (parity path) |
- * 1 bf16x3 split MFMA (fast path, same tolerance class). */
+ * 1 bf16x3 split MFMA (fast path, same tolerance class) with every utterance whose top-2 margin lies inside the split-precision
+ * error band scored again on the fp32 path, so the arg-max equals precision 0's | 2 bf16x3 split MFMA alone.
+ * Without loglik_out the per-utterance means are formed inside the scoring kernel (the [n_models x frames] matrix never exists). */
 int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_seg, float* loglik_out,
                   float* scores_out, int32_t* argmax_out, int where, int precision, float* kernel_ms);
+/* utterances the last precision = 1 call scored again on the fp32 path (diagnostics) */
+int ssp_gmm_last_rescored(const ssp_gmm* gmm, int32_t* n_out);
 
 /* ---- GMM training (EM): the O(frames x K x D) part of one iteration of sklearn GaussianMixture(covariance_type='diag').fit as
  *      the reference trains its speaker models and UBM (GMM_UBM.py:158-170; sklearn mixture/_base.py:_e_step,

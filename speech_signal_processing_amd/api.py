@@ -364,7 +364,9 @@ class GmmScorer:
               precision: int = 0, timing: bool = False) -> dict:
         """Returns a dict with the requested arrays:
         loglik (M, F) per-frame log-likelihood per model (= score_samples), scores (U, M) mean log-likelihood
-        (= GaussianMixture.score), argmax (U,) int32 over speaker models of score - score_ubm."""
+        (= GaussianMixture.score), argmax (U,) int32 over speaker models of score - score_ubm.
+        precision: 0 exact-fp32 MFMA | 1 bf16x3 split MFMA with the close calls (top-2 margin inside the split-precision error
+        band) scored again in fp32, so the arg-max equals precision 0's (``last_rescored`` = how many) | 2 bf16x3 alone."""
         keep, ptr, where = _as_f32(feats, "feats")
         if keep.ndim != 2 or keep.shape[1] != self.D:
             raise ValueError("feats must be (frames, %d)" % self.D)
@@ -393,6 +395,12 @@ class GmmScorer:
         if timing:
             res["kernel_ms"] = ms.value
         return res
+
+    @property
+    def last_rescored(self) -> int:
+        n = C.c_int32(0)
+        _lib.check(self._lib.ssp_gmm_last_rescored(self._h, C.byref(n)))
+        return n.value
 
     def close(self):
         if getattr(self, "_h", None):

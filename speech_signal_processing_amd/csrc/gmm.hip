@@ -37,9 +37,98 @@ struct GmmArgs {
     const float* feats;   // [F x D]
     const float* wimg;    // [n_tiles][NQ][2][32][4]  packed row tiles (32 mixtures each)
     const char* wimg16;   // bf16x3 path: [n_tiles][NK][hi|lo][2][32][8 bf16] + [2][16] fp32 constants + pad (see pack)
-    float* llT;           // [n_models x F] model-major per-frame log-likelihood
+    float* llT;           // [n_models x F] model-major per-frame log-likelihood (FUSED == false)
     int64_t F;            // total frames (rows of feats)
     int32_t D, n_models, tiles_per_model, n_tiles;
+    // fused per-utterance epilogue (FUSED == true): a wave's 64 frames are cut at utterance boundaries into pieces; the sum of a
+    // model's log-likelihood over a piece goes to partial[piece][model] (fixed in-wave order: bit-reproducible) and a small second
+    // kernel adds an utterance's pieces in order — the [n_models x F] matrix never exists
+    const int64_t* frame_off;   // [n_utt + 1] absolute frame offsets of this batch's utterances (device)
+    const int32_t* piece_base;  // [n_utt + 1] first piece id of every utterance of the batch
+    double* partial;            // [n_pieces x n_models], float64: the order in which an utterance's frames meet (which depends on where
+                                // the utterance sits in the batch) then has no visible effect on the fp32 mean
+    int64_t frame_base;         // absolute index of the batch's first frame
+    int32_t n_utt;
+};
+
+// sum over lanes 0..31 of a value that is zero on lanes 32..63, in float64 and in a fixed order: inclusive DPP row scans, then the two
+// row totals
+template <int CTRL>
+__device__ __forceinline__ double row_shr_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double sum_lower_half(double v) {
+    v += row_shr_f64<0x111>(v);
+    v += row_shr_f64<0x112>(v);
+    v += row_shr_f64<0x114>(v);
+    v += row_shr_f64<0x118>(v);
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    const long long r0 = ((long long)__builtin_amdgcn_readlane(hi, 15) << 32) | (unsigned int)__builtin_amdgcn_readlane(lo, 15);
+    const long long r1 = ((long long)__builtin_amdgcn_readlane(hi, 31) << 32) | (unsigned int)__builtin_amdgcn_readlane(lo, 31);
+    return __builtin_bit_cast(double, r0) + __builtin_bit_cast(double, r1);
+}
+
+// Per-wave bookkeeping of the fused epilogue: which utterances the wave's 64 frames belong to.
+template <int CT>
+struct PieceMap {
+    int utt[CT];    // utterance (batch-relative) of this lane's frame in column tile ct; -1 on the upper lane half / past the batch
+    int u_lo, np;   // first utterance overlapping the wave's span, utterances overlapping it (wave-uniform)
+    int pid0;       // piece id of u_lo's piece in this span
+    __device__ __forceinline__ void init(const GmmArgs& a, int64_t span0 /*batch frame index of the span's first frame*/, int fl, int h) {
+        u_lo = 0;
+        np = 0;
+        pid0 = -1;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) utt[ct] = -1;
+        if (span0 >= a.F) return;
+        const int64_t g0 = a.frame_base + span0;
+        // last utterance that starts at or before g0 and is not empty-before-g0: upper_bound(frame_off, g0) - 1
+        int lo = 0, hi = a.n_utt;  // invariant: frame_off[lo] <= g0 < frame_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.frame_off[mid] <= g0) lo = mid; else hi = mid;
+        }
+        u_lo = lo;
+        const int64_t span_end = min(span0 + 32 * CT, a.F) + a.frame_base;
+        int u_hi = u_lo;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int64_t g = g0 + ct * 32 + fl;
+            int u = u_lo;
+            if (g < span_end) {
+                while (a.frame_off[u + 1] <= g) ++u;
+                if (h == 0) utt[ct] = u;
+                u_hi = max(u_hi, u);
+            }
+        }
+        // (lanes hold increasing utterance ids: the largest sits on the span's last valid frame; a max over the wave finds it)
+        for (int o = 32; o > 0; o >>= 1) u_hi = max(u_hi, __shfl_xor(u_hi, o));
+        u_hi = __builtin_amdgcn_readfirstlane(u_hi);
+        np = u_hi - u_lo + 1;
+        pid0 = a.piece_base[u_lo] + (int)(span0 / (32 * CT) - (a.frame_off[u_lo] - a.frame_base) / (32 * CT));
+    }
+    // piece id of the p-th utterance of the span (p > 0: the utterance starts inside the span, its first piece); -1: no frames
+    __device__ __forceinline__ int pid(const GmmArgs& a, int p) const {
+        if (p == 0) return pid0;
+        const int u = u_lo + p;
+        return a.frame_off[u + 1] > a.frame_off[u] ? a.piece_base[u] : -1;
+    }
+    template <class LL>
+    __device__ __forceinline__ void emit(const GmmArgs& a, int model, const LL& ll, int lane) const {
+        for (int p = 0; p < np; ++p) {
+            const int u = u_lo + p;
+            double v = 0.0;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) v += utt[ct] == u ? (double)ll[ct] : 0.0;
+            const double tot = sum_lower_half(v);
+            const int id = pid(a, p);
+            if (lane == 0 && id >= 0) a.partial[(size_t)id * a.n_models + model] = tot;
+        }
+    }
 };
 
 // Online log-sum-exp over one 32x32 accumulator tile (16 mixtures per lane).  The packed weights carry a factor log2(e),
@@ -105,7 +194,7 @@ __device__ __forceinline__ void stage_frames(float* __restrict__ xs, const float
 }
 
 // NQ = k-depth / 8 of the packed image (k-depth >= 2D+1); CT = 32-frame column tiles per wave
-template <int NQ, int CT>
+template <int NQ, int CT, bool FUSED>
 __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_FLOATS = NQ * 2 * 32 * 4;
@@ -144,6 +233,8 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
             }
     }
 
+    PieceMap<CT> pm;
+    if (FUSED) pm.init(a, f0 + (int64_t)wave * CT * 32, fl, h);
     __syncthreads();  // every wave has its frames in registers: the staging bytes become the tile ring
     stage_tile<NQ>(a.wimg, wbuf, wave, lane);  // row tile 0
     __syncthreads();
@@ -180,14 +271,16 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) lse2_update(acc[ct], run_m[ct], run_s[ct]);
         if (++rt == a.tiles_per_model) {
+            float llv[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const float ll = lse2_finish(run_m[ct], run_s[ct]);
+                llv[ct] = lse2_finish(run_m[ct], run_s[ct]);
                 const int fidx = (wave * CT + ct) * 32 + fl;
-                if (h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = ll;
+                if (!FUSED && h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = llv[ct];
                 run_m[ct] = -INFINITY;
                 run_s[ct] = 0.f;
             }
+            if (FUSED) pm.emit(a, model, llv, lane);
             rt = 0;
             ++model;
         }
@@ -214,7 +307,7 @@ __device__ __forceinline__ void stage_tile16(const char* __restrict__ tile, char
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(tile + 2 * NK * 1024 + lane * 4), (lds_ptr_t)(dst + 2 * NK * 1024), 4, 0, 0);
 }
 
-template <int NK, int CT>
+template <int NK, int CT, bool FUSED>
 __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE_BYTES = 2 * NK * 1024 + 256;
@@ -253,6 +346,8 @@ __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
                 bl[ct][ks][jj] = (__bf16)(v - (float)hi);
             }
     }
+    PieceMap<CT> pm;
+    if (FUSED) pm.init(a, f0 + (int64_t)wave * CT * 32, fl, h);
     __syncthreads();  // every wave has its fragments: the staging area becomes the tile ring
     // stage the (up to GROUP) tiles of group g into ring slot `slot` (offsets are formed from the LDS base directly so
     // the address stays in the LDS address space)
@@ -310,14 +405,16 @@ __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) lse2_update(acc[ct], run_m[ct], run_s[ct]);
             if (++rt == a.tiles_per_model) {
+                float llv[CT];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const float ll = lse2_finish(run_m[ct], run_s[ct]);
+                    llv[ct] = lse2_finish(run_m[ct], run_s[ct]);
                     const int fidx = (wave * CT + ct) * 32 + fl;
-                    if (h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = ll;
+                    if (!FUSED && h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = llv[ct];
                     run_m[ct] = -INFINITY;
                     run_s[ct] = 0.f;
                 }
+                if (FUSED) pm.emit(a, model, llv, lane);
                 rt = 0;
                 ++model;
             }
@@ -372,30 +469,132 @@ __global__ __launch_bounds__(256) void gmm_utt_reduce_kernel(const float* __rest
     }
 }
 
-template <int NQ, int CT>
+// fused path, second kernel: an utterance's score under model m = (sum of its pieces' partial sums, in piece order) / T, then the score
+// differences against the UBM, their arg-max (first index on ties, numpy) and the margin between the best and the second best
+// difference.  One workgroup per utterance; partial is [piece][model], so a piece's row is read coalesced.
+__global__ __launch_bounds__(256) void gmm_piece_reduce_kernel(const double* __restrict__ partial, const int64_t* __restrict__ frame_off,
+                                                               const int32_t* __restrict__ piece_base, int n_models, int has_ubm,
+                                                               float* __restrict__ scores, int32_t* __restrict__ argmax_out,
+                                                               float* __restrict__ margin_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = reinterpret_cast<float*>(smem);
+    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = (int)(frame_off[u + 1] - frame_off[u]);
+    const int p0 = piece_base[u], p1 = piece_base[u + 1];
+    for (int m = tid; m < n_models; m += 256) {
+        double s = 0.0;
+        for (int p = p0; p < p1; ++p) s += partial[(size_t)p * n_models + m];
+        const float v = (float)(s / (double)T);  // T == 0 -> NaN (numpy mean of empty)
+        sc[m] = v;
+        if (scores) scores[(size_t)u * n_models + m] = v;
+    }
+    __syncthreads();
+    if (wave == 0 && (argmax_out || margin_out)) {
+        const float base = has_ubm ? sc[0] : 0.f;
+        float best = -INFINITY, second = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int m = has_ubm + lane; m < n_models; m += 64) {
+            const float v = sc[m] - base;
+            if (v > best || bi == 0x7fffffff) {
+                second = bi == 0x7fffffff ? second : best;
+                best = v;
+                bi = m - has_ubm;
+            } else if (v > second) {
+                second = v;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o), os = __shfl_xor(second, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) {
+                second = bi == 0x7fffffff ? os : fmaxf(best, os);
+                best = ob;
+                bi = oi;
+            } else if (oi != 0x7fffffff) {
+                second = fmaxf(second, ob);
+            }
+        }
+        if (lane == 0) {
+            if (argmax_out) argmax_out[u] = bi == 0x7fffffff ? 0 : bi;
+            if (margin_out) margin_out[u] = best - second;  // +inf with one speaker model, NaN when scores are NaN
+        }
+    }
+}
+
+// ---- bf16x3 close calls: utterances whose top-2 margin is within the split-precision error band are listed IN ORDER (one workgroup,
+// ballot prefix: deterministic) for re-scoring on the exact fp32 path
+__global__ __launch_bounds__(256) void gmm_flag_kernel(const float* __restrict__ margin, const float* __restrict__ scores, int n_models,
+                                                       int n_utt, float rel_thr, int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    __shared__ int s_base, s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int u0 = 0; u0 < n_utt; u0 += 256) {
+        const int u = u0 + tid;
+        bool f = false;
+        if (u < n_utt) {
+            const float mg = margin[u];
+            const float mag = fabsf(scores[(size_t)u * n_models]) + 1.0f;
+            f = !(mg >= rel_thr * mag);  // close call, or not comparable (NaN)
+        }
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (f) list[off + __popcll(b & ((1ull << lane) - 1ull))] = u;
+        __syncthreads();
+        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) *count = s_base;
+}
+
+// rows of the listed utterances into a compact matrix (sub_off: their frame offsets in the compact matrix)
+__global__ __launch_bounds__(256) void gmm_gather_frames_kernel(const float* __restrict__ feats, const int64_t* __restrict__ frame_off,
+                                                                const int32_t* __restrict__ list, const int64_t* __restrict__ sub_off,
+                                                                int D, float* __restrict__ out) {
+    const int i = blockIdx.x, u = list[i];
+    const int64_t a0 = frame_off[u], n = (frame_off[u + 1] - a0) * D;
+    const float* __restrict__ src = feats + a0 * D;
+    float* __restrict__ dst = out + sub_off[i] * D;
+    for (int64_t k = threadIdx.x; k < n; k += 256) dst[k] = src[k];
+}
+
+// results of the re-scored utterances back into the batch's outputs
+__global__ __launch_bounds__(256) void gmm_scatter_kernel(const int32_t* __restrict__ list, int n_models, const float* __restrict__ sub_scores,
+                                                          const int32_t* __restrict__ sub_argmax, float* __restrict__ scores,
+                                                          int32_t* __restrict__ argmax_out) {
+    const int i = blockIdx.x, u = list[i];
+    if (scores)
+        for (int m = threadIdx.x; m < n_models; m += 256) scores[(size_t)u * n_models + m] = sub_scores[(size_t)i * n_models + m];
+    if (argmax_out && threadIdx.x == 0) argmax_out[u] = sub_argmax[i];
+}
+
+template <int NQ, int CT, bool FUSED>
 static int launch_loglik(const GmmArgs& a, hipStream_t s) {
     constexpr int FRAMES_WG = 4 * CT * 32;
     const size_t lds = std::max<size_t>((size_t)2 * NQ * 2 * 32 * 4, (size_t)FRAMES_WG * a.D) * sizeof(float);
     const int64_t grid = ceil_div<int64_t>(a.F, FRAMES_WG);
     if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many frames for one launch");
     if (lds > 64 * 1024)
-        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_loglik_kernel<NQ, CT>),
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_loglik_kernel<NQ, CT, FUSED>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gmm_loglik_kernel<NQ, CT>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gmm_loglik_kernel<NQ, CT, FUSED>), dim3((unsigned)grid), dim3(256), lds, s, a);
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }
 
-template <int NK, int CT>
+template <int NK, int CT, bool FUSED>
 static int launch_loglik16(const GmmArgs& a, hipStream_t s) {
     constexpr int FRAMES_WG = 4 * CT * 32;
     const size_t lds = std::max<size_t>((size_t)2 * 2 * (2 * NK * 1024 + 256), (size_t)FRAMES_WG * a.D * sizeof(float));
     const int64_t grid = ceil_div<int64_t>(a.F, FRAMES_WG);
     if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many frames for one launch");
     if (lds > 64 * 1024)
-        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_loglik_bf16x3_kernel<NK, CT>),
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gmm_loglik_bf16x3_kernel<NK, CT, FUSED>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gmm_loglik_bf16x3_kernel<NK, CT>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gmm_loglik_bf16x3_kernel<NK, CT, FUSED>), dim3((unsigned)grid), dim3(256), lds, s, a);
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }
@@ -419,6 +618,14 @@ struct ssp_gmm {
     ssp::DevBuf wimg16;   // bf16 hi/lo image of the same models (precision = 1)
     int32_t nk16 = 0;     // k-depth / 16 of the bf16 image (0: D too large for the bf16 kernels)
     ssp::DevBuf scratch;  // llT when the caller does not ask for it (grow-only)
+    // fused per-utterance epilogue: piece tables of the last single-batch call (cached per segments handle) + grow-only buffers
+    uint64_t pb_serial = 0;
+    int32_t pb_gran = 0, pb_pieces = 0;
+    std::vector<int32_t> pb_host;
+    ssp::DevBuf pb_dev, partial, margin, flag_list, flag_count, sub_feats, sub_off, sub_scores, sub_argmax, sub_pb, sub_partial;
+    std::vector<int32_t> sub_list_host, sub_pb_host;
+    std::vector<int64_t> sub_off_host;
+    int32_t last_rescored = 0;
 };
 
 using namespace ssp;
@@ -569,112 +776,256 @@ int ssp_gmm_destroy(ssp_gmm* gmm) {
     return SSP_OK;
 }
 
+}  // extern "C"
+
+namespace ssp {
+
+static int launch_kernel_any(ssp_gmm* gmm, const GmmArgs& a, bool bf16, bool fused, hipStream_t s) {
+    if (a.F <= 0) return SSP_OK;
+    if (bf16) {
+#define SSP_G16(NK_)                                                                          \
+    case NK_:                                                                                  \
+        return fused ? launch_loglik16<NK_, 2, true>(a, s) : launch_loglik16<NK_, 2, false>(a, s);
+        switch (gmm->nk16) {
+            SSP_G16(1) SSP_G16(2) SSP_G16(3) SSP_G16(4) SSP_G16(5) SSP_G16(6) SSP_G16(8)
+            default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no bf16 kernel for nk=%d", gmm->nk16);
+        }
+#undef SSP_G16
+    }
+#define SSP_G32(NQ_, CT_)                                                                      \
+    case NQ_:                                                                                  \
+        return fused ? launch_loglik<NQ_, CT_, true>(a, s) : launch_loglik<NQ_, CT_, false>(a, s);
+    switch (gmm->nq) {
+        SSP_G32(4, 2) SSP_G32(7, 2) SSP_G32(10, 2) SSP_G32(16, 2) SSP_G32(24, 1) SSP_G32(32, 1)
+        default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no kernel for nq=%d", gmm->nq);
+    }
+#undef SSP_G32
+}
+
+// frames per piece granule = frames of one wave of the scoring kernel
+static int piece_granule(const ssp_gmm* gmm, bool bf16) { return (bf16 || gmm->nq <= 16) ? 64 : 32; }
+
+// piece table of utterances [u0, u1) (absolute host offsets h_off): pb[i] = first piece of utterance u0 + i, pb[u1 - u0] = pieces
+static void piece_table(const int64_t* h_off, int64_t u0, int64_t u1, int gran, std::vector<int32_t>& pb) {
+    pb.resize((size_t)(u1 - u0) + 1);
+    const int64_t base = h_off[u0];
+    int32_t acc = 0;
+    for (int64_t u = u0; u < u1; ++u) {
+        pb[(size_t)(u - u0)] = acc;
+        const int64_t a = h_off[u] - base, b = h_off[u + 1] - base;
+        if (b > a) acc += (int32_t)((b - 1) / gran - a / gran + 1);
+    }
+    pb[(size_t)(u1 - u0)] = acc;
+}
+
+// Fused scoring of n_utt utterances: d_feats is indexed by ABSOLUTE frame (row h_off[u] is utterance u's first frame), h_off / d_off
+// are the same n_utt + 1 offsets on the host / device.  bf16: the split-precision kernel.  d_margin (nullable): top-2 margins.
+// `sub`: use the second buffer set (the re-scoring pass runs while the first set still holds the batch's tables).
+static int score_fused(ssp_gmm* gmm, const float* d_feats, const int64_t* h_off, const int64_t* d_off, int64_t n_utt, uint64_t seg_serial,
+                       bool bf16, bool sub, float* d_sc, int32_t* d_am, float* d_margin, hipStream_t s) {
+    const int M = gmm->n_models;
+    const int gran = piece_granule(gmm, bf16);
+    const size_t cap = [] {
+        const char* e = getenv("SSP_GMM_SCRATCH_BYTES");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4 << 30;
+    }();
+    DevBuf& pb_dev = sub ? gmm->sub_pb : gmm->pb_dev;
+    DevBuf& partial = sub ? gmm->sub_partial : gmm->partial;
+    std::vector<int32_t>& pb_host = sub ? gmm->sub_pb_host : gmm->pb_host;
+    // batches of whole utterances whose piece sums fit the cap (pieces <= frames / gran + utterances).  All batches' piece tables go to
+    // the device in ONE upload before the first launch (pb_host stays untouched until the next call).
+    const int64_t max_pieces = std::max<int64_t>((int64_t)(cap / ((size_t)M * sizeof(double))), 2);
+    std::vector<int64_t> cuts{0};
+    {
+        int64_t u0 = 0;
+        while (u0 < n_utt) {
+            int64_t u1 = u0 + 1;
+            auto bound = [&](int64_t ue) { return (h_off[ue] - h_off[u0]) / gran + (ue - u0); };
+            if (bound(n_utt) <= max_pieces) {
+                u1 = n_utt;
+            } else {
+                while (u1 < n_utt && bound(u1 + 1) <= max_pieces) ++u1;
+            }
+            cuts.push_back(u1);
+            u0 = u1;
+        }
+    }
+    const bool whole = cuts.size() == 2;
+    const bool cached = !sub && whole && seg_serial != 0 && gmm->pb_serial == seg_serial && gmm->pb_gran == gran;
+    int32_t max_batch_pieces = cached ? gmm->pb_pieces : 1;
+    if (!cached) {
+        pb_host.clear();
+        std::vector<int32_t> one;
+        for (size_t bi = 0; bi + 1 < cuts.size(); ++bi) {
+            piece_table(h_off, cuts[bi], cuts[bi + 1], gran, one);
+            max_batch_pieces = std::max(max_batch_pieces, one.back());
+            pb_host.insert(pb_host.end(), one.begin(), one.end());
+        }
+        SSP_TRY(pb_dev.reserve(pb_host.size() * sizeof(int32_t)));
+        SSP_HIP(hipMemcpyAsync(pb_dev.p, pb_host.data(), pb_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        if (!sub) {
+            gmm->pb_serial = whole ? seg_serial : 0;
+            gmm->pb_gran = gran;
+            gmm->pb_pieces = max_batch_pieces;
+        }
+    }
+    SSP_TRY(partial.reserve((size_t)max_batch_pieces * M * sizeof(double)));
+    size_t pb_pos = 0;
+    for (size_t bi = 0; bi + 1 < cuts.size(); ++bi) {
+        const int64_t u0 = cuts[bi], u1 = cuts[bi + 1];
+        const int32_t* pb_b = pb_dev.as<int32_t>() + pb_pos;
+        pb_pos += (size_t)(u1 - u0) + 1;
+        GmmArgs a{};
+        a.feats = d_feats + (size_t)h_off[u0] * gmm->D;
+        a.wimg = gmm->wimg.as<float>();
+        a.wimg16 = gmm->wimg16.as<char>();
+        a.F = h_off[u1] - h_off[u0];
+        a.D = gmm->D;
+        a.n_models = M;
+        a.tiles_per_model = gmm->tiles_per_model;
+        a.n_tiles = M * gmm->tiles_per_model;
+        a.frame_off = d_off + u0;
+        a.piece_base = pb_b;
+        a.partial = partial.as<double>();
+        a.frame_base = h_off[u0];
+        a.n_utt = (int32_t)(u1 - u0);
+        SSP_TRY(launch_kernel_any(gmm, a, bf16, true, s));
+        hipLaunchKernelGGL(gmm_piece_reduce_kernel, dim3((unsigned)(u1 - u0)), dim3(256), (size_t)M * sizeof(float), s, partial.as<double>(),
+                           d_off + u0, pb_b, M, gmm->has_ubm, d_sc ? d_sc + (size_t)u0 * M : nullptr,
+                           d_am ? d_am + u0 : nullptr, d_margin ? d_margin + u0 : nullptr);
+        SSP_HIP(hipGetLastError());
+    }
+    return SSP_OK;
+}
+
+}  // namespace ssp
+
+extern "C" {
+
 int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_seg, float* loglik_out,
                   float* scores_out, int32_t* argmax_out, int where, int precision, float* kernel_ms) {
     if (!gmm || !frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: null handle");
     ssp_ctx* ctx = gmm->ctx;
     SSP_TRY(use_ctx(ctx));
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: where");
-    if (precision != 0 && precision != 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: precision must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA)");
-    if (precision == 1 && gmm->nk16 == 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_score: bf16x3 path covers D <= 64");
+    if (precision < 0 || precision > 2)
+        SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: precision must be 0 (fp32 MFMA), 1 (bf16x3 MFMA + fp32 re-scoring of close calls) or 2 (bf16x3 MFMA alone)");
+    if (precision != 0 && gmm->nk16 == 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_score: bf16x3 path covers D <= 64");
     if (kernel_ms) *kernel_ms = 0.f;
     const int64_t F = frame_seg->host.back();
     const int64_t n_utt = frame_seg->n;
     if (n_utt == 0) return SSP_OK;
     if (F > 0 && !feats) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: null feats");
+    if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many utterances");
     hipStream_t s = ctx->stream;
     const int M = gmm->n_models;
+    const bool bf16 = precision != 0;
     Staged sin, sll, ssc, sam;
     int rc;
     const float* d_feats = (const float*)sin.in(ctx, feats, (size_t)F * gmm->D * sizeof(float), where, &rc);
     SSP_TRY(rc);
     const size_t ll_bytes = (size_t)M * (size_t)std::max<int64_t>(F, 1) * sizeof(float);
-    // Per-frame log-likelihoods are model-major [M x frames].  When the caller wants them the whole [M x F] matrix is
-    // produced in one pass; otherwise they are scratch, and utterances are processed in batches so that the scratch
-    // stays below a fixed cap (configs[3]: 1252 models x 4.5e7 frames per GPU would otherwise need 224 GB).
-    const size_t scratch_cap = (size_t)4 << 30;
-    const char* cap_env = getenv("SSP_GMM_SCRATCH_BYTES");
-    const size_t cap = cap_env ? (size_t)strtoull(cap_env, nullptr, 10) : scratch_cap;
-    float* d_ll = nullptr;
-    int64_t batch_frames_cap = F;
-    if (loglik_out) {
-        d_ll = (float*)sll.out(loglik_out, ll_bytes, where, &rc);
-        SSP_TRY(rc);
-    } else {
-        batch_frames_cap = std::max<int64_t>((int64_t)(cap / ((size_t)M * sizeof(float))), 1);
-        const int64_t need_frames = std::min<int64_t>(std::max<int64_t>(F, 1), std::max<int64_t>(batch_frames_cap, frame_seg->max_len()));
-        const size_t need = (size_t)M * (size_t)need_frames * sizeof(float);
-        if (gmm->scratch.bytes < need) SSP_TRY(gmm->scratch.alloc(need));
-        d_ll = gmm->scratch.as<float>();
-    }
     float* d_sc = (float*)ssc.out(scores_out, (size_t)n_utt * M * sizeof(float), where, &rc);
     SSP_TRY(rc);
     int32_t* d_am = (int32_t*)sam.out(argmax_out, (size_t)n_utt * sizeof(int32_t), where, &rc);
     SSP_TRY(rc);
-    if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many utterances");
-
     Timer tm;
-    SSP_TRY(tm.start(kernel_ms != nullptr, s));
-    const int64_t f_begin = frame_seg->host.front();
-    int64_t u0 = 0;
-    while (u0 < n_utt) {
-        // batch = utterances [u0, u1): as many as fit the frame cap (at least one)
-        int64_t u1 = u0 + 1;
-        if (loglik_out) {
-            u1 = n_utt;
-        } else {
-            while (u1 < n_utt && frame_seg->host[u1 + 1] - frame_seg->host[u0] <= batch_frames_cap) ++u1;
-        }
-        const int64_t fb0 = loglik_out ? 0 : frame_seg->host[u0];
-        const int64_t fb1 = loglik_out ? F : frame_seg->host[u1];
-        const int64_t Fb = fb1 - fb0;
+    if (loglik_out) {
+        // the caller wants score_samples: the whole [M x F] matrix in one pass, per-utterance means from it
+        float* d_ll = (float*)sll.out(loglik_out, ll_bytes, where, &rc);
+        SSP_TRY(rc);
+        SSP_TRY(tm.start(kernel_ms != nullptr, s));
         GmmArgs a{};
-        a.feats = d_feats + (size_t)fb0 * gmm->D;
+        a.feats = d_feats;
         a.wimg = gmm->wimg.as<float>();
         a.wimg16 = gmm->wimg16.as<char>();
         a.llT = d_ll;
-        a.F = Fb;
+        a.F = F;
         a.D = gmm->D;
         a.n_models = M;
         a.tiles_per_model = gmm->tiles_per_model;
         a.n_tiles = M * gmm->tiles_per_model;
-        if (Fb > 0 && precision == 1) {
-            switch (gmm->nk16) {
-                case 1: SSP_TRY((launch_loglik16<1, 2>(a, s))); break;
-                case 2: SSP_TRY((launch_loglik16<2, 2>(a, s))); break;
-                case 3: SSP_TRY((launch_loglik16<3, 2>(a, s))); break;
-                case 4: SSP_TRY((launch_loglik16<4, 2>(a, s))); break;
-                case 5: SSP_TRY((launch_loglik16<5, 2>(a, s))); break;
-                case 6: SSP_TRY((launch_loglik16<6, 2>(a, s))); break;
-                case 8: SSP_TRY((launch_loglik16<8, 2>(a, s))); break;
-                default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no bf16 kernel for nk=%d", gmm->nk16);
-            }
-        } else if (Fb > 0) {
-            switch (gmm->nq) {
-                case 4: SSP_TRY((launch_loglik<4, 2>(a, s))); break;
-                case 7: SSP_TRY((launch_loglik<7, 2>(a, s))); break;
-                case 10: SSP_TRY((launch_loglik<10, 2>(a, s))); break;
-                case 16: SSP_TRY((launch_loglik<16, 2>(a, s))); break;
-                case 24: SSP_TRY((launch_loglik<24, 1>(a, s))); break;
-                case 32: SSP_TRY((launch_loglik<32, 1>(a, s))); break;
-                default: SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: no kernel for nq=%d", gmm->nq);
-            }
-        }
+        SSP_TRY(launch_kernel_any(gmm, a, bf16, false, s));
         if (scores_out || argmax_out) {
-            // the reduce kernel indexes llT columns by (frame offset - frame_base): batch frames start at column 0
-            hipLaunchKernelGGL(gmm_utt_reduce_kernel, dim3((unsigned)(u1 - u0)), dim3(256), (size_t)M * sizeof(float), s, d_ll, Fb,
-                               frame_seg->dev.as<int64_t>() + u0, fb0, M, gmm->has_ubm, d_sc ? d_sc + (size_t)u0 * M : nullptr,
-                               d_am ? d_am + u0 : nullptr);
+            hipLaunchKernelGGL(gmm_utt_reduce_kernel, dim3((unsigned)n_utt), dim3(256), (size_t)M * sizeof(float), s, d_ll, F,
+                               frame_seg->dev.as<int64_t>(), (int64_t)0, M, gmm->has_ubm, d_sc, d_am);
             SSP_HIP(hipGetLastError());
         }
-        u0 = u1;
+    } else if (scores_out || argmax_out) {
+        // fused path: per-utterance sums leave the scoring kernel as piece partials, [M x F] never reaches HBM
+        const bool rescore = precision == 1 && gmm->has_ubm + 1 < M;  // (one speaker model: nothing to confuse)
+        float* d_margin = nullptr;
+        float* d_sc_work = d_sc;
+        if (rescore) {
+            SSP_TRY(gmm->margin.reserve((size_t)n_utt * sizeof(float)));
+            d_margin = gmm->margin.as<float>();
+            if (!d_sc_work) {  // the close-call test looks at the score's magnitude: scores are needed even when only arg-max is asked for
+                SSP_TRY(gmm->sub_scores.reserve((size_t)n_utt * M * sizeof(float)));
+                d_sc_work = gmm->sub_scores.as<float>();
+            }
+        }
+        SSP_TRY(tm.start(kernel_ms != nullptr, s));
+        SSP_TRY(score_fused(gmm, d_feats, frame_seg->host.data(), frame_seg->dev.as<int64_t>(), n_utt, frame_seg->serial, bf16, false,
+                            d_sc_work, d_am, d_margin, s));
+        if (rescore) {
+            // utterances whose top-2 margin lies within the split-precision error band are scored again on the exact fp32 path, so the
+            // arg-max is the fp32 path's for every utterance.  Band: |score error| of the bf16x3 kernel is <= 1e-5 (|score| + 1)
+            // (measured 7e-6 |score| at configs[2]); the margin threshold leaves a factor 8
+            const float rel_thr = 8.0e-5f;
+            SSP_TRY(gmm->flag_list.reserve((size_t)n_utt * sizeof(int32_t)));
+            SSP_TRY(gmm->flag_count.reserve(sizeof(int32_t)));
+            hipLaunchKernelGGL(gmm_flag_kernel, dim3(1), dim3(256), 0, s, d_margin, d_sc_work, M, (int)n_utt, rel_thr,
+                               gmm->flag_list.as<int32_t>(), gmm->flag_count.as<int32_t>());
+            SSP_HIP(hipGetLastError());
+            int32_t n_flag = 0;
+            SSP_HIP(hipMemcpyAsync(&n_flag, gmm->flag_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            SSP_HIP(hipStreamSynchronize(s));
+            gmm->last_rescored = n_flag;
+            if (n_flag > 0) {
+                gmm->sub_list_host.resize((size_t)n_flag);
+                SSP_HIP(hipMemcpyAsync(gmm->sub_list_host.data(), gmm->flag_list.p, (size_t)n_flag * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                SSP_HIP(hipStreamSynchronize(s));
+                gmm->sub_off_host.resize((size_t)n_flag + 1);
+                gmm->sub_off_host[0] = 0;
+                for (int32_t i = 0; i < n_flag; ++i) {
+                    const int32_t u = gmm->sub_list_host[(size_t)i];
+                    gmm->sub_off_host[(size_t)i + 1] = gmm->sub_off_host[(size_t)i] + (frame_seg->host[(size_t)u + 1] - frame_seg->host[(size_t)u]);
+                }
+                const int64_t Fs = gmm->sub_off_host.back();
+                SSP_TRY(gmm->sub_off.reserve(((size_t)n_flag + 1) * sizeof(int64_t)));
+                SSP_HIP(hipMemcpyAsync(gmm->sub_off.p, gmm->sub_off_host.data(), ((size_t)n_flag + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+                SSP_TRY(gmm->sub_feats.reserve((size_t)std::max<int64_t>(Fs, 1) * gmm->D * sizeof(float)));
+                hipLaunchKernelGGL(gmm_gather_frames_kernel, dim3((unsigned)n_flag), dim3(256), 0, s, d_feats, frame_seg->dev.as<int64_t>(),
+                                   gmm->flag_list.as<int32_t>(), gmm->sub_off.as<int64_t>(), gmm->D, gmm->sub_feats.as<float>());
+                SSP_HIP(hipGetLastError());
+                // (when the caller asked for no scores, sub_scores already holds the work copy: the re-scored rows go to a second area)
+                const size_t work_rows = d_sc ? 0 : (size_t)n_utt;
+                SSP_TRY(gmm->sub_scores.reserve((work_rows + (size_t)n_flag) * M * sizeof(float)));
+                if (!d_sc) d_sc_work = gmm->sub_scores.as<float>();
+                float* sub_sc = gmm->sub_scores.as<float>() + work_rows * M;
+                SSP_TRY(gmm->sub_argmax.reserve((size_t)n_flag * sizeof(int32_t)));
+                SSP_TRY(score_fused(gmm, gmm->sub_feats.as<float>(), gmm->sub_off_host.data(), gmm->sub_off.as<int64_t>(), n_flag, 0, false, true,
+                                    sub_sc, gmm->sub_argmax.as<int32_t>(), nullptr, s));
+                hipLaunchKernelGGL(gmm_scatter_kernel, dim3((unsigned)n_flag), dim3(256), 0, s, gmm->flag_list.as<int32_t>(), M, sub_sc,
+                                   gmm->sub_argmax.as<int32_t>(), d_sc, d_am);
+                SSP_HIP(hipGetLastError());
+            }
+        }
+    } else {
+        SSP_TRY(tm.start(kernel_ms != nullptr, s));
     }
-    (void)f_begin;
     SSP_TRY(tm.stop(s, kernel_ms));
     SSP_TRY(sll.back(ctx, loglik_out, ll_bytes, where));
     SSP_TRY(ssc.back(ctx, scores_out, (size_t)n_utt * M * sizeof(float), where));
     SSP_TRY(sam.back(ctx, argmax_out, (size_t)n_utt * sizeof(int32_t), where));
     if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(s));
+    return SSP_OK;
+}
+
+/* diagnostics: utterances the last precision = 1 call re-scored on the fp32 path */
+int ssp_gmm_last_rescored(const ssp_gmm* gmm, int32_t* n_out) {
+    if (!gmm || !n_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_last_rescored: null");
+    *n_out = gmm->last_rescored;
     return SSP_OK;
 }
 

@@ -563,8 +563,42 @@ def test_gmm_configs3_model_count_vs_oracle(ssp, precision):
     assert (np.asarray(r["argmax"])[safe] == ref_am[safe]).all() and safe.sum() >= 3
 
 
+def test_gmm_bf16x3_close_calls_are_rescored_in_fp32(ssp):
+    """precision = 1 (bf16x3 MFMA) must give the fp32 path's arg-max on every utterance: speakers that differ by less than the
+    split-precision error (two identical models, models 1e-6 apart) make close calls, which are scored again on the fp32 path;
+    precision = 2 (no re-scoring) is allowed to differ there.  Also: scores of re-scored rows are the fp32 path's bit for bit."""
+    pkg, api = ssp
+    rng = np.random.default_rng(41)
+    K, D, S, U = 64, 39, 12, 400
+    w = rng.dirichlet(5 * np.ones(K))
+    mu = rng.standard_normal((K, D))
+    cov = rng.uniform(0.5, 2.0, (K, D))
+    mus = [mu] + [mu + 0.05 * rng.standard_normal((K, D)) for _ in range(S)]
+    mus[5] = mus[4].copy()                                   # an exact tie: numpy's first index wins
+    mus[9] = mus[8] + 1e-6 * rng.standard_normal((K, D))     # a difference far below the bf16x3 error
+    lens = rng.integers(20, 200, U)
+    feats = np.vstack([(mus[1 + u % S][rng.choice(K, size=n, p=w)] + np.sqrt(cov[rng.choice(K, size=n)]) * rng.standard_normal((n, D))).astype(np.float32)
+                       for u, n in enumerate(lens)])
+    ctx = api.default_context()
+    sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), np.stack(mus), np.stack([cov] * (S + 1)), has_ubm=True)
+    seg = api.Segments.from_lengths(ctx, lens)
+    r0 = sc.score(feats, seg, precision=0)
+    r1 = sc.score(feats, seg, precision=1)
+    n_res = sc.last_rescored
+    r2 = sc.score(feats, seg, precision=2)
+    assert np.array_equal(np.asarray(r0["argmax"]), np.asarray(r1["argmax"]))
+    assert 0 < n_res < U
+    changed = (np.asarray(r1["scores"]) != np.asarray(r2["scores"])).any(axis=1)
+    assert changed.sum() <= n_res and np.array_equal(np.asarray(r1["scores"])[changed], np.asarray(r0["scores"])[changed])
+    assert np.abs(np.asarray(r2["scores"]) - np.asarray(r0["scores"])).max() <= 1e-4 * np.abs(np.asarray(r0["scores"])).max()
+    print("bf16x3: %d of %d utterances re-scored; raw bf16x3 arg-max differs on %d" % (n_res, U, (np.asarray(r2["argmax"]) != np.asarray(r0["argmax"])).sum()))
+    only_am = sc.score(feats, seg, scores=False, precision=1)   # arg-max alone: the work copy of the scores is internal
+    assert np.array_equal(np.asarray(only_am["argmax"]), np.asarray(r0["argmax"]))
+
+
 def test_gmm_bounded_scratch_batches(ssp, monkeypatch):
-    """the per-frame log-likelihood scratch is capped: scoring in many small utterance batches gives bit-identical results"""
+    """the piece-sum scratch is capped: scoring in many small utterance batches gives bit-identical results (the sums are float64, so
+    where an utterance's frames are cut into pieces has no visible effect on its fp32 mean)"""
     pkg, api = ssp
     rng = np.random.default_rng(8)
     K, D, M = 16, 13, 6
@@ -575,7 +609,7 @@ def test_gmm_bounded_scratch_batches(ssp, monkeypatch):
     feats = rng.standard_normal((int(lens.sum()), D)).astype(np.float32)
     seg = api.Segments.from_lengths(ctx, lens)
     ref = sc.score(feats, seg)
-    monkeypatch.setenv("SSP_GMM_SCRATCH_BYTES", str(M * 4 * 300))  # ~300 frames per batch
+    monkeypatch.setenv("SSP_GMM_SCRATCH_BYTES", str(M * 8 * 12))  # room for 12 piece sums per batch: a few utterances each
     got = sc.score(feats, seg)
     ok = lens > 0
     assert np.array_equal(np.asarray(ref["scores"])[ok], np.asarray(got["scores"])[ok])

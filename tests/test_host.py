@@ -166,3 +166,31 @@ def test_plp_front_tables_match_oracle():
         np.testing.assert_allclose(t.fbank, fb, rtol=1e-6, atol=1e-30)
         np.testing.assert_allclose(t.window, w, atol=1e-7)
         assert np.array_equal(t.dct, np.eye(t.cfg.n_filt, dtype=np.float32))
+
+
+def test_wav_read_matches_scipy(tmp_path):
+    """utils/tools.py:45-58 — read() returns what scipy.io.wavfile.read (the reference's call) returns; save_wave_file round-trips."""
+    from scipy.io import wavfile
+    from speech_signal_processing_amd.utils import tools
+    rng = np.random.default_rng(0)
+    cases = {"i16": (rng.integers(-30000, 30000, 4001)).astype(np.int16), "f32": rng.standard_normal(777).astype(np.float32),
+             "u8": rng.integers(0, 255, 100).astype(np.uint8), "i32": rng.integers(-2 ** 30, 2 ** 30, 55).astype(np.int32),
+             "stereo": rng.integers(-3000, 3000, (321, 2)).astype(np.int16)}
+    for name, x in cases.items():
+        path = str(tmp_path / (name + ".wav"))
+        wavfile.write(path, 16000 if name != "u8" else 8000, x)
+        fs0, a0 = wavfile.read(path)
+        fs1, a1 = tools.read(path)
+        assert fs0 == fs1 and a0.dtype == a1.dtype and a0.shape == a1.shape and np.array_equal(a0, a1), name
+    path = str(tmp_path / "saved.wav")
+    tools.save_wave_file(path, [cases["i16"][:2000].tobytes(), cases["i16"][2000:].tobytes()], framerate=16000)
+    fs, a = tools.read(path)
+    assert fs == 16000 and np.array_equal(a, cases["i16"])
+    w = tools.wave_read(path)
+    assert w.getnframes() == 4001 and w.getframerate() == 16000
+    w.close()
+    t0 = tools.get_time()
+    assert tools.get_time(t0) >= 0.0
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.wav").write_bytes(b"not a wav file at all")
+        tools.read(str(tmp_path / "bad.wav"))
