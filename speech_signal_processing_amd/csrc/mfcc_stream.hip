@@ -51,8 +51,11 @@ __device__ __forceinline__ float delta_weight(float t, float tp, float Tm1, floa
 
 // NZ / POWER / PRE / MELV as in mfcc_fused512_kernel; KS = 4-filter k-steps of the DCT product (n_filt <= 4 KS); NS = DPP scan
 // steps of the piece filterbank (a filter's pieces span <= 2^NS lanes)
+#ifndef SSP_STREAM_OCC
+#define SSP_STREAM_OCC 3  // waves per SIMD the register budget is cut for (experiment: 2 = 256 VGPRs, every twiddle resident)
+#endif
 template <int NZ, int POWER, int PRE, int MELV, int KS, int NS>
-__global__ __launch_bounds__(64 * STREAM_WAVES, 3) void mfcc_stream512_kernel(MfccArgs a, FastArgs f, StreamArgs sa) {
+__global__ __launch_bounds__(64 * STREAM_WAVES, SSP_STREAM_OCC) void mfcc_stream512_kernel(MfccArgs a, FastArgs f, StreamArgs sa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,14 +75,21 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, 3) void mfcc_stream512_kernel(Mf
     // tables anywhere else): twiddles W_256^(k1 j) are resident for k1 <= 8 and W^(k1 j) = W^((k1 - 8) j) W^(8 j) above; split twiddles
     // W_512^(j + 16 i) for i < 4 and times W_8 above; that pays for the DCT matrix as resident MFMA A operand
     // (lane (ceps = j, kq = g), k-step s <-> filter KS g + s)
-    v2f twr[8], wpr[4];
+#ifndef SSP_STREAM_NTW
+#define SSP_STREAM_NTW 10  // resident twiddles W_256^(k1 j), k1 <= NTW (the largest sets that leave no spill inside the loop; a spill
+#endif                     // reload there waits on vmcnt behind the sample DMA and exposes its whole latency every quad)
+#ifndef SSP_STREAM_NWP
+#define SSP_STREAM_NWP 8   // resident split twiddles
+#endif
+    constexpr int NTW = SSP_STREAM_NTW, NWP = SSP_STREAM_NWP;
+    v2f twr[NTW], wpr[NWP];
 #pragma unroll
-    for (int k1 = 1; k1 <= 8; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
+    for (int k1 = 1; k1 <= NTW; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
     float dA[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) dA[s] = sa.dctA[s * 64 + lane];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);
+    for (int i = 0; i < NWP; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);
     v4f mw[MELV];
     int mofs[MELV];
 #pragma unroll
@@ -164,10 +174,12 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, 3) void mfcc_stream512_kernel(Mf
                 v2f pf[NZ];
                 v2f pm[PRE ? NZ : 1];
                 // the quad's DMA has landed; the stores of a preceding step were issued behind it and may still be in flight
+#ifndef SSP_S_NOWAIT  // (ablation, wrong results: what the wait for the sample DMA costs)
                 if (stores_pending == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (stores_pending == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else if (stores_pending == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+#endif
                 stores_pending = 0;
                 // the stage comes to registers in two halves (the first is windowed into z while the second is in flight: all of it
                 // at once is the register peak of the kernel)
@@ -215,8 +227,11 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, 3) void mfcc_stream512_kernel(Mf
                 fft16(z);
 #pragma unroll
                 for (int k1 = 1; k1 < 16; ++k1) {
-                    z[k1] = cmul(z[k1], twr[(k1 - 1) & 7]);
-                    if (k1 > 8) z[k1] = cmul(z[k1], twr[7]);
+                    if (k1 <= NTW) {
+                        z[k1] = cmul(z[k1], twr[(k1 - 1) % NTW]);
+                    } else {  // W^(k1 j) = W^((k1 - 8) j) W^(8 j)
+                        z[k1] = cmul(cmul(z[k1], twr[(k1 - 9) % NTW]), twr[7]);
+                    }
                 }
                 // ---- transpose through LDS (rows of 128 B, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
                 char* zf = zbuf + g * ZFRAME;
@@ -256,8 +271,8 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, 3) void mfcc_stream512_kernel(Mf
                         my = __builtin_amdgcn_update_dpp(oy, my, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
                         const v2f zmk = v2f{mx, my};
                         const v2f zk = z[k2];
-                        v2f w = wpr[k2 & 3];
-                        if (k2 >= 4) w = cmulc(w, 0.70710678118654752f, -0.70710678118654752f);  // W_512^64 = W_8
+                        v2f w = wpr[k2 < NWP ? k2 : k2 - 4];
+                        if (k2 >= NWP) w = cmulc(w, 0.70710678118654752f, -0.70710678118654752f);  // W_512^64 = W_8
                         const v2f e = __builtin_elementwise_fma(zmk, v2f{1.f, -1.f}, zk);
                         const v2f d = __builtin_elementwise_fma(zmk, v2f{-1.f, 1.f}, zk);
                         const v2f o = cmul_negi(d, w);
@@ -509,7 +524,8 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
     sa.n_chunks = n_chunks;
     SSP_TRY(p->f_counter.reserve(64));
     sa.work_counter = p->f_counter.as<int32_t>();
-    const size_t lds = (size_t)sa.table_bytes + (size_t)STREAM_WAVES * sa.wave_bytes;
+    size_t lds = (size_t)sa.table_bytes + (size_t)STREAM_WAVES * sa.wave_bytes;
+    if (const char* e = getenv("SSP_MFCC_LDS_PAD")) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(e));  // diagnostic: caps the workgroups per CU
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): LDS footprint %zu B exceeds 160 KiB", lds);
     if ((int64_t)p->fast_max_samples * 4 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): utterance too long for 32-bit offsets");
     const int nz = c.win_len <= 416 ? 13 : 16, pw = c.spec_power, pr = c.preemph_mode ? 1 : 0;
