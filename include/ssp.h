@@ -44,6 +44,7 @@ typedef struct ssp_ctx ssp_ctx;
 typedef struct ssp_segments ssp_segments;
 typedef struct ssp_mfcc_plan ssp_mfcc_plan;
 typedef struct ssp_gmm ssp_gmm;
+typedef struct ssp_dnn ssp_dnn;           /* a fully connected network packed for the MFMA forward pass */
 
 /* MFCC dialect knobs.  Three presets are built by the host side:
  *   in-repo  utils/processing.py:19-144  (Hamming, |X|/L, 40 talkbox filters folded, log10(.+1e-8), c0..c12)
@@ -194,6 +195,15 @@ int ssp_dtw_path(ssp_ctx* ctx, const float* x, int64_t r, const float* y, int64_
  * relu != 0 applies max(0, .); Y: float[N x units].  All four arrays live on the side `where` names. */
 int ssp_dense_forward(ssp_ctx* ctx, const float* X, int64_t N, int32_t d_in, const float* Wt, const float* bias,
                       int32_t units, int32_t relu, float* Y, int where, float* kernel_ms);
+
+/* The whole network as one object: n_layers Dense layers, layer l = (Wt[l]: HOST float[dims[l+1] x dims[l]] = Keras kernel transposed,
+ * bias[l]: HOST float[dims[l+1]] or NULL, relu[l]).  ssp_dnn_forward = spkModel.predict: X float[N x dims[0]] -> Y float[N x dims[n_layers]].
+ * Layers whose input and output widths are <= 256 (the reference's three hidden-to-hidden / output layers) run inside one kernel with
+ * the activations kept in registers between layers; wider layers in front of them (the 1274-input layer) run one GEMM launch each. */
+int ssp_dnn_create(ssp_ctx* ctx, int32_t n_layers, const int32_t* dims, const float* const* Wt, const float* const* bias,
+                   const int32_t* relu, ssp_dnn** out);
+int ssp_dnn_destroy(ssp_dnn* dnn);
+int ssp_dnn_forward(ssp_dnn* dnn, const float* X, int64_t N, float* Y, int where, float* kernel_ms);
 
 /* ---- d-vector cosine scoring: replaces the scipy cosine double loop + argmin
  *      (d_vector.py:315-319, 346-361) ---- */

@@ -63,6 +63,9 @@ SIGNATURES = {
     "ssp_gmm_last_rescored": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "ssp_gmm_em_stats": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _F32P, C.c_int64, _P, _P, _P, _P, C.c_int, _MSP]),
     "ssp_dense_forward": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, _F32P, C.c_int32, C.c_int32, _F32P, C.c_int, _MSP]),
+    "ssp_dnn_create": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(_P)]),
+    "ssp_dnn_destroy": (C.c_int, [_P]),
+    "ssp_dnn_forward": (C.c_int, [_P, _F32P, C.c_int64, _F32P, C.c_int, _MSP]),
     "ssp_dtw_distances": (C.c_int, [_P, _F32P, _P, _F32P, _P, C.c_int32, C.c_int32, _F32P, C.c_int, _MSP]),
     "ssp_dtw_path": (C.c_int, [_P, _F32P, C.c_int64, _F32P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "ssp_centroids": (C.c_int, [_P, _F32P, _P, C.c_int64, C.c_int32, C.c_int32, _F32P, C.c_int, _MSP]),

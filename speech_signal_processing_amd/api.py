@@ -501,6 +501,57 @@ def dense_forward(ctx: Context, X, Wt, bias=None, relu: bool = False, timing: bo
     return (Y, ms.value) if timing else Y
 
 
+class DnnForward:
+    """A fully connected network packed once for the GPU forward pass (ssp_dnn): ``layers`` = list of (Wt (units, d_in) float32 — the
+    Keras kernel transposed —, bias (units,) or None, relu bool).  ``forward(X)`` = predict: the layers whose widths are <= 256 run in
+    one kernel with the activations kept in registers (the d-vector network's hidden and output layers), wider layers in front of
+    them one GEMM launch each."""
+
+    def __init__(self, ctx: Context, layers):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        n = len(layers)
+        if n < 1:
+            raise ValueError("at least one layer")
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w, _, _ in layers]
+        bs = [None if b is None else np.ascontiguousarray(b, dtype=np.float32).reshape(-1) for _, b, _ in layers]
+        dims = [int(ws[0].shape[1])] + [int(w.shape[0]) for w in ws]
+        for i, w in enumerate(ws):
+            if w.ndim != 2 or w.shape[1] != dims[i] or (bs[i] is not None and bs[i].shape[0] != dims[i + 1]):
+                raise ValueError("layer %d: kernel (units, d_in) / bias (units,) do not chain" % i)
+        self.dims = dims
+        c_dims = (C.c_int32 * (n + 1))(*dims)
+        c_w = (C.c_void_p * n)(*[w.ctypes.data for w in ws])
+        c_b = (C.c_void_p * n)(*[None if b is None else b.ctypes.data for b in bs])
+        c_r = (C.c_int32 * n)(*[1 if r else 0 for _, _, r in layers])
+        h = C.c_void_p()
+        _lib.check(self._lib.ssp_dnn_create(ctx._h, n, c_dims, c_w, c_b, c_r, C.byref(h)))
+        self._h = h
+
+    def forward(self, X, timing: bool = False):
+        xk, xp, where = _as_f32(X, "X")
+        if xk.ndim != 2 or int(xk.shape[1]) != self.dims[0]:
+            raise ValueError("X must be (N, %d)" % self.dims[0])
+        N = int(xk.shape[0])
+        Y = self.ctx._empty((N, self.dims[-1]), where)
+        yp = Y.data_ptr() if where == _lib.DEVICE else Y.ctypes.data
+        ms = C.c_float(0.0)
+        with self.ctx._ordered(where):
+            _lib.check(self._lib.ssp_dnn_forward(self._h, xp, N, yp, where, C.byref(ms) if timing else None))
+        return (Y, ms.value) if timing else Y
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ssp_dnn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True, minval: bool = True,
                     timing: bool = False) -> dict:
     """dist[i,j] = clip(1 - cos(X[i], C[j]), 0, 2); argmin over j (first index on ties) — d_vector.py:315-319."""

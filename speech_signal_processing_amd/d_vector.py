@@ -49,6 +49,9 @@ class DenseNet:
             self.layers.append((Wt, bt, act == 'relu'))
         self.input_dim = int(self.layers[0][0].shape[1])
         self.output_dim = int(d_prev)
+        # the whole network as one packed object: hidden / output layers chained in registers (ssp_dnn)
+        self._net = api.DnnForward(self._ctx, [(np.ascontiguousarray(np.asarray(W, dtype=np.float32).T),
+                                                None if b is None else np.asarray(b, dtype=np.float32), act == 'relu') for W, b, act in layers])
 
     def predict(self, X, batch_size=None):
         """X (N, input_dim) numpy or torch CUDA tensor -> (N, output_dim) of the same kind (numpy in: float32 out)."""
@@ -57,8 +60,7 @@ class DenseNet:
         h = X if is_t else torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).cuda(self.layers[0][0].device)
         if h.ndim != 2 or h.shape[1] != self.input_dim:
             raise ValueError("X must be (N, %d)" % self.input_dim)
-        for Wt, bt, relu in self.layers:
-            h = api.dense_forward(self._ctx, h, Wt, bt, relu=relu)
+        h = self._net.forward(h)
         return h if is_t else h.cpu().numpy()
 
 

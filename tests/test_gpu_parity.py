@@ -1037,6 +1037,31 @@ def test_dense_forward_vs_oracle(ssp, N, d_in, units, relu):
     assert np.abs(nob - X.astype(np.float64) @ W.astype(np.float64)).max() <= 1e-4 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("dims,N", [([1274, 256, 256, 256, 256], 333), ([40, 32, 16], 70), ([300, 256, 200, 7], 129),
+                                    ([13, 5], 1), ([600, 300, 256, 256], 64), ([256, 256], 65)])
+def test_packed_network_forward_vs_oracle(ssp, dims, N):
+    """ssp_dnn (api.DnnForward): the layers whose widths are <= 256 run chained in registers (odd widths are zero padded inside the packed
+    image), wider ones in front as GEMM launches; against the float64 numpy forward of the same Dense / ReLU stack, with and without
+    biases, ReLU on every layer but the last (d_vector.py:171-189)."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(sum(dims) + N)
+    X = rng.standard_normal((N, dims[0])).astype(np.float32)
+    layers = []
+    for i in range(len(dims) - 1):
+        W = (rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i])).astype(np.float32)      # Keras layout (d_in, units)
+        b = None if i == 1 else (0.2 * rng.standard_normal(dims[i + 1])).astype(np.float32)
+        layers.append((W, b, 'relu' if i + 2 < len(dims) else 'linear'))
+    ref = O.dense_net_forward(X, layers)
+    net = api.DnnForward(api.default_context(), [(np.ascontiguousarray(W.T), b, act == 'relu') for W, b, act in layers])
+    got = np.asarray(net.forward(X))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+    import torch
+    got_dev = net.forward(torch.from_numpy(X).cuda()).cpu().numpy()
+    assert np.array_equal(got_dev, got)
+
+
 def test_dvector_network_predict_and_test(ssp):
     """DenseNet.predict = the reference's spkModel.predict (Dense(256)+ReLU x 3, Dense(256)) and nn_model.test on its output"""
     import torch
