@@ -183,6 +183,11 @@ int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double* weights, 
 int ssp_dtw_distances(ssp_ctx* ctx, const float* xq, const ssp_segments* q_seg, const float* xt, const ssp_segments* t_seg,
                       int32_t dim, int32_t normalize, float* dist_out, int where, float* kernel_ms);
 
+/* The dtw_method = 2 branch of the same matcher (MFCC_DTW.py:69-70: fastdtw(x, y, dist=euclidean), radius 1): the FastDTW approximation
+ * for every (query, template) pair of 1-D sequences, float64 like the package.  Host arrays in, dist_out: HOST double[n_q x n_t]. */
+int ssp_fastdtw_distances(ssp_ctx* ctx, const float* xq, const ssp_segments* q_seg, const float* xt, const ssp_segments* t_seg,
+                          int32_t radius, double* dist_out, float* kernel_ms);
+
 /* One pair WITH the warping path — what generate_template (MFCC_DTW.py:187-217) takes from accelerated_dtw: d and
  * path = _traceback(D0) (first minimum of diagonal / up / left at every step), computed in float64 like the package.
  * x: HOST float[r x dim], y: HOST float[c x dim]; path_i_out / path_j_out: HOST int32[r + c] (path_len_out entries are written). */

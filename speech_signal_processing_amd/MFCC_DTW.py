@@ -32,10 +32,13 @@ def _MFCC(raw_signal):
 
 
 def distance_dtw(sample_x, sample_y, show=False, dtw_method=1, dist=None, normalize=False):
-    """MFCC_DTW.py:57-76 — d of dtw.accelerated_dtw(sample_x, sample_y, dist='euclidean') (dtw_method=1; fastdtw's
-    approximation, dtw_method=2, is not reproduced).  ``normalize=True`` divides by len(x) + len(y) (dtw <= 1.3.3)."""
+    """MFCC_DTW.py:57-76 — dtw_method=1: d of dtw.accelerated_dtw(sample_x, sample_y, dist='euclidean') (``normalize=True`` divides by
+    len(x) + len(y), dtw <= 1.3.3); dtw_method=2: d of fastdtw.fastdtw(sample_x, sample_y, dist=euclidean) (radius 1; the reference's
+    flattened 1-D sequences)."""
+    if dtw_method == 2:
+        return float(api.fastdtw_distances(api.default_context(), [sample_x], [sample_y])[0, 0])
     if dtw_method != 1:
-        raise NotImplementedError("only dtw_method=1 (accelerated_dtw) is implemented")
+        raise ValueError("dtw_method must be 1 (accelerated_dtw) or 2 (fastdtw)")
     return float(api.dtw_distances(api.default_context(), [sample_x], [sample_y], normalize=normalize)[0, 0])
 
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ssp_dnn_destroy": (C.c_int, [_P]),
     "ssp_dnn_forward": (C.c_int, [_P, _F32P, C.c_int64, _F32P, C.c_int, _MSP]),
     "ssp_dtw_distances": (C.c_int, [_P, _F32P, _P, _F32P, _P, C.c_int32, C.c_int32, _F32P, C.c_int, _MSP]),
+    "ssp_fastdtw_distances": (C.c_int, [_P, _F32P, _P, _F32P, _P, C.c_int32, C.c_void_p, _MSP]),
     "ssp_dtw_path": (C.c_int, [_P, _F32P, C.c_int64, _F32P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "ssp_centroids": (C.c_int, [_P, _F32P, _P, C.c_int64, C.c_int32, C.c_int32, _F32P, C.c_int, _MSP]),
     "ssp_cosine_identify": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, C.c_int32, _F32P, _P, _F32P, C.c_int, _MSP]),

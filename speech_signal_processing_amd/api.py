@@ -458,6 +458,22 @@ def dtw_distances(ctx: Context, queries, templates, normalize: bool = False, tim
     return (out, ms.value) if timing else out
 
 
+def fastdtw_distances(ctx: Context, queries, templates, radius: int = 1, timing: bool = False):
+    """All-pairs FastDTW distances (ssp_fastdtw_distances): the reference's dtw_method = 2 (MFCC_DTW.py:69-70) on 1-D sequences,
+    float64.  Returns the (n_q, n_t) float64 matrix."""
+    def pack(seqs):
+        arrs = [np.ascontiguousarray(np.asarray(s, dtype=np.float32).reshape(-1)) for s in seqs]
+        flat = np.concatenate(arrs) if arrs else np.zeros(0, np.float32)
+        return flat, Segments.from_lengths(ctx, [a.shape[0] for a in arrs])
+    fq, sq = pack(queries)
+    ft, st = pack(templates)
+    out = np.empty((sq.n, st.n), dtype=np.float64)
+    ms = C.c_float(0.0)
+    _lib.check(ctx._lib.ssp_fastdtw_distances(ctx._h, fq.ctypes.data, sq._h, ft.ctypes.data, st._h, int(radius), out.ctypes.data,
+                                               C.byref(ms) if timing else None))
+    return (out, ms.value) if timing else out
+
+
 def dtw_path(ctx: Context, x, y):
     """d and the warping path of dtw.accelerated_dtw(x, y, 'euclidean') (ssp_dtw_path, float64 on the GPU).
     x (r,) or (r, dim), y (c,) or (c, dim).  Returns (d, path_i int64[len], path_j int64[len])."""

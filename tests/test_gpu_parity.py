@@ -983,6 +983,35 @@ def test_dtw_vs_oracle_flattened_mfcc(ssp):
     assert MFCC_DTW.distance_test(test[0], train).shape == (1, 3)
 
 
+def test_fastdtw_vs_package_algorithm(ssp):
+    """dtw_method = 2 (MFCC_DTW.py:69-70): the GPU FastDTW (interval windows, one thread per pair) against the restatement of the
+    package's own set-based algorithm, bit for bit in float64: every length class (below radius + 2, odd / even at every level),
+    constant sequences (ties everywhere: the first-minimum rule decides the path), flattened-MFCC-sized pairs."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd import MFCC_DTW
+    rng = np.random.default_rng(21)
+    lens_q = [1, 2, 3, 4, 5, 7, 16, 33, 100, 257]
+    lens_t = [1, 2, 3, 6, 9, 31, 64, 130]
+    Q = [rng.standard_normal(n).astype(np.float32) for n in lens_q] + [np.zeros(12, np.float32), np.ones(9, np.float32)]
+    T = [rng.standard_normal(n).astype(np.float32) for n in lens_t] + [np.zeros(7, np.float32), np.arange(20, dtype=np.float32)]
+    got = api.fastdtw_distances(api.default_context(), Q, T)
+    for i, x in enumerate(Q):
+        for j, y in enumerate(T):
+            assert got[i, j] == O.fastdtw_distance(x, y), (len(x), len(y), got[i, j], O.fastdtw_distance(x, y))
+    a, b = rng.standard_normal(1222).astype(np.float32), rng.standard_normal(1183).astype(np.float32)
+    d = MFCC_DTW.distance_dtw(a, b, dtw_method=2)
+    assert d == O.fastdtw_distance(a, b)
+    assert d >= MFCC_DTW.distance_dtw(a, b, dtw_method=1) * (1 - 1e-5)   # an approximation from above of the exact DTW
+    for r in (2, 3):
+        got_r = api.fastdtw_distances(api.default_context(), Q[4:9], T[3:7], radius=r)
+        for i, x in enumerate(Q[4:9]):
+            for j, y in enumerate(T[3:7]):
+                assert got_r[i, j] == O.fastdtw_distance(x, y, radius=r), (r, len(x), len(y))
+    with pytest.raises(ValueError):
+        MFCC_DTW.distance_dtw(a, b, dtw_method=3)
+
+
 def test_dtw_path_and_generate_template(ssp):
     """the warping path (float64 wavefront + traceback on the GPU) equals the package's traceback step for step, and
     generate_template (MFCC_DTW.py:187-217) reproduces the oracle's template"""

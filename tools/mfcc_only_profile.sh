@@ -10,7 +10,7 @@ cp $(find gpurun_out/final_mfcc/prof -name "*kernel_stats.csv" | head -1) gpurun
 find gpurun_out/final_mfcc/prof -type f -delete
 python3 - <<'PY'
 import csv, json
-rows = [r for r in csv.DictReader(open('gpurun_out/final_mfcc/kernel_trace.csv')) if 'mfcc_fused512' in r['Kernel_Name']]
+rows = [r for r in csv.DictReader(open('gpurun_out/final_mfcc/kernel_trace.csv')) if 'mfcc_stream512' in r['Kernel_Name'] or 'mfcc_fused512' in r['Kernel_Name']]
 d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
 j = json.load(open('gpurun_out/final_mfcc/bench_line.json'))
 print("launches %d; all: %s" % (len(d), " ".join("%.3f" % x for x in d)))
