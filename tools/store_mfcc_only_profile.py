@@ -17,7 +17,7 @@ The headline kernel alone: 1 set-up + 3 warm-up + 10 timed launches of `%s`.
 | ms (rocprofv3 kernel trace) | %s |
 
 * `--stats` row: calls %s, average %.3f ms (includes the set-up and warm-up launches), min %.3f, max %.3f (`%s_final_mfcc_only_kernel_stats.csv`).
-* mean of the 10 timed launches (rocprofv3): **%.3f ms**; mean hipEvent duration measured inside `bench.py` in the same run
+* mean of the 10 timed launches (rocprofv3): **%.3f ms**; median hipEvent duration measured inside `bench.py` in the same run
   (`roofline.kernel_ms` of `%s_final_mfcc_only_bench_line.json`): **%.3f ms** -> `roofline.achieved` %.0f GB/s, `frac` %.4f.
 * boxes of the pool differ by a few percent for one binary.
 """ % (ROUND, st['Name'], " | ".join(str(i + 1) for i in range(len(d))), "---|" * len(d), " | ".join("%.3f" % x for x in d),
