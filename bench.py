@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused workgroup kernel | 3 fused wave-stream kernel")
+    ap.add_argument("--inrepo-variant", type=int, default=0, help="kernel variant of the in-repo MFCC stage (as --variant)")
     ap.add_argument("--stages", default="mfcc,inrepo,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
     ap.add_argument("--gmm4-utts", type=int, default=12000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU; SURVEY.md 8(d) asks for >= 12000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -317,13 +318,13 @@ def main():
             iseg = api.Segments.from_lengths(ctx, np.full(i_utt, i_samp, dtype=np.int64))
             ifseg = iplan.frame_segments(iseg)
             ifeat = torch.empty((ifseg.total, iplan.d_out), dtype=torch.float32, device=device)
-            iplan.run(flat[: i_utt * i_samp], iseg, ifseg, out=ifeat)
+            iplan.run(flat[: i_utt * i_samp], iseg, ifseg, out=ifeat, variant=args.inrepo_variant)
             ims = []
             barrier()
             torch.cuda.synchronize()
             t0i = time.perf_counter()
             for _ in range(max(2, min(args.steps, 5))):
-                _, ms = iplan.run(flat[: i_utt * i_samp], iseg, ifseg, out=ifeat, timing=True)
+                _, ms = iplan.run(flat[: i_utt * i_samp], iseg, ifseg, out=ifeat, timing=True, variant=args.inrepo_variant)
                 ims.append(ms)
             torch.cuda.synchronize()
             barrier()
@@ -336,7 +337,8 @@ def main():
                 "value": ifseg.total * world * len(ims) / i_elapsed, "unit": "frames/s", "sample_rate": ifs, "frame": "512/256",
                 "utterances_per_gpu": i_utt, "frames_per_gpu": int(ifseg.total), "dtype": "f32",
                 "roofline": {"bound": "hbm", "achieved": i_bytes / (i_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": i_bytes / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "mfcc_fused512_kernel",
+                             "frac": i_bytes / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": "mfcc_stream512_kernel" if args.inrepo_variant in (0, 3) else "mfcc_fused512_kernel",
                              "kernel_ms": i_ms, "algorithmic_bytes_per_launch": i_bytes, "bytes_per_frame": 256 * 4 + 13 * 4}}
             del iplan, ifeat
 

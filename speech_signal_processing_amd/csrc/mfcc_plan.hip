@@ -94,8 +94,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     if (variant == 3) {
         // wave-stream kernel: a chunk is a run of frames one WAVE walks alone (no LDS bound); whole utterances up to 512 frames, longer ones
         // in 512-frame chunks with a recomputed 4-frame halo.  CMVN needs the whole utterance: always the stand-alone kernel afterwards.
-        for (int64_t u = 0; u < sseg->n; ++u)
-            if (sseg->host[u] & 3) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): utterance %lld does not start on a 16-byte boundary", (long long)u);
+        // (utterances may start at any sample: the 16-byte LDS-DMA loads of the sample stage only need dword-aligned addresses)
         ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
         split_cmvn = c.cmvn != 0;
         whole = false;
@@ -409,15 +408,14 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     }
     if (v == 2 && !(mfcc_fast_supported(plan->cfg) && plan->fast_ready))
         SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the fused fast kernel does not cover this cfg");
-    // (16-byte sample DMA: the batch's base address and every utterance start must sit on 16-byte boundaries)
-    const bool stream_ok = plan->stream_ready && mfcc_stream_supported(plan) && (where == SSP_HOST || (reinterpret_cast<uintptr_t>(samples) & 15) == 0);
+    const bool stream_ok = plan->stream_ready && mfcc_stream_supported(plan);
     if (v == 3 && !stream_ok) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the wave-stream kernel does not cover this cfg");
     if (variant == 0 && v == 2 && stream_ok) v = 3;
     // the work table is cached per (segment pair, REQUESTED variant): an auto request that fell back to another kernel is remembered
     // as such instead of being rebuilt (chunk table upload + stream sync) on every call
     if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_request != variant) {
         int brc = build_work(plan, sample_seg, frame_seg, v);
-        if (brc == SSP_ERR_UNSUPPORTED && variant == 0 && v == 3) {  // auto: unaligned utterance starts go to the workgroup kernel
+        if (brc == SSP_ERR_UNSUPPORTED && variant == 0 && v == 3) {  // auto: a batch the stream kernel cannot lay out goes to the workgroup kernel
             v = 2;
             brc = build_work(plan, sample_seg, frame_seg, v);
         }

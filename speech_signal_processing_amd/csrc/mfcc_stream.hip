@@ -1,4 +1,4 @@
-// mfcc_stream512_kernel — the throughput kernel of the fused MFCC pass for n_fft == 512 dialects with 13 cepstra, <= 48 filters and
+// mfcc_stream512_kernel — the throughput kernel of the fused MFCC pass for n_fft == 512 dialects with 13 cepstra, <= 40 filters and
 // N = 2 regression deltas (the reference's sidekit call sites GMM_UBM.py:89 / d_vector.py:91 and its own utils/processing.py:110-144).
 //
 // Every WAVE is an independent stream: it claims a chunk (a run of consecutive frames of one utterance) from a global counter and
@@ -51,11 +51,10 @@ __device__ __forceinline__ float delta_weight(float t, float tp, float Tm1, floa
 
 // NZ / POWER / PRE / MELV as in mfcc_fused512_kernel; KS = 4-filter k-steps of the DCT product (n_filt <= 4 KS); NS = DPP scan
 // steps of the piece filterbank (a filter's pieces span <= 2^NS lanes)
-#ifndef SSP_STREAM_OCC
-#define SSP_STREAM_OCC 3  // waves per SIMD the register budget is cut for (experiment: 2 = 256 VGPRs, every twiddle resident)
-#endif
-template <int NZ, int POWER, int PRE, int MELV, int KS, int NS>
-__global__ __launch_bounds__(64 * STREAM_WAVES, SSP_STREAM_OCC) void mfcc_stream512_kernel(MfccArgs a, FastArgs f, StreamArgs sa) {
+// OCC = waves per SIMD the register budget is cut for: 3 (168 VGPRs, 52 KiB of LDS per workgroup) for the hop-160 dialects; 2 (256
+// VGPRs, every twiddle resident) where the sample stage of a longer hop or a wider DCT operand does not fit three workgroups per CU
+template <int NZ, int POWER, int PRE, int MELV, int KS, int NS, int OCC>
+__global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(MfccArgs a, FastArgs f, StreamArgs sa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, SSP_STREAM_OCC) void mfcc_stream
 #ifndef SSP_STREAM_NWP
 #define SSP_STREAM_NWP 8   // resident split twiddles
 #endif
-    constexpr int NTW = SSP_STREAM_NTW, NWP = SSP_STREAM_NWP;
+    constexpr int NTW = OCC >= 3 ? SSP_STREAM_NTW : 15, NWP = OCC >= 3 ? SSP_STREAM_NWP : 8;
     v2f twr[NTW], wpr[NWP];
 #pragma unroll
     for (int k1 = 1; k1 <= NTW; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
@@ -479,14 +478,11 @@ bool mfcc_stream_supported(const ssp_mfcc_plan* p) {
     if (!(mfcc_fast_supported(c) && p->fast_ready)) return false;
     if (getenv("SSP_MFCC_NO_STREAM")) return false;
     const int ks = (c.n_filt + 3) / 4;
-    return f.melv >= 2 && f.melv <= 5 && c.n_ceps == 13 && ks <= 6 && (c.hop & 3) == 0 && (c.delta_order == 0 || c.delta_N == 2);
+    return f.melv >= 2 && f.melv <= (ks <= 6 ? 4 : 5) && c.n_ceps == 13 && ks <= 10 && (c.delta_order == 0 || c.delta_N == 2);
 }
 
-static int stream_ks(const ssp_mfcc_cfg& c) {
-    const int ks = (c.n_filt + 3) / 4;
-    (void)ks;
-    return 6;  // (wider filterbanks need a DCT table that no longer fits three workgroups per CU: they stay on the workgroup kernel)
-}
+// k-steps of the DCT product the instances are built for: 6 (<= 24 filters: the sidekit dialects) or 10 (<= 40: the in-repo MFCC)
+static int stream_ks(const ssp_mfcc_cfg& c) { return (c.n_filt + 3) / 4 <= 6 ? 6 : 10; }
 
 int build_stream_tables(ssp_mfcc_plan* p) {
     const ssp_mfcc_cfg& c = p->cfg;
@@ -529,31 +525,46 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): LDS footprint %zu B exceeds 160 KiB", lds);
     if ((int64_t)p->fast_max_samples * 4 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): utterance too long for 32-bit offsets");
     const int nz = c.win_len <= 416 ? 13 : 16, pw = c.spec_power, pr = c.preemph_mode ? 1 : 0;
+    // three workgroups per CU (52 KiB each, 168 VGPRs) when the stage and the operands allow it, two otherwise
+    // (measured on the in-repo dialect, 59 KiB per workgroup: 2 x 4 waves per CU with every twiddle resident 8.2 ms; 168-VGPR instances
+    //  in 1- / 2- / 3-wave workgroups, 11 / 10 / 9 waves per CU, 9.1 - 9.4 ms)
+    const int occ = (nz == 13 && KS == 6 && lds <= 53248) ? 3 : 2;
+    const int wg_waves = STREAM_WAVES;
     bool launched = false;
-#define SSP_STREAM_CASE(NZ_, PW_, PR_, MV_, KS_)                                                                      \
-    if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && f.melv == MV_ && KS == KS_) {                               \
-        auto* kfn = f.mel_ns <= 2 ? mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 2> : mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 4>;                                                     \
+#define SSP_STREAM_CASE(NZ_, PW_, PR_, MV_, KS_, OCC_)                                                                \
+    if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && f.melv == MV_ && KS == KS_ && occ == OCC_) {                \
+        auto* kfn = f.mel_ns <= 2 ? mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 2, OCC_>                             \
+                                  : mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 4, OCC_>;                            \
         if (lds > 64 * 1024)                                                                                            \
             SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         int per_cu = 0;                                                                                                 \
-        SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * STREAM_WAVES, lds));                    \
-        const int grid = std::min((n_chunks + STREAM_WAVES - 1) / STREAM_WAVES, std::max(1, per_cu) * p->ctx->num_cu);    \
+        SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * wg_waves, lds));                        \
+        const int grid = std::min((n_chunks + wg_waves - 1) / wg_waves, std::max(1, per_cu) * p->ctx->num_cu);          \
         SSP_HIP(hipMemsetAsync(sa.work_counter, 0, 64, stream));                                                        \
         if (getenv("SSP_DEBUG")) fprintf(stderr, "[ssp] mfcc stream: grid %d (%d per CU), lds %zu\n", grid, per_cu, lds); \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * STREAM_WAVES), lds, stream, args, f, sa);                         \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * wg_waves), lds, stream, args, f, sa);                             \
         launched = true;                                                                                                \
     }
 #ifdef SSP_FAST_MINIMAL
-    SSP_STREAM_CASE(13, 2, 1, 3, 6)
+    SSP_STREAM_CASE(13, 2, 1, 3, 6, 3)
+    SSP_STREAM_CASE(16, 1, 0, 3, 10, 2)
+    SSP_STREAM_CASE(16, 1, 0, 5, 10, 2)
 #else
-#define SSP_STREAM_MV(NZ_, PW_, PR_)                                                                                    \
-    SSP_STREAM_CASE(NZ_, PW_, PR_, 2, 6) SSP_STREAM_CASE(NZ_, PW_, PR_, 3, 6) SSP_STREAM_CASE(NZ_, PW_, PR_, 4, 6)
-    SSP_STREAM_MV(13, 2, 1)
-    SSP_STREAM_MV(13, 2, 0)
-    SSP_STREAM_MV(13, 1, 0)
-    SSP_STREAM_MV(16, 2, 1)
-    SSP_STREAM_MV(16, 2, 0)
-    SSP_STREAM_MV(16, 1, 0)
+#define SSP_STREAM_MV(NZ_, PW_, PR_, KS_, OCC_)                                                                         \
+    SSP_STREAM_CASE(NZ_, PW_, PR_, 2, KS_, OCC_) SSP_STREAM_CASE(NZ_, PW_, PR_, 3, KS_, OCC_) SSP_STREAM_CASE(NZ_, PW_, PR_, 4, KS_, OCC_)
+    SSP_STREAM_MV(13, 2, 1, 6, 3)
+    SSP_STREAM_MV(13, 2, 0, 6, 3)
+    SSP_STREAM_MV(13, 1, 0, 6, 3)
+    SSP_STREAM_MV(16, 2, 1, 6, 2)
+    SSP_STREAM_MV(16, 2, 0, 6, 2)
+    SSP_STREAM_MV(16, 1, 0, 6, 2)
+    SSP_STREAM_MV(16, 2, 1, 10, 2)
+    SSP_STREAM_MV(16, 2, 0, 10, 2)
+    SSP_STREAM_MV(16, 1, 0, 10, 2)
+    SSP_STREAM_MV(13, 2, 1, 10, 2)
+    // the folded 40-filter bank of the in-repo MFCC at 8 kHz needs five 16-byte reads per lane
+    SSP_STREAM_CASE(16, 2, 1, 5, 10, 2) SSP_STREAM_CASE(16, 2, 0, 5, 10, 2) SSP_STREAM_CASE(16, 1, 0, 5, 10, 2)
+    SSP_STREAM_CASE(13, 2, 1, 5, 10, 2)
 #undef SSP_STREAM_MV
 #endif
 #undef SSP_STREAM_CASE

@@ -132,8 +132,7 @@ def test_sidekit_preset_vs_oracle(ssp, delta_order, cmvn, variant):
         assert_feat_close(got[u], ref, what=f"utt {u} order {delta_order} cmvn {cmvn}")
 
 
-# variant 3 = wave-stream kernel (DCT / delta / delta-delta on the matrix cores): 16-byte sample DMA, so every utterance must start
-# on a 16-byte boundary (lengths in multiples of 4 samples); batches that do not go to the workgroup kernel in auto mode
+# variant 3 = wave-stream kernel (DCT / delta / delta-delta on the matrix cores)
 STREAM_LENS = [48000, 16000, 400, 560, 720, 1040, 1044, 3000, 4800, 8000, 100004, 20000, 404, 880, 2960, 5200, 399 + 1, 82320, 163840 + 400]
 
 
@@ -167,20 +166,34 @@ def test_stream_kernel_matches_workgroup_kernel_and_auto(ssp):
         assert np.array_equal(a3, a0)  # auto = the stream kernel on aligned batches
         if a3.size:
             assert np.abs(a3 - a2).max() <= 1e-4 * max(1.0, np.abs(a2).max())
-    # utterances that do not start on 16-byte boundaries: the stream kernel refuses, auto falls back to the workgroup kernel
-    odd = [synth_audio(u, 16000 + 37 * u, 16000) for u in range(5)]
-    with pytest.raises(Exception):
-        _run_plan(api, tables, odd, variant=3)
+    # utterances that start at any sample (the 16-byte sample DMA only needs dword-aligned addresses), and a batch whose base address
+    # is off the 16-byte grid: the same kernel, the same values as each utterance alone
+    odd = [synth_audio(u, 16000 + 37 * u, 16000) for u in range(9)] + [synth_audio(40, 48001, 16000), synth_audio(41, 401, 16000)]
+    f3, _ = _run_plan(api, tables, odd, variant=3)
     f0, _ = _run_plan(api, tables, odd, variant=0)
     f2, _ = _run_plan(api, tables, odd, variant=2)
-    for a0, a2 in zip(f0, f2):
-        assert np.array_equal(a0, a2)
+    for u, (a3, a0, a2) in enumerate(zip(f3, f0, f2)):
+        assert np.array_equal(a3, a0)
+        assert np.abs(a3 - a2).max() <= 1e-4 * max(1.0, np.abs(a2).max())
+        alone, _ = _run_plan(api, tables, [odd[u]], variant=3)
+        assert np.array_equal(alone[0], a3), u
+    import torch
+    ctx = api.default_context(torch_stream=True)
+    plan = api.MfccPlan(ctx, tables)
+    flat = np.concatenate(odd).astype(np.float32)
+    seg = api.Segments.from_lengths(ctx, [len(s) for s in odd])
+    fseg = plan.frame_segments(seg)
+    for mis in (1, 2, 3):
+        buf = torch.zeros(len(flat) + 8, device="cuda")
+        buf[mis:mis + len(flat)] = torch.from_numpy(flat).cuda()
+        out = plan.run(buf[mis:mis + len(flat)], seg, fseg, variant=3).cpu().numpy()
+        assert np.array_equal(out, np.concatenate(f3)), mis
 
 
-@pytest.mark.parametrize("nwin,shift", [(0.032, 0.016), (0.025, 0.005), (0.02, 0.01)])
+@pytest.mark.parametrize("nwin,shift", [(0.032, 0.016), (0.025, 0.005), (0.02, 0.01), (0.025, 0.005625)])
 def test_stream_kernel_other_geometries(ssp, nwin, shift):
     """Other framings on the stream kernel: a full 512-sample window with hop 256 (five DMA pieces per quad), hop 80 (three whole
-    pieces), a 320-sample window; and a dialect it does not cover (in-repo: 40 filters) answering UNSUPPORTED for an explicit request."""
+    pieces), a 320-sample window, hop 90 (not a multiple of 4 samples); and a dialect it does not cover (20 cepstra) answering UNSUPPORTED for an explicit request."""
     pkg, api = ssp
     from oracle import ref_cpu as O
     sigs = [synth_audio(u, n, 16000) for u, n in enumerate([16000, 48000, 512, 1024, 4444 * 4, 100000])]
@@ -190,7 +203,7 @@ def test_stream_kernel_other_geometries(ssp, nwin, shift):
     for u, s in enumerate(sigs):
         assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"stream {nwin}/{shift} utt {u}")
     with pytest.raises(Exception):
-        _run_plan(api, pkg.preset_inrepo(16000, 512, 256), [synth_audio(0, 16000, 16000)], variant=3)
+        _run_plan(api, pkg.preset_sidekit(nceps=20), [synth_audio(0, 16000, 16000)], variant=3)
 
 
 def test_sidekit_shape_fact(ssp):
@@ -297,6 +310,27 @@ def test_inrepo_dialect_both_kernels_vs_oracle(ssp, variant, geom):
     cfg["delta_order"] = 2
     for u, s in enumerate(sigs):
         assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"inrepo {geom} utt {u} variant {variant}")
+
+
+@pytest.mark.parametrize("geom", [(8000, 512, 256), (16000, 512, 256), (16000, 512, 100)])
+@pytest.mark.parametrize("order", [0, 2])
+def test_inrepo_dialect_on_the_stream_kernel(ssp, geom, order):
+    """The reference's own MFCC (utils/processing.py:110-144: 40 filters -> ten k-steps of the DCT product, 512-sample window, hop 256:
+    five DMA pieces per quad) on the wave-stream kernel, ragged batch, against the oracle; and
+    identical to what the library picks on its own (variant 0)."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    fs, L, st = geom
+    sigs = [synth_audio(u, 3000 + 777 * u, fs) for u in range(9)] + [synth_audio(20, 100, fs), np.zeros(700, np.float32),
+                                                                           synth_audio(21, 512, fs), synth_audio(22, 120000, fs)]
+    tables = pkg.preset_inrepo(fs, L, st, delta_order=order)
+    got, _ = _run_plan(api, tables, sigs, variant=3)
+    auto, _ = _run_plan(api, tables, sigs, variant=0)
+    cfg, w, fb, dct = O.inrepo_tables(fs, L, st)
+    cfg["delta_order"] = order
+    for u, s in enumerate(sigs):
+        assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"inrepo {geom} utt {u} stream kernel")
+        assert np.array_equal(got[u], auto[u])
 
 
 @pytest.mark.parametrize("geom", [(16000, 400, 160), (8000, 401, 200), (16000, 480, 160), (8000, 100, 37)])
