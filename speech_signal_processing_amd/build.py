@@ -21,6 +21,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-fno-gpu-rdc", "-munsafe-fp-atomics", "-Wno-pass-failed"] + os.environ.get("SSP_EXTRA_FLAGS", "").split()
 
 
+# per-source flags.  gmm.hip: MFMA accumulators in ordinary VGPRs (the log-sum-exp epilogue reads all of them: from AGPRs that is one
+# v_accvgpr_read per element) and no SLP re-packing of the epilogue's scalar adds into v_pk_add_f32 (slow beside MFMAs)
+SOURCE_FLAGS = {"gmm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
+
+
 def _deps():
     out = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
     out.append(os.path.join(os.path.dirname(HERE), "include", "ssp.h"))
@@ -40,7 +45,7 @@ def _compile(src: str) -> str:
     newest = max(os.path.getmtime(p) for p in _deps() if p.endswith((".hpp", ".h")) or p == srcp)
     if os.path.exists(obj) and os.path.getmtime(obj) > newest:
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", srcp, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *SOURCE_FLAGS.get(src, []), "-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

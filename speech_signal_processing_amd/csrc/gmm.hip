@@ -134,20 +134,39 @@ struct PieceMap {
 // Online log-sum-exp over one 32x32 accumulator tile (16 mixtures per lane).  The packed weights carry a factor log2(e),
 // so the accumulator is log2 p: exponentials are bare v_exp_f32, the result is converted back with one multiply by ln 2.
 __device__ __forceinline__ void lse2_update(const f32x16& acc, float& run_m, float& run_s) {
+#ifdef SSP_GMM_ABL_NOLSE  // ablation (wrong results): the MFMAs alone
+    {
+        run_s += acc[0] + acc[15];
+        run_m = 0.f;
+        return;
+    }
+#endif
+#ifdef SSP_GMM_ABL_NOMAX  // ablation (wrong results): what the running maximum and the subtraction cost
+    {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            s0 += __builtin_amdgcn_exp2f(acc[i]);
+            s1 += __builtin_amdgcn_exp2f(acc[i + 1]);
+        }
+        run_s += s0 + s1;
+        run_m = 0.f;
+        return;
+    }
+#endif
     float tm = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
     for (int i = 3; i < 15; i += 2) tm = fmaxf(fmaxf(tm, acc[i]), acc[i + 1]);
     tm = fmaxf(tm, acc[15]);
     const float nm = fmaxf(run_m, tm);
-    typedef float v2f_ __attribute__((ext_vector_type(2)));
-    const v2f_ nm2 = v2f_{nm, nm};
-    v2f_ sacc = v2f_{0.f, 0.f};
+    // (scalar subtract / add: beside MFMAs a packed v_pk_add_f32 costs the SIMD's vector issue more than the two instructions it
+    //  replaces — 42.8 -> 40.4 ms on configs[2]; the file is built with -fno-slp-vectorize so the compiler does not re-pack them)
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; i += 2) {  // packed subtract / add on register pairs, transcendental per element
-        const v2f_ dlt = v2f_{acc[i], acc[i + 1]} - nm2;
-        sacc += v2f_{__builtin_amdgcn_exp2f(dlt.x), __builtin_amdgcn_exp2f(dlt.y)};
+    for (int i = 0; i < 16; i += 2) {
+        s0 += __builtin_amdgcn_exp2f(acc[i] - nm);
+        s1 += __builtin_amdgcn_exp2f(acc[i + 1] - nm);
     }
-    const float s0 = sacc.x, s1 = sacc.y;
     run_s = run_s * __builtin_amdgcn_exp2f(run_m - nm) + (s0 + s1);
     run_m = nm;
 }
@@ -397,9 +416,13 @@ __global__ __launch_bounds__(256) void gmm_loglik_bf16x3_kernel(GmmArgs a) {
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(wcur + (((ks * 2 + 1) * 2 + h) * 32 + fl) * 16);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
+#ifdef SSP_GMM_ABL_NOMFMA  // ablation (wrong results): the epilogue alone
+                    acc[ct][ks] += (float)al[0] * (float)bh[ct][ks][0] + (float)ah[1] * (float)bl[ct][ks][1];
+#else
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ct][ks], acc[ct], 0, 0, 0);
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ct][ks], acc[ct], 0, 0, 0);
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ct][ks], acc[ct], 0, 0, 0);
+#endif
                 }
             }
 #pragma unroll

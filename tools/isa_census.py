@@ -7,7 +7,7 @@ lines = open(path).read().split("\n")
 # find kernel body
 start = 0
 for i, l in enumerate(lines):
-    if l.endswith(":") and sub in l and not l.startswith(".L") and "_Z" in l:
+    if re.match(r"^_Z\S+:", l) and sub in l.split(":")[0]:
         start = i
         break
 blocks = collections.OrderedDict()
