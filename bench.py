@@ -184,8 +184,9 @@ def main():
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused workgroup kernel | 3 fused wave-stream kernel")
+    ap.add_argument("--ref26-variant", type=int, default=0, help="kernel variant of the 26-d + CMVN stage (as --variant)")
     ap.add_argument("--inrepo-variant", type=int, default=0, help="kernel variant of the in-repo MFCC stage (as --variant)")
-    ap.add_argument("--stages", default="mfcc,inrepo,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
+    ap.add_argument("--stages", default="mfcc,ref26,inrepo,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
     ap.add_argument("--gmm4-utts", type=int, default=12000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU; SURVEY.md 8(d) asks for >= 12000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
@@ -305,6 +306,27 @@ def main():
                      "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame},
         "roofline_valu": valu,
     }
+
+    # ------------------------------------------------------------------ what GMM_UBM.extract_feature actually returns (GMM_UBM.py:89-93): [c, delta] 26-d,
+    # scaled per utterance (sklearn.preprocessing.scale); the same resident audio
+    if "ref26" in stages:
+        rplan = api.MfccPlan(ctx, pkg.preset_sidekit(fs=fs, delta_order=1, cmvn=1))
+        rfeat = torch.empty((n_frames, rplan.d_out), dtype=torch.float32, device=device)
+        rplan.run(flat, seg, fseg, out=rfeat, variant=args.ref26_variant)
+        rms = []
+        for _ in range(max(2, min(args.steps, 5))):
+            _, ms = rplan.run(flat, seg, fseg, out=rfeat, timing=True, variant=args.ref26_variant)
+            rms.append(ms)
+        r_ms = float(np.median(rms))
+        r_bytes = n_utt * n_samp * 4 + n_frames * rplan.d_out * 4
+        result["mfcc_ref26_cmvn"] = {
+            "metric": "MFCC frames/s, the reference's extract_feature output: 13 cepstra + delta, per-utterance mean / variance scaling (26-d)",
+            "value": n_frames / (r_ms * 1e-3), "unit": "frames/s", "d_out": rplan.d_out, "dtype": "f32",
+            "roofline": {"bound": "hbm", "achieved": r_bytes / (r_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mfcc_stream512_kernel + cmvn_kernel (the scaling pass re-reads and re-writes the features)",
+                         "kernel_ms": r_ms, "algorithmic_bytes_per_launch": r_bytes, "bytes_per_frame": tables.cfg.hop * 4 + rplan.d_out * 4}}
+        del rplan, rfeat
 
     # ------------------------------------------------------------------ the reference-pinned dialect: in-repo MFCC (utils/processing.py:19-144)
     if "inrepo" in stages:

@@ -139,7 +139,8 @@ int build_fast_tables(ssp_mfcc_plan* plan);
 size_t mfcc_fast_lds(const ssp_mfcc_cfg& cfg, FastArgs& f, int chunk_frames);
 int mfcc_fast_max_chunk(const ssp_mfcc_cfg& cfg, const FastArgs& f);  // most frames one workgroup can take at once
 int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, int chunk_frames, hipStream_t stream);
-bool mfcc_stream_supported(const ssp_mfcc_plan* plan);  // cfg covered by the wave-stream kernel (alignment of a batch is checked per run)
+bool mfcc_stream_supported(const ssp_mfcc_plan* plan);  // cfg covered by the wave-stream kernel
+bool mfcc_stream_fuses_cmvn(const ssp_mfcc_plan* plan); // ... by an instance that scales the features itself (cmvn) when every utterance is one chunk
 int build_stream_tables(ssp_mfcc_plan* plan);
 int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, hipStream_t stream);
 }  // namespace ssp

@@ -93,10 +93,11 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     p->cache_variant = p->cache_request = -1;
     if (variant == 3) {
         // wave-stream kernel: a chunk is a run of frames one WAVE walks alone (no LDS bound); whole utterances up to 512 frames, longer ones
-        // in 512-frame chunks with a recomputed 4-frame halo.  CMVN needs the whole utterance: always the stand-alone kernel afterwards.
+        // in 512-frame chunks with a recomputed 4-frame halo.  CMVN needs the whole utterance: inside the kernel when every utterance is a
+        // single chunk (and the dialect has a scaling instance), the stand-alone kernel afterwards otherwise.
         // (utterances may start at any sample: the 16-byte LDS-DMA loads of the sample stage only need dword-aligned addresses)
         ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
-        split_cmvn = c.cmvn != 0;
+        split_cmvn = c.cmvn != 0 && !(max_T <= 512 && mfcc_stream_fuses_cmvn(p));
         whole = false;
     } else if (variant == 2) {
         // persistent workgroups with a fixed LDS footprint; a chunk's cepstra (+ delta halo) and a block of output rows

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "mfcc.hpp"
 #include "cplx.hpp"
@@ -26,6 +27,7 @@
 namespace ssp {
 
 namespace {
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 constexpr int ZROW = 128;          // bytes per 16-complex row of a frame's transpose image (chunks XOR-swizzled, see mfcc_fast.hip)
 constexpr int ZFRAME = 16 * ZROW;  // 2048 B per frame
 constexpr int LM_OFF = 1792;       // log-mel row of frame g sits at LM_OFF - 64 g inside its image (behind the P row)
@@ -53,7 +55,9 @@ __device__ __forceinline__ float delta_weight(float t, float tp, float Tm1, floa
 // steps of the piece filterbank (a filter's pieces span <= 2^NS lanes)
 // OCC = waves per SIMD the register budget is cut for: 3 (168 VGPRs, 52 KiB of LDS per workgroup) for the hop-160 dialects; 2 (256
 // VGPRs, every twiddle resident) where the sample stage of a longer hop or a wider DCT operand does not fit three workgroups per CU
-template <int NZ, int POWER, int PRE, int MELV, int KS, int NS, int OCC>
+// CM: per-utterance mean / variance scaling (sklearn.preprocessing.scale, GMM_UBM.py:93) inside the kernel, for batches whose utterances
+// are all single chunks: the wave sums x and x^2 of every column it stores (float64), then re-reads its own rows and rewrites them
+template <int NZ, int POWER, int PRE, int MELV, int KS, int NS, int OCC, int CM>
 __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(MfccArgs a, FastArgs f, StreamArgs sa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         }
         prefetch(0);
         int stores_pending = 0;  // buffer stores issued behind the DMA that is waited for at the top of the next iteration
+        double cs1[CM ? 3 : 1] = {}, cs2[CM ? 3 : 1] = {};  // CM: sums of this lane's stored values per block (column = lane & 15)
 
         for (int q = 0; q < Q; ++q) {
             if (q < nquads) {
@@ -417,6 +422,11 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
 #else
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off, 0, 0);
 #endif
+                    if (CM) {
+                        const double dv = off != 0x7ffffff0 ? (double)v : 0.0;
+                        cs1[CM ? blk : 0] += dv;
+                        cs2[CM ? blk : 0] = __builtin_fma(dv, dv, cs2[CM ? blk : 0]);
+                    }
                 };
                 // cepstra of the output rows straight from the ring
                 {
@@ -461,6 +471,69 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetch (zeros) and every store have completed
+        if (CM) {
+            // ---- scaling pass: column statistics over the four lane groups, then the utterance's rows once more through L2
+            int ol = lane;
+            asm volatile("" : "+v"(ol));
+            const int g = ol >> 4, j = ol & 15;
+            float* ct = reinterpret_cast<float*>(ring);  // [0, 48): means, [48, 96): 1 / std  (the ring is idle until the next chunk zeroes it)
+#pragma unroll
+            for (int blk = 0; blk < 3; ++blk) {
+                if (blk > dord) break;
+                double a1 = cs1[CM ? blk : 0], a2 = cs2[CM ? blk : 0];
+                a1 += __shfl_xor(a1, 16);
+                a2 += __shfl_xor(a2, 16);
+                a1 += __shfl_xor(a1, 32);
+                a2 += __shfl_xor(a2, 32);
+                const double mean = a1 / (double)T;
+                const double var = a2 / (double)T - mean * mean;
+                double sd = __builtin_sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));  // a negative rounding residue is zero; NaN stays NaN
+                if (sd < 10.0 * 1.1920929e-07) sd = 1.0;                                 // sk: _handle_zeros_in_scale (as cmvn_kernel)
+                if (g == 0 && j < nc) {
+                    ct[blk * nc + j] = (float)mean;
+                    ct[48 + blk * nc + j] = (float)(1.0 / sd);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the table is written (LDS operations of a wave execute in order)
+            // the utterance's rows once more: 16 loads in flight per lane (through L2: glc), 8 bytes per lane when rows are 8-byte
+            // aligned (an even number of columns)
+            const int tot = T * Dd;
+            auto rewrite = [&](auto wtag) {
+                constexpr int W = decltype(wtag)::value, B = 16;
+                const int n_el = tot / W;
+                const int step = (64 * W) % Dd;
+                int c = (ol * W) % Dd;
+                for (int i0 = 0; i0 < n_el; i0 += 64 * B) {
+                    v2f v[B];
+#pragma unroll
+                    for (int k = 0; k < B; ++k) {
+                        const int idx = i0 + 64 * k + ol;
+                        const int off = idx < n_el ? idx * (4 * W) : 0x7ffffff0;
+                        if (W == 2) v[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ro, off, 0, 1));
+                        else v[k] = v2f{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, off, 0, 1)), 0.f};
+                    }
+#pragma unroll
+                    for (int k = 0; k < B; ++k) {
+                        const int idx = i0 + 64 * k + ol;
+                        const int off = idx < n_el ? idx * (4 * W) : 0x7ffffff0;
+                        const int c1 = c + 1 == Dd ? 0 : c + 1;
+                        const float m0 = ct[c], is0 = ct[48 + c];
+                        if (W == 2) {
+                            const float m1 = ct[c1], is1 = ct[48 + c1];
+                            const v2f o = v2f{(v[k].x - m0) * is0, (v[k].y - m1) * is1};
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ro, off, 0, 0);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (v[k].x - m0) * is0), ro, off, 0, 0);
+                        }
+                        c += step;
+                        c = c >= Dd ? c - Dd : c;
+                    }
+                }
+            };
+            if ((Dd & 1) == 0) rewrite(std::integral_constant<int, 2>{});
+            else rewrite(std::integral_constant<int, 1>{});
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the next chunk zeroes the ring)
+        }
     }
 #ifdef SSP_S_CLOCK
     if (tid == 0) {
@@ -479,6 +552,12 @@ bool mfcc_stream_supported(const ssp_mfcc_plan* p) {
     if (getenv("SSP_MFCC_NO_STREAM")) return false;
     const int ks = (c.n_filt + 3) / 4;
     return f.melv >= 2 && f.melv <= (ks <= 6 ? 4 : 5) && c.n_ceps == 13 && ks <= 10 && (c.delta_order == 0 || c.delta_N == 2);
+}
+
+// the instances that scale the features themselves (cmvn): the sidekit call-site family
+bool mfcc_stream_fuses_cmvn(const ssp_mfcc_plan* p) {
+    const ssp_mfcc_cfg& c = p->cfg;
+    return mfcc_stream_supported(p) && c.win_len <= 416 && c.spec_power == 2 && c.preemph_mode != 0 && (c.n_filt + 3) / 4 <= 6;
 }
 
 // k-steps of the DCT product the instances are built for: 6 (<= 24 filters: the sidekit dialects) or 10 (<= 40: the in-repo MFCC)
@@ -528,13 +607,15 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
     // three workgroups per CU (52 KiB each, 168 VGPRs) when the stage and the operands allow it, two otherwise
     // (measured on the in-repo dialect, 59 KiB per workgroup: 2 x 4 waves per CU with every twiddle resident 8.2 ms; 168-VGPR instances
     //  in 1- / 2- / 3-wave workgroups, 11 / 10 / 9 waves per CU, 9.1 - 9.4 ms)
-    const int occ = (nz == 13 && KS == 6 && lds <= 53248) ? 3 : 2;
+    const int cm = args.cmvn != 0 ? 1 : 0;  // (the plan only leaves cmvn set when mfcc_stream_fuses_cmvn and every utterance is one chunk)
+    const int occ = (nz == 13 && KS == 6 && lds <= 53248 && !cm) ? 3 : 2;  // (the column sums of the scaling instances need the registers)
     const int wg_waves = STREAM_WAVES;
     bool launched = false;
-#define SSP_STREAM_CASE(NZ_, PW_, PR_, MV_, KS_, OCC_)                                                                \
-    if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && f.melv == MV_ && KS == KS_ && occ == OCC_) {                \
-        auto* kfn = f.mel_ns <= 2 ? mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 2, OCC_>                             \
-                                  : mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 4, OCC_>;                            \
+#define SSP_STREAM_CASE(NZ_, PW_, PR_, MV_, KS_, OCC_) SSP_STREAM_CASE_CM(NZ_, PW_, PR_, MV_, KS_, OCC_, 0)
+#define SSP_STREAM_CASE_CM(NZ_, PW_, PR_, MV_, KS_, OCC_, CM_)                                                        \
+    if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && f.melv == MV_ && KS == KS_ && occ == OCC_ && cm == CM_) {   \
+        auto* kfn = f.mel_ns <= 2 ? mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 2, OCC_, CM_>                        \
+                                  : mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 4, OCC_, CM_>;                       \
         if (lds > 64 * 1024)                                                                                            \
             SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         int per_cu = 0;                                                                                                 \
@@ -545,6 +626,7 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * wg_waves), lds, stream, args, f, sa);                             \
         launched = true;                                                                                                \
     }
+    SSP_STREAM_CASE_CM(13, 2, 1, 2, 6, 2, 1) SSP_STREAM_CASE_CM(13, 2, 1, 3, 6, 2, 1) SSP_STREAM_CASE_CM(13, 2, 1, 4, 6, 2, 1)
 #ifdef SSP_FAST_MINIMAL
     SSP_STREAM_CASE(13, 2, 1, 3, 6, 3)
     SSP_STREAM_CASE(16, 1, 0, 3, 10, 2)
@@ -568,6 +650,7 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
 #undef SSP_STREAM_MV
 #endif
 #undef SSP_STREAM_CASE
+#undef SSP_STREAM_CASE_CM
     if (!launched) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): no kernel instance for this cfg");
     SSP_HIP(hipGetLastError());
     return SSP_OK;

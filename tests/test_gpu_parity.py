@@ -155,6 +155,37 @@ def test_stream_kernel_vs_oracle(ssp, delta_order, cmvn):
     print("stream kernel: worst relative error %.2e" % worst)
 
 
+@pytest.mark.parametrize("delta_order", [0, 1, 2])
+def test_stream_kernel_scales_single_chunk_utterances_itself(ssp, delta_order):
+    """sklearn.preprocessing.scale (GMM_UBM.py:93) inside the wave-stream kernel: every utterance of the batch is one chunk (<= 512
+    frames), so the wave that walks it sums the columns it stores and rewrites its own rows.  Against the oracle (float64 scale), the
+    workgroup kernel's fused scaling and the stand-alone kernel; 1- and 2-frame utterances (a zero deviation scales by 1)."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    lens = [48000, 16000 + 37, 400, 560, 719, 1040, 3000, 4801, 8000, 20003, 82000, 81999, 405, 880]
+    sigs = [synth_audio(u, n, 16000) for u, n in enumerate(lens)]
+    tables = pkg.preset_sidekit(delta_order=delta_order, cmvn=1)
+    got, fseg = _run_plan(api, tables, sigs, variant=3)
+    assert max(np.diff(fseg.offsets)) <= 512
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=delta_order, cmvn=1)
+    g2, _ = _run_plan(api, tables, sigs, variant=2)
+    raw, _ = _run_plan(api, pkg.preset_sidekit(delta_order=delta_order, cmvn=0), sigs, variant=3)
+    ctx = api.default_context()
+    for u, s in enumerate(sigs):
+        assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"stream + scaling utt {u} len {len(s)} order {delta_order}")
+        assert np.abs(got[u] - g2[u]).max() <= 1e-4 * max(1.0, np.abs(g2[u]).max())
+        alone = np.asarray(api.cmvn_features(ctx, raw[u], api.Segments.from_lengths(ctx, [raw[u].shape[0]])))
+        assert np.abs(got[u] - alone).max() <= 1e-4 * max(1.0, np.abs(alone).max())
+        single, _ = _run_plan(api, tables, [s], variant=3)
+        assert np.array_equal(single[0], got[u]), u   # position independent
+    # one utterance longer than a chunk: the whole batch goes through the stand-alone scaling kernel, same values
+    long_sigs = sigs[:4] + [synth_audio(77, 100000, 16000)]
+    gl, fl = _run_plan(api, tables, long_sigs, variant=3)
+    assert max(np.diff(fl.offsets)) > 512
+    for u in range(4):
+        assert np.abs(gl[u] - got[u]).max() <= 1e-4 * max(1.0, np.abs(got[u]).max())
+
+
 def test_stream_kernel_matches_workgroup_kernel_and_auto(ssp):
     pkg, api = ssp
     sigs = [synth_audio(u, n, 16000) for u, n in enumerate(STREAM_LENS[:12])]
