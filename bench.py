@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused workgroup kernel | 3 fused wave-stream kernel")
     ap.add_argument("--ref26-variant", type=int, default=0, help="kernel variant of the 26-d + CMVN stage (as --variant)")
     ap.add_argument("--inrepo-variant", type=int, default=0, help="kernel variant of the in-repo MFCC stage (as --variant)")
-    ap.add_argument("--stages", default="mfcc,ref26,inrepo,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
+    ap.add_argument("--stages", default="mfcc,ref26,inrepo,librosa,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
     ap.add_argument("--gmm4-utts", type=int, default=12000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU; SURVEY.md 8(d) asks for >= 12000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
@@ -363,6 +363,30 @@ def main():
                              "kernel": "mfcc_stream512_kernel" if args.inrepo_variant in (0, 3) else "mfcc_fused512_kernel",
                              "kernel_ms": i_ms, "algorithmic_bytes_per_launch": i_bytes, "bytes_per_frame": 256 * 4 + 13 * 4}}
             del iplan, ifeat
+
+    # ------------------------------------------------------------------ the librosa dialect of MFCC_DTW.MFCC_lib (MFCC_DTW.py:28-31): sr 8000, n_fft 2048, hop 512,
+    # 128 mel filters, power_to_db with the utterance-wide top_db clamp, 13 coefficients; the same resident samples read as 8 kHz audio
+    if "librosa" in stages:
+        lplan = api.MfccPlan(ctx, pkg.preset_librosa(8000, 13))
+        l_samp = int(round(args.seconds * 8000))
+        l_utt = (n_utt * n_samp) // l_samp
+        lseg = api.Segments.from_lengths(ctx, np.full(l_utt, l_samp, dtype=np.int64))
+        lfseg = lplan.frame_segments(lseg)
+        lfeat = torch.empty((lfseg.total, lplan.d_out), dtype=torch.float32, device=device)
+        lplan.run(flat[: l_utt * l_samp], lseg, lfseg, out=lfeat)
+        lms = []
+        for _ in range(3):
+            _, ms = lplan.run(flat[: l_utt * l_samp], lseg, lfseg, out=lfeat, timing=True)
+            lms.append(ms)
+        l_ms = float(np.median(lms))
+        l_bytes = l_utt * l_samp * 4 + lfseg.total * lplan.d_out * 4
+        result["mfcc_librosa"] = {
+            "metric": "librosa-dialect MFCC frames/s (MFCC_DTW.MFCC_lib: n_fft 2048 / hop 512, 128 mel, top_db 80, 13-d)", "value": lfseg.total / (l_ms * 1e-3),
+            "unit": "frames/s", "utterances_per_gpu": l_utt, "frames_per_gpu": int(lfseg.total), "dtype": "f32",
+            "roofline": {"bound": "hbm", "achieved": l_bytes / (l_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": l_bytes / (l_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "mfcc_generic_kernel<2048> + topdb_dct_kernel",
+                         "kernel_ms": l_ms, "algorithmic_bytes_per_launch": l_bytes, "bytes_per_frame": 512 * 4 + 13 * 4}}
+        del lplan, lfeat
 
     # ------------------------------------------------------------------ GMM-UBM scoring stage (configs[2])
     if "gmm" in stages:
@@ -594,9 +618,9 @@ def main():
                          "unit": "pairs/s", "kernel_ms": ms, "cell_updates_per_s": nq * nt * L * L / ms * 1e3, "dtype": "f32"}
 
     if "plp" in stages:
-        # PLP features (sidekit plp): Bark front end through the MFCC pass + RASTA / Levinson / cepstrum back end, on a slice of the
-        # resident audio
-        n_p = min(n_utt, 20000)
+        # PLP features (sidekit plp): Bark front end through the MFCC pass (the wave-stream kernel's dense-band instance) + RASTA /
+        # Levinson / cepstrum back end, on the resident audio
+        n_p = n_utt
         pplan = api.MfccPlan(ctx, pkg.preset_sidekit_plp(fs=fs))
         pseg = api.Segments.from_lengths(ctx, np.full(n_p, n_samp, dtype=np.int64))
         pfs = pplan.frame_segments(pseg)
@@ -604,10 +628,14 @@ def main():
         sl = flat[:n_p * n_samp]
         pplan.run(sl, pseg, pfs, out=logspec)
         api.plp_post(ctx, logspec, pfs, fs / 2.0)
-        _, ms_f = pplan.run(sl, pseg, pfs, out=logspec, timing=True)
-        _, ms_b = api.plp_post(ctx, logspec, pfs, fs / 2.0, timing=True)
+        ms_f = float(np.median([pplan.run(sl, pseg, pfs, out=logspec, timing=True)[1] for _ in range(3)]))
+        ms_b = float(np.median([api.plp_post(ctx, logspec, pfs, fs / 2.0, timing=True)[1] for _ in range(3)]))
+        p_bytes = n_p * n_samp * 4 + pfs.total * pplan.d_out * 4
         result["plp"] = {"metric": "PLP frames/s (13-d, RASTA; Bark front end + LPC-cepstrum back end)", "value": pfs.total / (ms_f + ms_b) * 1e3,
-                         "unit": "frames/s", "front_ms": ms_f, "back_ms": ms_b, "utterances": n_p, "dtype": "f32"}
+                         "unit": "frames/s", "front_ms": ms_f, "back_ms": ms_b, "utterances": n_p, "dtype": "f32",
+                         "front_roofline": {"bound": "hbm", "achieved": p_bytes / (ms_f * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": p_bytes / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "mfcc_stream512_kernel<dense bands>",
+                                            "kernel_ms": ms_f, "bytes_per_frame": tables.cfg.hop * 4 + pplan.d_out * 4}}
         del logspec
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)

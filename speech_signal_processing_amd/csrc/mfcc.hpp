@@ -90,6 +90,7 @@ struct StreamArgs {
     int32_t wave_bytes;       // LDS per wave: 4 frame images + sample stage + cepstrum ring
     int32_t stage_bytes;      // sample stage (whole 1-KiB DMA pieces + a trailing 512-B half piece)
     int32_t table_bytes;      // workgroup-shared DCT operand table in front of the wave regions
+    const float* dense_w;     // dense-band instances: [lane][6 bands][20] weights (16 bins of the lane's chunk, bin 256, pad), pscale folded in
 };
 
 int launch_mfcc_generic(const MfccArgs& args, int n_chunks, size_t lds_bytes, int n_waves, int num_cu, hipStream_t stream);
@@ -130,7 +131,7 @@ struct ssp_mfcc_plan {
     ssp::DevBuf f_tw16, f_wpost, f_melw, f_mello, f_melid, f_dct, f_pcw, f_pcofs, f_pcmask, f_pcfid, f_scratch, f_counter;
     // wave-stream kernel
     bool stream_ready = false;
-    ssp::DevBuf s_dctA;
+    ssp::DevBuf s_dctA, s_dense;
 };
 
 namespace ssp {
@@ -140,6 +141,7 @@ size_t mfcc_fast_lds(const ssp_mfcc_cfg& cfg, FastArgs& f, int chunk_frames);
 int mfcc_fast_max_chunk(const ssp_mfcc_cfg& cfg, const FastArgs& f);  // most frames one workgroup can take at once
 int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, int chunk_frames, hipStream_t stream);
 bool mfcc_stream_supported(const ssp_mfcc_plan* plan);  // cfg covered by the wave-stream kernel
+bool mfcc_stream_dense(const ssp_mfcc_plan* plan);      // ... by the dense-band instance (identity DCT over <= 24 dense filterbank rows: the PLP front end)
 bool mfcc_stream_fuses_cmvn(const ssp_mfcc_plan* plan); // ... by an instance that scales the features itself (cmvn) when every utterance is one chunk
 int build_stream_tables(ssp_mfcc_plan* plan);
 int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, hipStream_t stream);

@@ -411,7 +411,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
         SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the fused fast kernel does not cover this cfg");
     const bool stream_ok = plan->stream_ready && mfcc_stream_supported(plan);
     if (v == 3 && !stream_ok) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the wave-stream kernel does not cover this cfg");
-    if (variant == 0 && v == 2 && stream_ok) v = 3;
+    if (variant == 0 && stream_ok && (v == 2 || mfcc_stream_dense(plan))) v = 3;
     // the work table is cached per (segment pair, REQUESTED variant): an auto request that fell back to another kernel is remembered
     // as such instead of being rebuilt (chunk table upload + stream sync) on every call
     if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_request != variant) {

@@ -93,16 +93,34 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
     for (int s = 0; s < KS; ++s) dA[s] = sa.dctA[s * 64 + lane];
 #pragma unroll
     for (int i = 0; i < NWP; ++i) wpr[i] = *reinterpret_cast<const v2f*>(&f.wpost[i * 16 + j]);
-    v4f mw[MELV];
-    int mofs[MELV];
+    // MELV == 0: DENSE filterbank rows (the Bark bands of the PLP front end: every band has a weight on every bin) with an identity
+    // "DCT".  Lane (c = lane & 15, b = lane >> 4) holds the weights of bands 6 b .. 6 b + 5 on bins 16 c .. 16 c + 15 (and on bin 256)
+    // in registers; the log band energies of a quad leave as two coalesced stores, no ring, no time steps.
+    constexpr bool DENSE = MELV == 0;
+    constexpr int MV = DENSE ? 1 : MELV;
+    v4f mw[MV];
+    int mofs[MV];
+    v2f mk01 = v2f{0.f, 0.f}, mk23 = v2f{0.f, 0.f};
+    int mfid = -1;
+    v4f dw[DENSE ? 6 : 1][4];
+    float dw256[DENSE ? 6 : 1];
+    if (DENSE) {
 #pragma unroll
-    for (int i = 0; i < MELV; ++i) {
-        mw[i] = *reinterpret_cast<const v4f*>(f.pc_w + ((size_t)lane * MELV + i) * 4);
-        mofs[i] = f.pc_ofs[lane * MELV + i];
+        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dw[DENSE ? k : 0][i] = *reinterpret_cast<const v4f*>(sa.dense_w + ((size_t)lane * 6 + k) * 20 + 4 * i);
+            dw256[DENSE ? k : 0] = sa.dense_w[((size_t)lane * 6 + k) * 20 + 16];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MV; ++i) {
+            mw[i] = *reinterpret_cast<const v4f*>(f.pc_w + ((size_t)lane * MV + i) * 4);
+            mofs[i] = f.pc_ofs[lane * MV + i];
+        }
+        mk01 = *reinterpret_cast<const v2f*>(f.pc_mask + lane * 4);
+        mk23 = NS > 2 ? *reinterpret_cast<const v2f*>(f.pc_mask + lane * 4 + 2) : v2f{0.f, 0.f};
+        mfid = f.pc_fid[lane];
     }
-    const v2f mk01 = *reinterpret_cast<const v2f*>(f.pc_mask + lane * 4);
-    const v2f mk23 = NS > 2 ? *reinterpret_cast<const v2f*>(f.pc_mask + lane * 4 + 2) : v2f{0.f, 0.f};
-    const int mfid = f.pc_fid[lane];
 
     const int hop = a.hop;
     const float pre = PRE ? a.preemph : 0.f;
@@ -135,7 +153,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         const int nquads = (R + 3) >> 2;
         const int E = t0 + n - ta;                 // emitted frames end (relative)
         const int n_steps = (E + 4 + 15) >> 4;     // step b emits rows [16 b - 4, 16 b + 12)
-        const int Q = 4 * n_steps;
+        const int Q = DENSE ? nquads : 4 * n_steps;
         const float Tm1 = (float)(T - 1);
 
         const uint64_t xaddr = reinterpret_cast<uint64_t>(a.samples + s0);
@@ -180,6 +198,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 // the quad's DMA has landed; the stores of a preceding step were issued behind it and may still be in flight
 #ifndef SSP_S_NOWAIT  // (ablation, wrong results: what the wait for the sample DMA costs)
                 if (stores_pending == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (stores_pending == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 else if (stores_pending == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else if (stores_pending == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
@@ -296,6 +315,55 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                     if (POWER == 1) p128 = __builtin_sqrtf(p128);
                     if (j == 0) P[128] = p128;
                 }
+                if (DENSE) {
+                    // ---- dense bands: partial sums of this lane's 17 bins for 6 bands and the quad's 4 frames ...
+                    int ol = lane;
+                    asm volatile("" : "+v"(ol));
+                    const int c = ol & 15;
+                    float r[4][6];
+#pragma unroll
+                    for (int fr = 0; fr < 4; ++fr) {
+                        const char* pr = zbuf + fr * ZFRAME;
+                        const v4f p0 = *reinterpret_cast<const v4f*>(pr + 64 * c), p1 = *reinterpret_cast<const v4f*>(pr + 64 * c + 16);
+                        const v4f p2 = *reinterpret_cast<const v4f*>(pr + 64 * c + 32), p3 = *reinterpret_cast<const v4f*>(pr + 64 * c + 48);
+                        const float p256 = *reinterpret_cast<const float*>(pr + 1024);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            v4f acc = p0 * dw[DENSE ? k : 0][0];
+                            acc = __builtin_elementwise_fma(p1, dw[DENSE ? k : 0][1], acc);
+                            acc = __builtin_elementwise_fma(p2, dw[DENSE ? k : 0][2], acc);
+                            acc = __builtin_elementwise_fma(p3, dw[DENSE ? k : 0][3], acc);
+                            const v2f hs = v2f{acc.x, acc.y} + v2f{acc.z, acc.w};
+                            r[fr][k] = __builtin_fmaf(p256, dw256[DENSE ? k : 0], hs.x + hs.y);
+                        }
+                    }
+                    // ... meet through LDS ([frame][band of the group][lane] over the frame images, whose P rows are consumed): output
+                    // o = frame * n_bands + band sums the 16 bin-chunk lanes of its band group
+                    float* sc = reinterpret_cast<float*>(zbuf);
+#pragma unroll
+                    for (int fr = 0; fr < 4; ++fr)
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) sc[(fr * 6 + k) * 64 + ol] = r[fr][k];
+                    const int nb = a.n_filt;
+#pragma unroll
+                    for (int rd = 0; rd < 2; ++rd) {
+                        const int o = rd * 64 + ol;
+                        const int fr = (o >= nb) + (o >= 2 * nb) + (o >= 3 * nb);
+                        const int band = o - fr * nb;
+                        const int bg = (band * 43) >> 8, k = band - 6 * bg;  // band / 6 for band < 24
+                        const bool valid = o < 4 * nb;
+                        const float* src = sc + ((valid ? fr * 6 + k : 0) * 64 + (valid ? 16 * bg : 0));
+                        const v4f s0 = *reinterpret_cast<const v4f*>(src), s1 = *reinterpret_cast<const v4f*>(src + 4);
+                        const v4f s2 = *reinterpret_cast<const v4f*>(src + 8), s3 = *reinterpret_cast<const v4f*>(src + 12);
+                        const v4f s4 = (s0 + s1) + (s2 + s3);
+                        const float val = stream_log(f, (s4.x + s4.y) + (s4.z + s4.w));
+                        const bool ok = valid && ta + 4 * q + fr < tb;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, ok ? ((ta + 4 * q) * Dd + o) * 4 : 0x7ffffff0, 0, 0);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch is read: the next quad's transposes may overwrite it
+                    stores_pending = 2;
+                    continue;
+                }
                 // ---- piece filterbank + log: all 64 lanes on one frame at a time (see mfcc_fast.hip step 7)
 #ifndef SSP_S_NOMEL
                 {
@@ -307,7 +375,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                         const char* pr = zbuf + fr * ZFRAME;
                         v4f acc = *reinterpret_cast<const v4f*>(pr + mofs[0]) * mw[0];
 #pragma unroll
-                        for (int i = 1; i < MELV; ++i) acc = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(pr + mofs[i]), mw[i], acc);
+                        for (int i = 1; i < MV; ++i) acc = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(pr + mofs[i]), mw[i], acc);
                         const v2f h = v2f{acc.x, acc.y} + v2f{acc.z, acc.w};
                         sfr[fr] = h.x + h.y;
                     }
@@ -545,11 +613,19 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// dense-band instance: <= 24 filterbank rows that the piece filterbank cannot hold, identity "DCT", no deltas, the sidekit front end
+bool mfcc_stream_dense(const ssp_mfcc_plan* p) {
+    const ssp_mfcc_cfg& c = p->cfg;
+    return mfcc_fast_supported(c) && p->fast_ready && !getenv("SSP_MFCC_NO_STREAM") && p->fast.melv == 0 && p->args.dct_identity &&
+           c.n_filt <= 24 && c.delta_order == 0 && c.win_len <= 416 && c.spec_power == 2 && c.preemph_mode != 0;
+}
+
 bool mfcc_stream_supported(const ssp_mfcc_plan* p) {
     const ssp_mfcc_cfg& c = p->cfg;
     const FastArgs& f = p->fast;
     if (!(mfcc_fast_supported(c) && p->fast_ready)) return false;
     if (getenv("SSP_MFCC_NO_STREAM")) return false;
+    if (mfcc_stream_dense(p)) return true;
     const int ks = (c.n_filt + 3) / 4;
     return f.melv >= 2 && f.melv <= (ks <= 6 ? 4 : 5) && c.n_ceps == 13 && ks <= 10 && (c.delta_order == 0 || c.delta_N == 2);
 }
@@ -557,7 +633,7 @@ bool mfcc_stream_supported(const ssp_mfcc_plan* p) {
 // the instances that scale the features themselves (cmvn): the sidekit call-site family
 bool mfcc_stream_fuses_cmvn(const ssp_mfcc_plan* p) {
     const ssp_mfcc_cfg& c = p->cfg;
-    return mfcc_stream_supported(p) && c.win_len <= 416 && c.spec_power == 2 && c.preemph_mode != 0 && (c.n_filt + 3) / 4 <= 6;
+    return mfcc_stream_supported(p) && !mfcc_stream_dense(p) && c.win_len <= 416 && c.spec_power == 2 && c.preemph_mode != 0 && (c.n_filt + 3) / 4 <= 6;
 }
 
 // k-steps of the DCT product the instances are built for: 6 (<= 24 filters: the sidekit dialects) or 10 (<= 40: the in-repo MFCC)
@@ -576,6 +652,24 @@ int build_stream_tables(ssp_mfcc_plan* p) {
         }
     SSP_TRY(p->s_dctA.alloc(dA.size() * sizeof(float)));
     SSP_HIP(hipMemcpy(p->s_dctA.p, dA.data(), dA.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (mfcc_stream_dense(p)) {
+        // lane (c = l & 15, b = l >> 4): bands 6 b + k on bins 16 c + i (i < 16) and, on chunk 15 only, bin 256; the split step leaves
+        // 2 X[k], the scale of the spectrum is folded in (as the piece filterbank does)
+        const int nb = 257;
+        std::vector<float> fb((size_t)c.n_filt * nb), dw((size_t)64 * 6 * 20, 0.f);
+        SSP_HIP(hipMemcpy(fb.data(), p->fbank_dense.p, fb.size() * sizeof(float), hipMemcpyDeviceToHost));
+        const float pscale = (c.spec_power == 2 ? 0.25f : 0.5f) * c.spec_scale;
+        for (int l = 0; l < 64; ++l)
+            for (int k = 0; k < 6; ++k) {
+                const int band = 6 * (l >> 4) + k, ch = l & 15;
+                if (band >= c.n_filt) continue;
+                float* d = dw.data() + ((size_t)l * 6 + k) * 20;
+                for (int i = 0; i < 16; ++i) d[i] = pscale * fb[(size_t)band * nb + 16 * ch + i];
+                if (ch == 15) d[16] = pscale * fb[(size_t)band * nb + 256];
+            }
+        SSP_TRY(p->s_dense.alloc(dw.size() * sizeof(float)));
+        SSP_HIP(hipMemcpy(p->s_dense.p, dw.data(), dw.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     p->stream_ready = true;
     return SSP_OK;
 }
@@ -588,8 +682,9 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
     const int KS = stream_ks(c);
     // padded filter slots of the log-mel rows (up to 4 KS) must read as finite zeros
     f.lm_pad = 4 * KS - c.n_filt;
-    if (f.lm_pad > 16) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): %d filters leave more than 16 padded slots", c.n_filt);
+    if (f.lm_pad > 16 && f.melv != 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): %d filters leave more than 16 padded slots", c.n_filt);
     sa.dctA = p->s_dctA.as<float>();
+    sa.dense_w = p->s_dense.as<float>();
     // the trailing half piece of the sample stage only writes 512 B
     const int n_piece = (f.slen + 255) >> 8;
     const bool has_half = (f.slen & 255) != 0 && (f.slen & 255) <= 128;
@@ -608,7 +703,8 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
     // (measured on the in-repo dialect, 59 KiB per workgroup: 2 x 4 waves per CU with every twiddle resident 8.2 ms; 168-VGPR instances
     //  in 1- / 2- / 3-wave workgroups, 11 / 10 / 9 waves per CU, 9.1 - 9.4 ms)
     const int cm = args.cmvn != 0 ? 1 : 0;  // (the plan only leaves cmvn set when mfcc_stream_fuses_cmvn and every utterance is one chunk)
-    const int occ = (nz == 13 && KS == 6 && lds <= 53248 && !cm) ? 3 : 2;  // (the column sums of the scaling instances need the registers)
+    // (the column sums of the scaling instances and the 102 weights per lane of the dense-band instance need the registers)
+    const int occ = (nz == 13 && KS == 6 && lds <= 53248 && !cm && f.melv != 0) ? 3 : 2;
     const int wg_waves = STREAM_WAVES;
     bool launched = false;
 #define SSP_STREAM_CASE(NZ_, PW_, PR_, MV_, KS_, OCC_) SSP_STREAM_CASE_CM(NZ_, PW_, PR_, MV_, KS_, OCC_, 0)
@@ -627,6 +723,7 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
         launched = true;                                                                                                \
     }
     SSP_STREAM_CASE_CM(13, 2, 1, 2, 6, 2, 1) SSP_STREAM_CASE_CM(13, 2, 1, 3, 6, 2, 1) SSP_STREAM_CASE_CM(13, 2, 1, 4, 6, 2, 1)
+    SSP_STREAM_CASE(13, 2, 1, 0, 6, 2)  // dense bands (the PLP front end)
 #ifdef SSP_FAST_MINIMAL
     SSP_STREAM_CASE(13, 2, 1, 3, 6, 3)
     SSP_STREAM_CASE(16, 1, 0, 3, 10, 2)

@@ -186,6 +186,32 @@ def test_stream_kernel_scales_single_chunk_utterances_itself(ssp, delta_order):
         assert np.abs(gl[u] - got[u]).max() <= 1e-4 * max(1.0, np.abs(got[u]).max())
 
 
+def test_stream_kernel_dense_bands_plp_front_end(ssp):
+    """The PLP front end (GMM_UBM.py:95 / d_vector.py:93: sidekit plp up to ln(Bark band energies): 21 bands with a weight on every
+    one of the 257 bins, identity DCT) on the wave-stream kernel's dense-band instance: against the generic kernel (same tables), for a
+    ragged batch with 1-frame and multi-chunk utterances, and identical to what the library picks on its own."""
+    pkg, api = ssp
+    tables = pkg.preset_sidekit_plp()
+    sigs = [synth_audio(u, n, 16000) for u, n in enumerate([48000, 16037, 400, 560, 719, 3000, 4801, 100003, 163840 + 401])]
+    g3, fseg = _run_plan(api, tables, sigs, variant=3)
+    g1, _ = _run_plan(api, tables, sigs, variant=1)
+    g0, _ = _run_plan(api, tables, sigs, variant=0)
+    assert g3[0].shape[1] == 21 and max(np.diff(fseg.offsets)) > 512
+    worst = 0.0
+    for u in range(len(sigs)):
+        assert np.array_equal(g3[u], g0[u])
+        assert np.isfinite(g3[u]).all()
+        worst = max(worst, float(np.abs(g3[u] - g1[u]).max() / max(1.0, np.abs(g1[u]).max())))
+        single, _ = _run_plan(api, tables, [sigs[u]], variant=3)
+        assert np.array_equal(single[0], g3[u]), u
+    observe("plp front end, dense-band stream instance vs generic kernel", worst, FEAT_TOL)
+    assert worst <= FEAT_TOL
+    from oracle import ref_cpu as O
+    cfg, w, fb, dct = O.sidekit_plp_tables()
+    for u in (1, 3, 5):
+        assert_feat_close(g3[u], O.mfcc_pipeline(sigs[u], cfg, w, fb, dct), what=f"plp front end utt {u}")
+
+
 def test_stream_kernel_matches_workgroup_kernel_and_auto(ssp):
     pkg, api = ssp
     sigs = [synth_audio(u, n, 16000) for u, n in enumerate(STREAM_LENS[:12])]
