@@ -91,7 +91,12 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     // with it): the key is dropped first and only restored at the end
     p->cache_sseg = p->cache_fseg = 0;
     p->cache_variant = p->cache_request = -1;
-    if (variant == 3) {
+    if (variant == 4) {
+        // 2048-point wave-stream kernel: first pass only (log filterbank rows + utterance maxima); chunks of 64 frames, one wave each
+        ch = 64;
+        split_topdb = true;
+        whole = false;
+    } else if (variant == 3) {
         // wave-stream kernel: a chunk is a run of frames one WAVE walks alone (no LDS bound); whole utterances up to 512 frames, longer ones
         // in 512-frame chunks with a recomputed 4-frame halo.  CMVN needs the whole utterance: inside the kernel when every utterance is a
         // single chunk (and the dialect has a scaling instance), the stand-alone kernel afterwards otherwise.
@@ -311,6 +316,7 @@ int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* win
         set_error("mfcc plan: table upload failed");
         rc = SSP_ERR_HIP;
     }
+    if (rc == SSP_OK) rc = build_s2k_tables(p);  // (n_fft == 2048 without deltas; leaves s2k_ready false otherwise)
     if (rc == SSP_OK && mfcc_fast_supported(*cfg)) {
         const int frc = build_fast_tables(p);  // a filterbank the fused kernel cannot lay out only disables that kernel
         if (frc != SSP_OK && frc != SSP_ERR_UNSUPPORTED) rc = frc;
@@ -383,7 +389,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     SSP_TRY(use_ctx(plan->ctx));
     if (sample_seg->n != frame_seg->n) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: sample/frame segment counts differ");
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: where");
-    if (variant < 0 || variant > 3) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: variant");
+    if (variant < 0 || variant > 4) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: variant");
     const int64_t total_frames = frame_seg->total();
     const int64_t n_samp_total = sample_seg->host.back();
     if (kernel_ms) *kernel_ms = 0.f;
@@ -412,6 +418,8 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     const bool stream_ok = plan->stream_ready && mfcc_stream_supported(plan);
     if (v == 3 && !stream_ok) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the wave-stream kernel does not cover this cfg");
     if (variant == 0 && stream_ok && (v == 2 || mfcc_stream_dense(plan))) v = 3;
+    if (v == 4 && !mfcc_s2k_supported(plan)) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_mfcc_run: the 2048-point wave-stream kernel does not cover this cfg");
+    if (variant == 0 && v == 1 && mfcc_s2k_supported(plan)) v = 4;
     // the work table is cached per (segment pair, REQUESTED variant): an auto request that fell back to another kernel is remembered
     // as such instead of being rebuilt (chunk table upload + stream sync) on every call
     if (plan->cache_sseg != sample_seg->serial || plan->cache_fseg != frame_seg->serial || plan->cache_request != variant) {
@@ -441,7 +449,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     MfccArgs a = plan->args;
     if (plan->cache_split_cmvn) a.cmvn = 0;  // utterances longer than one workgroup's chunk: normalised by the CMVN kernel below
     a.lm_out = nullptr;
-    if (plan->cache_split_topdb && v == 1) {  // two-pass top_db: log-mel rows to a scratch, clamp + DCT in a second kernel
+    if (plan->cache_split_topdb && (v == 1 || v == 4)) {  // two-pass top_db: log-mel rows to a scratch, clamp + DCT in a second kernel
         SSP_TRY(plan->lm_scratch.reserve((size_t)total_frames * plan->cfg.n_filt * sizeof(float)));
         a.lm_out = plan->lm_scratch.as<float>();
         SSP_TRY(plan->umax_scratch.reserve((size_t)frame_seg->n * sizeof(float)));
@@ -456,7 +464,9 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     a.chunks = plan->chunks.as<MfccChunk>();
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, s));
-    if (v == 3)
+    if (v == 4)
+        SSP_TRY(launch_mfcc_s2k(a, plan, plan->cache_n_chunks, s));
+    else if (v == 3)
         SSP_TRY(launch_mfcc_stream(a, plan, plan->cache_n_chunks, s));
     else if (v == 2)
         SSP_TRY(launch_mfcc_fast(a, plan, plan->cache_n_chunks, plan->cache_chunk_frames, s));
@@ -465,7 +475,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     if (a.lm_out)
         SSP_TRY(launch_topdb_dct(a.lm_out, frame_seg->dev.as<int64_t>(), frame_seg->n, a.chunks, plan->cache_n_chunks, a.utt_max,
                                  plan->cfg.n_filt, plan->cfg.n_ceps, plan->dct.as<float>(),
-                                 plan->cfg.top_db, d_out, s));
+                                 plan->cfg.top_db >= 0.f ? plan->cfg.top_db : INFINITY /* no clamp: max - inf */, d_out, s));
     if (plan->cache_split_cmvn) SSP_TRY(launch_cmvn(d_out, d_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->d_out, frame_seg->max_len(), s));
     SSP_TRY(tm.stop(s, kernel_ms));
     SSP_TRY(sout.back(plan->ctx, feats_out, out_bytes, where));

@@ -1,0 +1,399 @@
+// mfcc_stream2048_kernel — first pass of the fused MFCC for n_fft == 2048 dialects without deltas (the librosa call site
+// MFCC_DTW.py:28-31: 2048-sample periodic Hann window, hop 512, centred frames with reflect padding, power spectrum, 128 Slaney mel
+// filters, 10 log10(max(1e-10, .)), clamp at the utterance maximum - 80 dB, DCT-II; and utils/processing.py:110-144 with frameSize 2048).
+//
+// Every WAVE is an independent stream (as in mfcc_stream.hip): it claims a chunk of consecutive frames of one utterance from a global
+// counter and walks it one frame at a time, the whole wave on one frame, 16 complex points of the 1024-point complex FFT (which carries
+// the 2048-point real FFT) per lane; no workgroup barrier after the tables are staged.  Per frame:
+//   * the samples of the NEXT frame are loaded into registers (16 eight-byte loads per lane, coalesced; frames that touch the utterance
+//     ends take a per-sample path with the reflect / zero rule) while this frame is transformed;
+//   * 1024 = 16 x 16 x 4: radix-16 over the registers, twiddle, transpose through wave-private LDS, radix-16, twiddle, a second transpose
+//     that leaves the four inputs of every radix-4 butterfly in one lane, radix-4;
+//   * the spectrum goes to LDS in natural order, the split step of the real FFT pairs bins k and 1024 - k, power / magnitude row P[0..1024];
+//   * filterbank as 4-tap pieces spread evenly over the lanes (a filter's pieces sit in different steps, so the LDS float adds that
+//     collect a filter's sum do not collide), log, and the log filterbank row leaves for the second pass (the utterance-wide top_db clamp
+//     needs every frame's maximum first; dialects without a clamp take the same second pass with the clamp off): launch_topdb_dct.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "mfcc.hpp"
+#include "cplx.hpp"
+
+namespace ssp {
+
+namespace {
+constexpr int S2K_WAVES = 4;
+constexpr int ROW1 = 68;                                   // complex slots per row of the first transpose image (64 + 4 pad)
+constexpr int S2K_BUF_BYTES = (1024 + 16 * 16) * 8;        // the natural-order spectrum image is the largest user of the wave buffer
+constexpr int S2K_WAVE_BYTES = S2K_BUF_BYTES + 128 * 4;    // + the log filterbank row
+constexpr int S2K_TWB_BYTES = 4 * 16 * 8;
+constexpr int S2K_TWS_BYTES = 9 * 64 * 8;                  // split twiddles (workgroup-shared: 18 registers per lane otherwise, and a spill
+                                                           // reload inside the frame loop waits behind the next frame's sample loads)
+__host__ __device__ constexpr int xpad(int k) { return k + ((k >> 6) << 4); }  // 64-point blocks 16 slots apart: their writes alternate bank halves
+
+struct __attribute__((packed, aligned(4))) f2u {
+    float x, y;
+};
+
+// LDS operations of one wave execute in issue order: between the phases that exchange data through the wave buffer only the COMPILER must
+// be kept from reordering.  (A wavefront-scope fence also makes it wait for every outstanding global load — the next frame's samples,
+// issued a moment earlier.)
+__device__ __forceinline__ void wave_sync2k() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float log2k(const MfccArgs& a, float v) {
+    if (a.floor_mode == 1) v += a.eps;
+    else if (a.floor_mode == 2) v = fmaxf(v, a.eps);
+    const float l2 = __builtin_amdgcn_logf(v);
+    return l2 * (a.log_mode == 0 ? 0.6931471805599453f : (a.log_mode == 1 ? 0.30102999566398120f : 3.0102999566398120f));
+}
+}  // namespace
+
+struct S2kArgs {
+    const float2* twA;   // [16][64]  W_1024^(l k1)
+    const float2* twB;   // [4][16]   W_64^(lb ka)
+    const float2* twS;   // [9][64]   W_2048^k, k = l + 64 i (k <= 512)
+    const char* mel;     // [steps0 + steps1][64] 4-tap weight steps: the group of the 64 shortest filters, then the 64 longest
+    const int32_t* minfo;  // [2][64][2] per group and lane: byte offset of the first step in the P row, filter id (-1: none)
+    int32_t* work_counter;
+    int32_t steps0, steps1, n_chunks, table_bytes;
+};
+
+__global__ __launch_bounds__(64 * S2K_WAVES, 2) void mfcc_stream2048_kernel(MfccArgs a, S2kArgs s) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup-shared tables: twB, split twiddles, then the piece records
+    {
+        const int n16 = s.table_bytes >> 4;
+        const v4f* src_b = reinterpret_cast<const v4f*>(s.twB);
+        const v4f* src_s = reinterpret_cast<const v4f*>(s.twS);
+        const v4f* src_m = reinterpret_cast<const v4f*>(s.mel);
+        v4f* dst = reinterpret_cast<v4f*>(smem);
+        constexpr int NB = S2K_TWB_BYTES / 16, NS = S2K_TWS_BYTES / 16;
+        for (int i = tid; i < n16; i += 64 * S2K_WAVES) dst[i] = i < NB ? src_b[i] : (i < NB + NS ? src_s[i - NB] : src_m[i - NB - NS]);
+    }
+    __syncthreads();
+    const v2f* twB = reinterpret_cast<const v2f*>(smem);
+    const v2f* twS = reinterpret_cast<const v2f*>(smem + S2K_TWB_BYTES);
+    const char* melt = smem + S2K_TWB_BYTES + S2K_TWS_BYTES;
+    char* wbase = smem + s.table_bytes + wave * S2K_WAVE_BYTES;
+    v2f* buf = reinterpret_cast<v2f*>(wbase);
+    [[maybe_unused]] float* lm = reinterpret_cast<float*>(wbase + S2K_BUF_BYTES);
+
+    // lane-resident tables: window taps of this lane's 16 complex points, first-pass twiddles, split twiddles
+    v2f wv[16], ta[15];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wv[r] = *reinterpret_cast<const v2f*>(a.window + 128 * r + 2 * lane);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) ta[k1 - 1] = *reinterpret_cast<const v2f*>(&s.twA[k1 * 64 + lane]);
+    const int mstart0 = s.minfo[lane * 2], mfid0 = s.minfo[lane * 2 + 1];
+    const int mstart1 = s.minfo[128 + lane * 2], mfid1 = s.minfo[128 + lane * 2 + 1];
+    const int hop = a.hop;
+    const int M = 1024;
+    const bool centre = a.frame_mode == 2;
+
+    for (;;) {
+        int cidx = 0;
+        if (lane == 0) cidx = atomicAdd(s.work_counter, 1);
+        cidx = __builtin_amdgcn_readfirstlane(cidx);
+        if (cidx >= s.n_chunks) break;
+        const MfccChunk ch = a.chunks[cidx];
+        const int64_t s0 = a.sample_off[ch.utt];
+        const int64_t N = a.sample_off[ch.utt + 1] - s0;
+        const int64_t f0 = a.frame_off[ch.utt];
+        const float* __restrict__ x = a.samples + s0;
+        const int t0 = __builtin_amdgcn_readfirstlane(ch.t0), n = __builtin_amdgcn_readfirstlane(ch.n);
+        float wave_max = -INFINITY;
+
+        auto load_frame = [&](int t, v2f (&v)[16]) {
+            const int64_t g0 = (int64_t)t * hop - (centre ? M : 0);
+            if (g0 >= 0 && g0 + 2 * M <= N) {
+                const float* __restrict__ xp = x + g0 + 2 * lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f2u t2 = *reinterpret_cast<const f2u*>(xp + 128 * r);
+                    v[r] = v2f{t2.x, t2.y};
+                }
+            } else {
+                // frames that touch the utterance ends: every index is formed first and every load is unconditional, so the 32 loads
+                // of a lane are in flight together (a conditional load per sample serialises them: one memory latency EACH, which made
+                // the four edge frames of a 47-frame utterance cost more than the other 43)
+                const int g0i = (int)g0, Ni = (int)N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float e[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        int g = g0i + 128 * r + 2 * lane + c;
+                        if (centre) {  // numpy.pad(mode='reflect'), as frame_sample() of the generic kernel
+                            g = g < 0 ? -g : g;
+                            g = g >= Ni ? 2 * (Ni - 1) - g : g;
+                            g = max(0, min(g, Ni - 1));
+                            e[c] = x[g];
+                        } else {
+                            const float xv = x[min(g, Ni - 1)];
+                            e[c] = g < Ni ? xv : 0.f;
+                        }
+                    }
+                    v[r] = v2f{e[0], e[1]};
+                }
+            }
+        };
+
+        v2f nx[16];
+        load_frame(t0, nx);
+        for (int t = t0; t < t0 + n; ++t) {
+            v2f z[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = nx[r] * wv[r];
+#ifndef SSP_2K_NOPREFETCH  // (ablation, wrong results: every frame transforms the chunk's first one)
+            if (t + 1 < t0 + n) load_frame(t + 1, nx);
+#endif
+#ifdef SSP_2K_NOFFT  // (ablation, wrong results): staging, log and stores only
+            lm[lane] = z[0].x + z[5].y + z[15].x;
+            lm[lane + 64] = z[1].x + z[9].y;
+            if (true) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int j = lane + 64 * hh;
+                    if (j < a.n_filt) a.lm_out[(size_t)(f0 + t) * a.n_filt + j] = lm[j];
+                }
+                continue;
+            }
+#endif
+            // ---- pass 1: DFT16 over r (points 64 r + l), twiddle W_1024^(l k1)
+            fft16(z);
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], ta[k1 - 1]);
+            // ---- transpose 1: lane (k1, lb) <- points l = 4 la + lb of row k1
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) buf[k1 * ROW1 + lane] = z[k1];
+            wave_sync2k();
+            const int k1p = lane >> 2, lb = lane & 3;
+#pragma unroll
+            for (int la = 0; la < 16; ++la) z[la] = buf[k1p * ROW1 + 4 * la + lb];
+            wave_sync2k();
+            // ---- pass 2: DFT16 over la, twiddle W_64^(lb ka)
+            fft16(z);
+#pragma unroll
+            for (int ka = 1; ka < 16; ++ka) z[ka] = cmul(z[ka], twB[lb * 16 + ka]);
+            // ---- transpose 2: the four lb of a (k1, ka) pair side by side (32-byte unit, units of a row XOR-swizzled by k1)
+#pragma unroll
+            for (int ka = 0; ka < 16; ++ka) buf[(k1p * 16 + (ka ^ k1p)) * 4 + lb] = z[ka];
+            wave_sync2k();
+            const int k1q = lane >> 2, kah = lane & 3;
+            v2f y[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int unit = k1q * 16 + ((4 * kah + i) ^ k1q);
+                const v4f q0 = *reinterpret_cast<const v4f*>(&buf[unit * 4]), q1 = *reinterpret_cast<const v4f*>(&buf[unit * 4 + 2]);
+                y[i][0] = v2f{q0.x, q0.y};
+                y[i][1] = v2f{q0.z, q0.w};
+                y[i][2] = v2f{q1.x, q1.y};
+                y[i][3] = v2f{q1.z, q1.w};
+            }
+            wave_sync2k();
+            // ---- pass 3: DFT4 over lb; Z[k1 + 16 ka + 256 kb] into the natural-order image
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dft4(y[i][0], y[i][1], y[i][2], y[i][3]);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) buf[xpad(k1q + 16 * (4 * kah + i) + 256 * kb)] = y[i][kb];
+            }
+            wave_sync2k();
+            // ---- split step of the real FFT (bins k and M - k from the pair Z[k], Z[M - k]), power / magnitude
+            float pa[9], pb[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int k = lane + 64 * i;
+                pa[i] = pb[i] = 0.f;
+                if (k <= M / 2) {
+                    const v2f zk = buf[xpad(k)];
+                    const v2f zm = buf[xpad((M - k) & (M - 1))];
+                    const v2f hz = zk * 0.5f;
+                    const v2f e = __builtin_elementwise_fma(zm, v2f{0.5f, -0.5f}, hz);
+                    const v2f d = __builtin_elementwise_fma(zm, v2f{-0.5f, 0.5f}, hz);
+                    const v2f o = cmul_negi(d, twS[i * 64 + lane]);
+                    const v2f xa = e + o, xb = e - o;
+                    float p0 = xa.x * xa.x + xa.y * xa.y, p1 = xb.x * xb.x + xb.y * xb.y;
+                    if (a.spec_power == 1) {
+                        p0 = __builtin_sqrtf(p0);
+                        p1 = __builtin_sqrtf(p1);
+                    }
+                    pa[i] = p0 * a.spec_scale;
+                    pb[i] = p1 * a.spec_scale;
+                }
+            }
+            wave_sync2k();
+            float* P = reinterpret_cast<float*>(buf);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int k = lane + 64 * i;
+                if (k <= M / 2) {
+                    P[k] = pa[i];
+                    P[M - k] = pb[i];
+                }
+            }
+            if (lane < 4) P[M + 1 + lane] = 0.f;  // (16-byte reads: the taps behind bin 1024 carry zero weights)
+            wave_sync2k();
+            // ---- filterbank + log: a lane per filter, the 64 shortest filters then the 64 longest (each group sweeps as many 4-tap
+            // steps as its longest filter needs; shorter ones carry zero weights, and start early enough to stay inside the P row);
+            // fixed summation order per filter, no cross-lane traffic; the row leaves for the second pass
+#ifndef SSP_2K_NOMEL
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int nst = g == 0 ? s.steps0 : s.steps1;
+                if (nst == 0) continue;
+                const v4f* wt = reinterpret_cast<const v4f*>(melt) + (size_t)(g == 0 ? 0 : s.steps0) * 64 + lane;
+                const char* pp = reinterpret_cast<const char*>(P) + (g == 0 ? mstart0 : mstart1);
+                v4f acc0 = v4f{0.f, 0.f, 0.f, 0.f}, acc1 = v4f{0.f, 0.f, 0.f, 0.f};
+                for (int st = 0; st < nst; st += 2) {  // (step counts are even)
+                    const v4f w0 = wt[st * 64], w1 = wt[(st + 1) * 64];
+                    const v4f p0 = *reinterpret_cast<const v4f*>(pp + 16 * st), p1 = *reinterpret_cast<const v4f*>(pp + 16 * st + 16);
+                    acc0 = __builtin_elementwise_fma(p0, w0, acc0);
+                    acc1 = __builtin_elementwise_fma(p1, w1, acc1);
+                }
+                const v4f acc = acc0 + acc1;
+                const int fid = g == 0 ? mfid0 : mfid1;
+                if (fid >= 0) {
+                    const float v = log2k(a, (acc.x + acc.y) + (acc.z + acc.w));
+                    a.lm_out[(size_t)(f0 + t) * a.n_filt + fid] = v;
+                    wave_max = fmaxf(wave_max, v);
+                }
+            }
+#endif
+            wave_sync2k();
+        }
+        // utterance maximum for the second pass (float order through the integer trick, as the generic kernel)
+        for (int o = 32; o > 0; o >>= 1) wave_max = fmaxf(wave_max, __shfl_xor(wave_max, o));
+        if (lane == 0 && wave_max > -INFINITY) {
+            if (wave_max >= 0.f) atomicMax(reinterpret_cast<int*>(a.utt_max + ch.utt), __float_as_int(wave_max));
+            else atomicMin(reinterpret_cast<unsigned*>(a.utt_max + ch.utt), __float_as_uint(wave_max));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool mfcc_s2k_supported(const ssp_mfcc_plan* p) { return p->s2k_ready && !getenv("SSP_MFCC_NO_STREAM2K"); }
+
+static bool s2k_cfg_ok(const ssp_mfcc_cfg& c) {
+    return c.n_fft == 2048 && c.win_len == 2048 && c.n_filt <= 128 && c.preemph_mode == 0 && c.delta_order == 0 && c.cmvn == 0 &&
+           c.hop >= 1 && (c.spec_power == 1 || c.spec_power == 2);
+}
+
+int build_s2k_tables(ssp_mfcc_plan* p) {
+    const ssp_mfcc_cfg& c = p->cfg;
+    p->s2k_ready = false;
+    if (!s2k_cfg_ok(c)) return SSP_OK;
+    const int nb = 1025;
+    std::vector<float2> twA(16 * 64), twB(4 * 16), twS(9 * 64);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int l = 0; l < 64; ++l) {
+            const double ang = -2.0 * M_PI * (double)(l * k1) / 1024.0;
+            twA[k1 * 64 + l] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+    for (int lb = 0; lb < 4; ++lb)
+        for (int ka = 0; ka < 16; ++ka) {
+            const double ang = -2.0 * M_PI * (double)(lb * ka) / 64.0;
+            twB[lb * 16 + ka] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+    for (int i = 0; i < 9; ++i)
+        for (int l = 0; l < 64; ++l) {
+            const int k = std::min(l + 64 * i, 512);
+            const double ang = -2.0 * M_PI * (double)k / 2048.0;
+            twS[i * 64 + l] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+    // filters sorted by their number of 4-tap steps: the 64 shortest form group 0, the rest group 1; a lane sweeps its filter from the
+    // first bin rounded down to 4, moved down (leading zero taps) where the group's step count would leave the P row
+    std::vector<float> fb((size_t)c.n_filt * nb);
+    SSP_HIP(hipMemcpy(fb.data(), p->fbank_dense.p, fb.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<int> lo(c.n_filt, 0), len(c.n_filt, 0), order(c.n_filt);
+    for (int j = 0; j < c.n_filt; ++j) {
+        int first = -1, last = -1;
+        for (int k = 0; k < nb; ++k)
+            if (fb[(size_t)j * nb + k] != 0.f) {
+                if (first < 0) first = k;
+                last = k;
+            }
+        lo[j] = first < 0 ? 0 : first;
+        len[j] = first < 0 ? 0 : last - first + 1;
+        order[j] = j;
+    }
+    auto nsteps = [&](int j) { return len[j] == 0 ? 0 : (lo[j] + len[j] - 1) / 4 - lo[j] / 4 + 1; };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return nsteps(x) < nsteps(y); });
+    const int P_END = 1028;  // floats of the P row that hold finite values (bins 0..1024 + 3 zeros)
+    int gsteps[2] = {0, 0};
+    for (int i = 0; i < c.n_filt; ++i) gsteps[i >> 6] = std::max(gsteps[i >> 6], nsteps(order[i]));
+    for (int g = 0; g < 2; ++g) gsteps[g] = (gsteps[g] + 1) & ~1;  // even (the sweep takes two steps per trip)
+    if (c.n_filt <= 64) gsteps[1] = 0;
+    std::vector<int32_t> minfo(2 * 64 * 2, 0);
+    for (int i = 0; i < 128; ++i) minfo[i * 2 + 1] = -1;
+    std::vector<char> mel((size_t)(gsteps[0] + gsteps[1]) * 64 * 16, 0);
+    for (int i = 0; i < c.n_filt; ++i) {
+        const int g = i >> 6, l = i & 63, j = order[i];
+        int start = lo[j] & ~3;
+        start = std::min(start, (P_END - 4 * gsteps[g]) & ~3);
+        if (start < 0 || start + 4 * gsteps[g] < lo[j] + len[j]) return SSP_OK;  // (a filter wider than the sweep: the generic kernel keeps the plan)
+        minfo[(g * 64 + l) * 2] = start * 4;
+        minfo[(g * 64 + l) * 2 + 1] = len[j] > 0 ? j : -1;
+        float* wt = reinterpret_cast<float*>(mel.data()) + (size_t)(g == 0 ? 0 : gsteps[0]) * 64 * 4;
+        for (int k = 0; k < len[j]; ++k) {
+            const int tap = lo[j] + k - start;
+            wt[((size_t)(tap / 4) * 64 + l) * 4 + (tap & 3)] = fb[(size_t)j * nb + lo[j] + k];
+        }
+    }
+    // (filters with no taps at all still produce log(0 + floor): they are listed with their id and zero weights)
+    for (int i = 0; i < c.n_filt; ++i)
+        if (len[order[i]] == 0) minfo[((i >> 6) * 64 + (i & 63)) * 2 + 1] = order[i];
+    const size_t table_bytes = S2K_TWB_BYTES + S2K_TWS_BYTES + mel.size();
+    if (table_bytes + (size_t)S2K_WAVES * S2K_WAVE_BYTES > 80 * 1024) return SSP_OK;  // (two workgroups per CU or not at all)
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        SSP_TRY(b.alloc(bytes));
+        SSP_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        return SSP_OK;
+    };
+    SSP_TRY(up(p->s2k_twA, twA.data(), twA.size() * sizeof(float2)));
+    SSP_TRY(up(p->s2k_twB, twB.data(), twB.size() * sizeof(float2)));
+    SSP_TRY(up(p->s2k_twS, twS.data(), twS.size() * sizeof(float2)));
+    SSP_TRY(up(p->s2k_mel, mel.data(), mel.size()));
+    SSP_TRY(up(p->s2k_minfo, minfo.data(), minfo.size() * sizeof(int32_t)));
+    p->s2k_steps = gsteps[0];
+    p->s2k_steps1 = gsteps[1];
+    p->s2k_ready = true;
+    return SSP_OK;
+}
+
+int launch_mfcc_s2k(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStream_t stream) {
+    if (n_chunks <= 0) return SSP_OK;
+    S2kArgs s{};
+    s.twA = p->s2k_twA.as<float2>();
+    s.twB = p->s2k_twB.as<float2>();
+    s.twS = p->s2k_twS.as<float2>();
+    s.mel = p->s2k_mel.as<char>();
+    s.minfo = p->s2k_minfo.as<int32_t>();
+    s.steps0 = p->s2k_steps;
+    s.steps1 = p->s2k_steps1;
+    s.n_chunks = n_chunks;
+    s.table_bytes = S2K_TWB_BYTES + S2K_TWS_BYTES + (p->s2k_steps + p->s2k_steps1) * 64 * 16;
+    SSP_TRY(p->f_counter.reserve(64));
+    s.work_counter = p->f_counter.as<int32_t>();
+    const size_t lds = (size_t)s.table_bytes + (size_t)S2K_WAVES * S2K_WAVE_BYTES;
+    const void* kfn = reinterpret_cast<const void*>(mfcc_stream2048_kernel);
+    if (lds > 64 * 1024) SSP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mfcc_stream2048_kernel, 64 * S2K_WAVES, lds));
+    const int grid = std::min((n_chunks + S2K_WAVES - 1) / S2K_WAVES, std::max(1, per_cu) * p->ctx->num_cu);
+    SSP_HIP(hipMemsetAsync(s.work_counter, 0, 64, stream));
+    if (getenv("SSP_DEBUG")) fprintf(stderr, "[ssp] mfcc stream2048: grid %d (%d per CU), lds %zu, %d + %d filterbank steps\n", grid, per_cu, lds, p->s2k_steps, p->s2k_steps1);
+    hipLaunchKernelGGL(mfcc_stream2048_kernel, dim3(grid), dim3(64 * S2K_WAVES), lds, stream, args, s);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
+}
+
+}  // namespace ssp

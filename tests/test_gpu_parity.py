@@ -212,6 +212,41 @@ def test_stream_kernel_dense_bands_plp_front_end(ssp):
         assert_feat_close(g3[u], O.mfcc_pipeline(sigs[u], cfg, w, fb, dct), what=f"plp front end utt {u}")
 
 
+@pytest.mark.parametrize("dialect", ["librosa8k", "librosa16k", "inrepo2048"])
+def test_stream2048_kernel_vs_oracle_and_generic(ssp, dialect):
+    """n_fft == 2048 dialects on the 2048-point wave-stream kernel (variant 4; first pass) + the clamp / DCT pass: MFCC_DTW.MFCC_lib's
+    librosa dialect (centred frames with reflect padding, utterance-wide top_db clamp) at two rates and utils/processing.py's MFCC with
+    frameSize 2048 (zero-padded tail, no clamp).  Ragged batch: utterances barely longer than half a window (every frame touches both
+    ends), multi-chunk utterances, odd lengths.  Against the oracle, the generic kernel, and what the library picks on its own."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    if dialect == "inrepo2048":
+        fs = 16000
+        tables = pkg.preset_inrepo(fs, 2048, 512)
+        cfg, w, fb, dct = O.inrepo_tables(fs, 2048, 512)
+    else:
+        fs = 8000 if dialect == "librosa8k" else 16000
+        tables = pkg.preset_librosa(fs, 13)
+        cfg, w, fb, dct = O.librosa_tables(fs, 13)
+    sigs = [synth_audio(u, n, fs) for u, n in enumerate([24000, 16037, 2049, 3000, 4801, 100003, 1025 + 7, 40000, 2048 * 40])]
+    g4, fseg = _run_plan(api, tables, sigs, variant=4)
+    g1, _ = _run_plan(api, tables, sigs, variant=1)
+    g0, _ = _run_plan(api, tables, sigs, variant=0)
+    assert max(np.diff(fseg.offsets)) > 128
+    worst = 0.0
+    for u, s_ in enumerate(sigs):
+        assert np.array_equal(g4[u], g0[u]), u
+        assert_feat_close(g4[u], O.mfcc_pipeline(s_, cfg, w, fb, dct), what=f"{dialect} utt {u} len {len(s_)}")
+        worst = max(worst, float(np.abs(g4[u] - g1[u]).max() / max(1.0, np.abs(g1[u]).max())))
+        single, _ = _run_plan(api, tables, [s_], variant=4)
+        assert np.array_equal(single[0], g4[u]), u
+    observe("2048-point stream kernel vs generic kernel, " + dialect, worst, FEAT_TOL)
+    assert worst <= FEAT_TOL
+    # a dialect it does not cover (deltas) answers UNSUPPORTED for an explicit request
+    with pytest.raises(Exception):
+        _run_plan(api, pkg.preset_inrepo(fs, 2048, 512, delta_order=2), sigs[:2], variant=4)
+
+
 def test_stream_kernel_matches_workgroup_kernel_and_auto(ssp):
     pkg, api = ssp
     sigs = [synth_audio(u, n, 16000) for u, n in enumerate(STREAM_LENS[:12])]
