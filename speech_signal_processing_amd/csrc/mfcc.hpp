@@ -132,6 +132,7 @@ struct ssp_mfcc_plan {
     // wave-stream kernel
     bool stream_ready = false;
     ssp::DevBuf s_dctA, s_dense;
+    bool cache_s2k_fused = false;  // (with the cached work table of a variant-4 run)
     bool s2k_ready = false;   // tables of the 2048-point wave-stream kernel (mfcc_stream2k.hip)
     int32_t s2k_steps = 0, s2k_steps1 = 0;
     ssp::DevBuf s2k_twA, s2k_twB, s2k_twS, s2k_mel, s2k_minfo;
@@ -146,6 +147,7 @@ int launch_mfcc_fast(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, in
 bool mfcc_stream_supported(const ssp_mfcc_plan* plan);  // cfg covered by the wave-stream kernel
 bool mfcc_s2k_supported(const ssp_mfcc_plan* plan);    // n_fft == 2048 plans without deltas: first pass on the 2048-point wave-stream kernel
 int build_s2k_tables(ssp_mfcc_plan* plan);
+bool mfcc_s2k_fuses(const ssp_mfcc_plan* plan, int64_t max_T, int chunk_frames);  // the first pass also clamps and takes the DCT (single-chunk utterances)
 int launch_mfcc_s2k(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, hipStream_t stream);
 bool mfcc_stream_dense(const ssp_mfcc_plan* plan);      // ... by the dense-band instance (identity DCT over <= 24 dense filterbank rows: the PLP front end)
 bool mfcc_stream_fuses_cmvn(const ssp_mfcc_plan* plan); // ... by an instance that scales the features itself (cmvn) when every utterance is one chunk

@@ -93,9 +93,10 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     p->cache_variant = p->cache_request = -1;
     if (variant == 4) {
         // 2048-point wave-stream kernel: first pass only (log filterbank rows + utterance maxima); chunks of 64 frames, one wave each
-        ch = 64;
-        split_topdb = true;
+        ch = 128;
+        split_topdb = true;  // (the rows always go through the global scratch; whether a second pass follows: cache_s2k_fused)
         whole = false;
+        p->cache_s2k_fused = mfcc_s2k_fuses(p, max_T, ch);
     } else if (variant == 3) {
         // wave-stream kernel: a chunk is a run of frames one WAVE walks alone (no LDS bound); whole utterances up to 512 frames, longer ones
         // in 512-frame chunks with a recomputed 4-frame halo.  CMVN needs the whole utterance: inside the kernel when every utterance is a
@@ -472,7 +473,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
         SSP_TRY(launch_mfcc_fast(a, plan, plan->cache_n_chunks, plan->cache_chunk_frames, s));
     else
         SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, plan->cache_waves, plan->ctx->num_cu, s));
-    if (a.lm_out)
+    if (a.lm_out && !(v == 4 && plan->cache_s2k_fused))
         SSP_TRY(launch_topdb_dct(a.lm_out, frame_seg->dev.as<int64_t>(), frame_seg->n, a.chunks, plan->cache_n_chunks, a.utt_max,
                                  plan->cfg.n_filt, plan->cfg.n_ceps, plan->dct.as<float>(),
                                  plan->cfg.top_db >= 0.f ? plan->cfg.top_db : INFINITY /* no clamp: max - inf */, d_out, s));

@@ -25,14 +25,18 @@
 namespace ssp {
 
 namespace {
-constexpr int S2K_WAVES = 4;
+#ifndef SSP_2K_WAVES
+#define SSP_2K_WAVES 12  // one 12-wave workgroup per CU = three waves per SIMD (170 VGPRs); the kernel has no barrier after the table staging
+#endif
+constexpr int S2K_WAVES = SSP_2K_WAVES;
 constexpr int ROW1 = 68;                                   // complex slots per row of the first transpose image (64 + 4 pad)
-constexpr int S2K_BUF_BYTES = (1024 + 16 * 16) * 8;        // the natural-order spectrum image is the largest user of the wave buffer
-constexpr int S2K_WAVE_BYTES = S2K_BUF_BYTES + 128 * 4;    // + the log filterbank row
+constexpr int S2K_BUF_BYTES = 16 * ROW1 * 8;               // 8.5 KiB: the first transpose image; the natural-order spectrum image (1084 slots) fits it
+constexpr int S2K_WAVE_BYTES = S2K_BUF_BYTES;
 constexpr int S2K_TWB_BYTES = 4 * 16 * 8;
+constexpr int S2K_WIN_BYTES = 2048 * 4, S2K_TWA_BYTES = 16 * 64 * 8;  // window and first-pass twiddles: workgroup-shared too (62 registers)
 constexpr int S2K_TWS_BYTES = 9 * 64 * 8;                  // split twiddles (workgroup-shared: 18 registers per lane otherwise, and a spill
                                                            // reload inside the frame loop waits behind the next frame's sample loads)
-__host__ __device__ constexpr int xpad(int k) { return k + ((k >> 6) << 4); }  // 64-point blocks 16 slots apart: their writes alternate bank halves
+__host__ __device__ constexpr int xpad(int k) { return k + ((k >> 6) << 2); }  // 64-point blocks 4 slots apart
 
 struct __attribute__((packed, aligned(4))) f2u {
     float x, y;
@@ -62,36 +66,50 @@ struct S2kArgs {
     const int32_t* minfo;  // [2][64][2] per group and lane: byte offset of the first step in the P row, filter id (-1: none)
     int32_t* work_counter;
     int32_t steps0, steps1, n_chunks, table_bytes;
+    int32_t fuse;        // every utterance of the batch is one chunk: the wave that walked it also clamps its rows and takes the DCT
+    float top_db;        // (< 0: no clamp)
 };
 
-__global__ __launch_bounds__(64 * S2K_WAVES, 2) void mfcc_stream2048_kernel(MfccArgs a, S2kArgs s) {
+__global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(MfccArgs a, S2kArgs s) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroup-shared tables: twB, split twiddles, then the piece records
+    // workgroup-shared tables: twB, split twiddles, window, first-pass twiddles, filterbank weight steps
     {
+        constexpr int NB = S2K_TWB_BYTES / 16, NS = S2K_TWS_BYTES / 16, NW = S2K_WIN_BYTES / 16, NA = S2K_TWA_BYTES / 16;
         const int n16 = s.table_bytes >> 4;
         const v4f* src_b = reinterpret_cast<const v4f*>(s.twB);
         const v4f* src_s = reinterpret_cast<const v4f*>(s.twS);
+        const v4f* src_w = reinterpret_cast<const v4f*>(a.window);
+        const v4f* src_a = reinterpret_cast<const v4f*>(s.twA);
         const v4f* src_m = reinterpret_cast<const v4f*>(s.mel);
         v4f* dst = reinterpret_cast<v4f*>(smem);
-        constexpr int NB = S2K_TWB_BYTES / 16, NS = S2K_TWS_BYTES / 16;
-        for (int i = tid; i < n16; i += 64 * S2K_WAVES) dst[i] = i < NB ? src_b[i] : (i < NB + NS ? src_s[i - NB] : src_m[i - NB - NS]);
+        for (int i = tid; i < n16; i += (int)blockDim.x) {
+            v4f v;
+            if (i < NB) v = src_b[i];
+            else if (i < NB + NS) v = src_s[i - NB];
+            else if (i < NB + NS + NW) v = src_w[i - NB - NS];
+            else if (i < NB + NS + NW + NA) v = src_a[i - NB - NS - NW];
+            else v = src_m[i - NB - NS - NW - NA];
+            dst[i] = v;
+        }
     }
+    // (in-wave finish only) the DCT matrix, [16][128] zero padded, behind the tables
+    float* dctl = reinterpret_cast<float*>(smem + s.table_bytes);
+    if (s.fuse)
+        for (int i = tid; i < 16 * 128; i += (int)blockDim.x) {
+            const int q = i >> 7, j = i & 127;
+            dctl[i] = (q < a.n_ceps && j < a.n_filt) ? a.dct[q * a.n_filt + j] : 0.f;
+        }
     __syncthreads();
     const v2f* twB = reinterpret_cast<const v2f*>(smem);
     const v2f* twS = reinterpret_cast<const v2f*>(smem + S2K_TWB_BYTES);
-    const char* melt = smem + S2K_TWB_BYTES + S2K_TWS_BYTES;
-    char* wbase = smem + s.table_bytes + wave * S2K_WAVE_BYTES;
+    const v2f* winl = reinterpret_cast<const v2f*>(smem + S2K_TWB_BYTES + S2K_TWS_BYTES) + lane;                 // pairs (w[2m], w[2m+1]), m = 64 r + l
+    const v2f* twAl = reinterpret_cast<const v2f*>(smem + S2K_TWB_BYTES + S2K_TWS_BYTES + S2K_WIN_BYTES) + lane;  // [k1][l]
+    const char* melt = smem + S2K_TWB_BYTES + S2K_TWS_BYTES + S2K_WIN_BYTES + S2K_TWA_BYTES;
+    char* wbase = smem + s.table_bytes + (s.fuse ? 16 * 128 * 4 : 0) + wave * S2K_WAVE_BYTES;
     v2f* buf = reinterpret_cast<v2f*>(wbase);
-    [[maybe_unused]] float* lm = reinterpret_cast<float*>(wbase + S2K_BUF_BYTES);
 
-    // lane-resident tables: window taps of this lane's 16 complex points, first-pass twiddles, split twiddles
-    v2f wv[16], ta[15];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) wv[r] = *reinterpret_cast<const v2f*>(a.window + 128 * r + 2 * lane);
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) ta[k1 - 1] = *reinterpret_cast<const v2f*>(&s.twA[k1 * 64 + lane]);
     const int mstart0 = s.minfo[lane * 2], mfid0 = s.minfo[lane * 2 + 1];
     const int mstart1 = s.minfo[128 + lane * 2], mfid1 = s.minfo[128 + lane * 2 + 1];
     const int hop = a.hop;
@@ -151,26 +169,14 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 2) void mfcc_stream2048_kernel(Mfcc
         for (int t = t0; t < t0 + n; ++t) {
             v2f z[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = nx[r] * wv[r];
+            for (int r = 0; r < 16; ++r) z[r] = nx[r] * winl[64 * r];
 #ifndef SSP_2K_NOPREFETCH  // (ablation, wrong results: every frame transforms the chunk's first one)
             if (t + 1 < t0 + n) load_frame(t + 1, nx);
-#endif
-#ifdef SSP_2K_NOFFT  // (ablation, wrong results): staging, log and stores only
-            lm[lane] = z[0].x + z[5].y + z[15].x;
-            lm[lane + 64] = z[1].x + z[9].y;
-            if (true) {
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int j = lane + 64 * hh;
-                    if (j < a.n_filt) a.lm_out[(size_t)(f0 + t) * a.n_filt + j] = lm[j];
-                }
-                continue;
-            }
 #endif
             // ---- pass 1: DFT16 over r (points 64 r + l), twiddle W_1024^(l k1)
             fft16(z);
 #pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], ta[k1 - 1]);
+            for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], twAl[64 * k1]);
             // ---- transpose 1: lane (k1, lb) <- points l = 4 la + lb of row k1
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) buf[k1 * ROW1 + lane] = z[k1];
@@ -272,7 +278,44 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 2) void mfcc_stream2048_kernel(Mfcc
         }
         // utterance maximum for the second pass (float order through the integer trick, as the generic kernel)
         for (int o = 32; o > 0; o >>= 1) wave_max = fmaxf(wave_max, __shfl_xor(wave_max, o));
-        if (lane == 0 && wave_max > -INFINITY) {
+        if (s.fuse) {
+            // ---- the whole utterance was this wave's: clamp at its maximum - top_db (librosa power_to_db) and DCT-II, rows re-read
+            // through L2.  Lane (q = lane & 15, part = lane >> 4): coefficient q over filters 32 part .. 32 part + 31
+            const float thr = s.top_db >= 0.f ? wave_max - s.top_db : -INFINITY;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows are written
+            const int rl = lane >> 2, part = lane & 3, nc = a.n_ceps, nf = a.n_filt;
+            // (the halves go through UNSIGNED variables: readfirstlane returns int, and an int low half with bit 31 set would
+            //  sign-extend over the high half when the address is put together)
+            const uint64_t raddr = reinterpret_cast<uint64_t>(a.lm_out + (size_t)(f0 + t0) * nf);
+            const uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)raddr);
+            const uint32_t rhi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(raddr >> 32));
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<float*>(((uint64_t)rhi << 32) | (uint64_t)rlo), 0, __builtin_amdgcn_readfirstlane(n * nf * 4), 0x00020000);
+            // 16 rows per trip: lane (row = lane >> 2, part = lane & 3) holds filters 32 part .. 32 part + 31 of its row; every coefficient
+            // is a product with the DCT row's same quarter (LDS, broadcast over the rows) summed over the four parts of a lane quad
+            for (int r0 = 0; r0 < n; r0 += 16) {
+                const int r = r0 + rl;
+                v4f l[8];
+#pragma unroll
+                for (int i4 = 0; i4 < 8; ++i4) {
+                    const int j = 32 * part + 4 * i4;
+                    l[i4] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rr, (r < n && j < nf) ? (r * nf + j) * 4 : 0x7ffffff0, 0, 1 /*glc*/));
+                    l[i4] = v4f{fmaxf(l[i4].x, thr), fmaxf(l[i4].y, thr), fmaxf(l[i4].z, thr), fmaxf(l[i4].w, thr)};
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (q >= nc) break;
+                    const v4f* dq = reinterpret_cast<const v4f*>(dctl + q * 128 + 32 * part);
+                    v4f acc = l[0] * dq[0];
+#pragma unroll
+                    for (int i4 = 1; i4 < 8; ++i4) acc = __builtin_elementwise_fma(l[i4], dq[i4], acc);
+                    float v = (acc.x + acc.y) + (acc.z + acc.w);
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    if (part == 0 && r < n) a.out[(size_t)(f0 + t0 + r) * nc + q] = v;
+                }
+            }
+        } else if (lane == 0 && wave_max > -INFINITY) {
             if (wave_max >= 0.f) atomicMax(reinterpret_cast<int*>(a.utt_max + ch.utt), __float_as_int(wave_max));
             else atomicMin(reinterpret_cast<unsigned*>(a.utt_max + ch.utt), __float_as_uint(wave_max));
         }
@@ -351,8 +394,8 @@ int build_s2k_tables(ssp_mfcc_plan* p) {
     // (filters with no taps at all still produce log(0 + floor): they are listed with their id and zero weights)
     for (int i = 0; i < c.n_filt; ++i)
         if (len[order[i]] == 0) minfo[((i >> 6) * 64 + (i & 63)) * 2 + 1] = order[i];
-    const size_t table_bytes = S2K_TWB_BYTES + S2K_TWS_BYTES + mel.size();
-    if (table_bytes + (size_t)S2K_WAVES * S2K_WAVE_BYTES > 80 * 1024) return SSP_OK;  // (two workgroups per CU or not at all)
+    const size_t table_bytes = S2K_TWB_BYTES + S2K_TWS_BYTES + S2K_WIN_BYTES + S2K_TWA_BYTES + mel.size();
+    if (table_bytes + 16 * 128 * 4 + (size_t)4 * S2K_WAVE_BYTES > 160 * 1024) return SSP_OK;  // (filterbanks whose weight steps do not fit keep the generic kernel)
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
         SSP_TRY(b.alloc(bytes));
         SSP_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
@@ -369,9 +412,17 @@ int build_s2k_tables(ssp_mfcc_plan* p) {
     return SSP_OK;
 }
 
+// every utterance of a batch is one chunk and the tables allow the in-wave finish: no second pass
+bool mfcc_s2k_fuses(const ssp_mfcc_plan* p, int64_t max_T, int chunk_frames) {
+    const ssp_mfcc_cfg& c = p->cfg;
+    return max_T <= chunk_frames && c.n_ceps <= 16 && (c.n_filt & 3) == 0 && c.n_filt <= 128 && !getenv("SSP_2K_NO_FUSE");
+}
+
 int launch_mfcc_s2k(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStream_t stream) {
     if (n_chunks <= 0) return SSP_OK;
     S2kArgs s{};
+    s.fuse = p->cache_s2k_fused ? 1 : 0;
+    s.top_db = p->cfg.top_db;
     s.twA = p->s2k_twA.as<float2>();
     s.twB = p->s2k_twB.as<float2>();
     s.twS = p->s2k_twS.as<float2>();
@@ -380,18 +431,23 @@ int launch_mfcc_s2k(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStr
     s.steps0 = p->s2k_steps;
     s.steps1 = p->s2k_steps1;
     s.n_chunks = n_chunks;
-    s.table_bytes = S2K_TWB_BYTES + S2K_TWS_BYTES + (p->s2k_steps + p->s2k_steps1) * 64 * 16;
+    s.table_bytes = S2K_TWB_BYTES + S2K_TWS_BYTES + S2K_WIN_BYTES + S2K_TWA_BYTES + (p->s2k_steps + p->s2k_steps1) * 64 * 16;
+    const size_t dct_bytes = s.fuse ? (size_t)16 * 128 * 4 : 0;
     SSP_TRY(p->f_counter.reserve(64));
     s.work_counter = p->f_counter.as<int32_t>();
-    const size_t lds = (size_t)s.table_bytes + (size_t)S2K_WAVES * S2K_WAVE_BYTES;
+    // waves per workgroup: 12 (one workgroup per CU, three waves per SIMD) where the tables leave room, else 8 or 4
+    int waves = S2K_WAVES;
+    while (waves > 4 && (size_t)s.table_bytes + dct_bytes + (size_t)waves * S2K_WAVE_BYTES > 160 * 1024) waves -= 4;
+    const size_t lds = (size_t)s.table_bytes + dct_bytes + (size_t)waves * S2K_WAVE_BYTES;
+    if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream2048): LDS footprint %zu B exceeds 160 KiB", lds);
     const void* kfn = reinterpret_cast<const void*>(mfcc_stream2048_kernel);
     if (lds > 64 * 1024) SSP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
-    SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mfcc_stream2048_kernel, 64 * S2K_WAVES, lds));
-    const int grid = std::min((n_chunks + S2K_WAVES - 1) / S2K_WAVES, std::max(1, per_cu) * p->ctx->num_cu);
+    SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mfcc_stream2048_kernel, 64 * waves, lds));
+    const int grid = std::min((n_chunks + waves - 1) / waves, std::max(1, per_cu) * p->ctx->num_cu);
     SSP_HIP(hipMemsetAsync(s.work_counter, 0, 64, stream));
     if (getenv("SSP_DEBUG")) fprintf(stderr, "[ssp] mfcc stream2048: grid %d (%d per CU), lds %zu, %d + %d filterbank steps\n", grid, per_cu, lds, p->s2k_steps, p->s2k_steps1);
-    hipLaunchKernelGGL(mfcc_stream2048_kernel, dim3(grid), dim3(64 * S2K_WAVES), lds, stream, args, s);
+    hipLaunchKernelGGL(mfcc_stream2048_kernel, dim3(grid), dim3(64 * waves), lds, stream, args, s);
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }
