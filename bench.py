@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU (configs[1]: 100k)")
     ap.add_argument("--seconds", type=float, default=3.0)
-    ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused workgroup kernel | 3 fused wave-stream kernel")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused workgroup kernel | 3 fused wave-stream kernel (| 4: the 2048-point one, librosa stage only)")
     ap.add_argument("--ref26-variant", type=int, default=0, help="kernel variant of the 26-d + CMVN stage (as --variant)")
     ap.add_argument("--inrepo-variant", type=int, default=0, help="kernel variant of the in-repo MFCC stage (as --variant)")
     ap.add_argument("--stages", default="mfcc,ref26,inrepo,librosa,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")

@@ -104,11 +104,12 @@ int ssp_mfcc_out_dim(const ssp_mfcc_cfg* cfg, int32_t* d_out);
 /* frame segments derived from sample segments with the plan's framing rule */
 int ssp_mfcc_frame_segments(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, ssp_segments** frame_seg_out);
 /* samples: float[total samples]; feats_out: float[total frames x d_out] row-major.
- * variant: 0 auto | 1 generic kernel | 4 n_fft == 2048 wave-stream kernel (no deltas: MFCC_DTW.py:28-31's librosa dialect; log filterbank
- * rows + utterance maxima in a first pass, clamp + DCT in a second) | 2 fused n_fft == 512 kernel, one workgroup per utterance chunk | 3 fused n_fft == 512 wave-stream
- * kernel (every wave walks its own chunk; DCT / delta / delta-delta on the matrix cores; needs 13 cepstra, <= 40 filters and N = 2
- * deltas: the sidekit call sites and the in-repo MFCC; utterances may start at any sample).  An explicit 2 / 3 answers
- * SSP_ERR_UNSUPPORTED when the cfg or batch is not covered; auto picks 3, then 2, then 4, then 1. */
+ * variant: 0 auto | 1 generic kernel (any cfg) | 2 fused n_fft == 512 kernel, one workgroup per utterance chunk | 3 n_fft == 512 wave-stream
+ * kernel (every wave walks its own chunk; DCT / delta / delta-delta on the matrix cores; 13 cepstra, <= 40 filters, N = 2 deltas: the
+ * sidekit call sites with or without scaling and the in-repo MFCC; a dense-band instance for the PLP front end; utterances may start at
+ * any sample) | 4 n_fft == 2048 wave-stream kernel (no deltas: MFCC_DTW.py:28-31's librosa dialect and frameSize 2048; log filterbank rows
+ * and utterance maxima, then the clamp + DCT in the same wave for single-chunk utterances or as a second pass).  An explicit 2 / 3 / 4
+ * answers SSP_ERR_UNSUPPORTED when the cfg is not covered; auto picks 3, then 2 (n_fft == 512), 4 (n_fft == 2048), then 1. */
 int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
                  const float* samples, float* feats_out, int where, int variant, float* kernel_ms);
 
