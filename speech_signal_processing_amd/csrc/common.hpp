@@ -37,6 +37,17 @@ void set_error(const char* fmt, ...);
         if (rc_ != SSP_OK) return rc_; \
     } while (0)
 
+// roctx range around a C-ABI call (tracing): a named range on the calling thread while SSP_ROCTX=1 is in the
+// environment (`rocprofv3 --marker-trace --kernel-trace -- python3 ...` then shows which entry point launched which kernels).  The roctx
+// library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so): no link-time dependency, no cost when off.
+struct TraceRange {
+    explicit TraceRange(const char* name);
+    ~TraceRange();
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+    bool on;
+};
+
 template <class T>
 static inline T ceil_div(T a, T b) {
     return (a + b - 1) / b;

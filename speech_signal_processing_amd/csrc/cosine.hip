@@ -552,6 +552,7 @@ extern "C" {
 
 int ssp_centroids(ssp_ctx* ctx, const float* X, const int32_t* labels, int64_t N, int32_t d, int32_t S, float* out, int where,
                   float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_centroids");
     SSP_TRY(use_ctx(ctx));
     if (N < 0 || d < 1 || S < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_centroids: bad shape");
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_centroids: where");
@@ -577,6 +578,7 @@ int ssp_centroids(ssp_ctx* ctx, const float* X, const int32_t* labels, int64_t N
 
 int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,
                         int32_t* argmin_out, float* min_out, int where, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_cosine_identify");
     SSP_TRY(use_ctx(ctx));
     if (N < 0 || d < 1 || S < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: bad shape N=%lld d=%d S=%d", (long long)N, d, S);
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: where");

@@ -1,7 +1,10 @@
 // Context, error reporting and segment handles of libsspgpu.so.
 #include "common.hpp"
 
+#include <dlfcn.h>
+
 #include <atomic>
+#include <cstdlib>
 
 namespace ssp {
 
@@ -12,6 +15,44 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- roctx ranges (TraceRange, common.hpp): resolved once per process, only when SSP_ROCTX is set
+namespace {
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)();
+struct Roctx {
+    roctx_push_t push = nullptr;
+    roctx_pop_t pop = nullptr;
+    Roctx() {
+        const char* e = getenv("SSP_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<roctx_push_t>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<roctx_pop_t>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+}  // namespace
+
+TraceRange::TraceRange(const char* name) : on(false) {
+    const Roctx& r = roctx();
+    if (r.push) {
+        r.push(name);
+        on = true;
+    }
+}
+TraceRange::~TraceRange() {
+    if (on) roctx().pop();
 }
 
 int segments_make(ssp_ctx* ctx, const int64_t* offsets, int64_t n, ssp_segments** out) {

@@ -183,6 +183,7 @@ using namespace ssp;
 
 extern "C" int ssp_dense_forward(ssp_ctx* ctx, const float* X, int64_t N, int32_t d_in, const float* Wt, const float* bias,
                                  int32_t units, int32_t relu, float* Y, int where, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_dense_forward");
     SSP_TRY(use_ctx(ctx));
     if (kernel_ms) *kernel_ms = 0.f;
     if (N < 0 || d_in < 1 || units < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_dense_forward: bad shape");

@@ -241,6 +241,7 @@ int ssp_dnn_destroy(ssp_dnn* dnn) {
 }
 
 int ssp_dnn_forward(ssp_dnn* dnn, const float* X, int64_t N, float* Y, int where, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_dnn_forward");
     if (!dnn) SSP_FAIL(SSP_ERR_INVALID, "ssp_dnn_forward: null handle");
     ssp_ctx* ctx = dnn->ctx;
     SSP_TRY(use_ctx(ctx));

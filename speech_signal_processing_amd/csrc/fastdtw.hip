@@ -196,6 +196,7 @@ using namespace ssp;
 
 extern "C" int ssp_fastdtw_distances(ssp_ctx* ctx, const float* xq, const ssp_segments* q_seg, const float* xt, const ssp_segments* t_seg,
                                      int32_t radius, double* dist_out, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_fastdtw_distances");
     SSP_TRY(use_ctx(ctx));
     if (kernel_ms) *kernel_ms = 0.f;
     if (!q_seg || !t_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_fastdtw_distances: null segments");

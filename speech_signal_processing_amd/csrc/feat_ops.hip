@@ -255,6 +255,7 @@ int ssp_cepstrum(ssp_ctx* ctx, const float* X, int64_t n_rows, int32_t n_bins, c
 
 int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim, int32_t N, float* out,
               int where, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_delta");
     SSP_TRY(use_ctx(ctx));
     if (!frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_delta: null segments");
     if (N < 1) SSP_FAIL(SSP_ERR_INVALID, "N must be an integer >= 1");  // GMM_UBM.py:59-60
@@ -291,6 +292,7 @@ int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, i
 
 int ssp_cmvn(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, int32_t dim, float* out, int where,
              float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_cmvn");
     SSP_TRY(use_ctx(ctx));
     if (!frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_cmvn: null segments");
     if (dim < 1 || dim > 4096) SSP_FAIL(SSP_ERR_INVALID, "ssp_cmvn: dim out of range");

@@ -657,6 +657,7 @@ extern "C" {
 
 int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const double* weights, const double* means,
                  const double* covars, int32_t has_ubm, ssp_gmm** out) {
+    ssp::TraceRange trace_("ssp_gmm_pack");
     if (!out) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_pack: null out");
     *out = nullptr;
     SSP_TRY(use_ctx(ctx));
@@ -927,6 +928,7 @@ extern "C" {
 
 int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_seg, float* loglik_out,
                   float* scores_out, int32_t* argmax_out, int where, int precision, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_gmm_score");
     if (!gmm || !frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: null handle");
     ssp_ctx* ctx = gmm->ctx;
     SSP_TRY(use_ctx(ctx));

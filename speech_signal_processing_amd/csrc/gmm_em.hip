@@ -348,6 +348,7 @@ using namespace ssp;
 extern "C" int ssp_gmm_em_stats(ssp_ctx* ctx, int32_t K, int32_t D, const double* weights, const double* means,
                                 const double* covars, const float* feats, int64_t n_frames, double* nk_out, double* sx_out,
                                 double* sxx_out, double* loglik_sum_out, int where, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_gmm_em_stats");
     SSP_TRY(use_ctx(ctx));
     if (kernel_ms) *kernel_ms = 0.f;
     if (K < 1 || D < 1 || !weights || !means || !covars || !nk_out || !sx_out || !sxx_out || !loglik_sum_out)

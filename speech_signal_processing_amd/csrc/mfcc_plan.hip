@@ -210,6 +210,7 @@ int ssp_mfcc_out_dim(const ssp_mfcc_cfg* cfg, int32_t* d_out) {
 
 int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* window, const float* fbank,
                          const float* dct, ssp_mfcc_plan** out) {
+    ssp::TraceRange trace_("ssp_mfcc_plan_create");
     if (!out) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_plan_create: null out");
     *out = nullptr;
     SSP_TRY(use_ctx(ctx));
@@ -386,6 +387,7 @@ int ssp_mfcc_frame_segments(ssp_mfcc_plan* plan, const ssp_segments* sample_seg,
 
 int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
                  const float* samples, float* feats_out, int where, int variant, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_mfcc_run");
     if (!plan || !sample_seg || !frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: null handle");
     SSP_TRY(use_ctx(plan->ctx));
     if (sample_seg->n != frame_seg->n) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: sample/frame segment counts differ");

@@ -133,6 +133,7 @@ using namespace ssp;
 
 extern "C" int ssp_plp_post(ssp_ctx* ctx, const float* logspec, const ssp_segments* frame_seg, int32_t n_bands, float fmax_hz,
                             int32_t plp_order, int32_t rasta, float lift, float* ceps_out, int where, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_plp_post");
     SSP_TRY(use_ctx(ctx));
     if (kernel_ms) *kernel_ms = 0.f;
     if (!frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_plp_post: null segments");
