@@ -969,6 +969,17 @@ def test_nn_model_test_enroll_eval(ssp):
         m.enroll(Xtr[lab_tr == s], "spk%d" % s)
     assert m.eval(Xva[lab_va == 1][0]) == "spk1"
     assert m.eval(-m.d_vector["spk0"] - m.d_vector["spk1"] - m.d_vector["spk2"]) is None  # every distance >= 1
+    # the scan rule of nn_model.eval (d_vector.py:346-361) against its float64 restatement on many targets: matches, no-match cases
+    # (every distance >= 1), low-dimensional targets where several enrolments are close, and an exact duplicate enrolment (first wins)
+    from oracle import ref_cpu as O
+    for s in range(3, S):
+        m.enroll(Xtr[lab_tr == s], "spk%d" % s)
+    m.enroll(Xtr[lab_tr == 4], "spk4_again")
+    names = list(m.d_vector.keys())
+    vecs = np.stack([np.asarray(m.d_vector[n], dtype=np.float64) for n in names])
+    targets = [Xva[i] for i in range(40)] + [-Xva[i] for i in range(5)] + [rng.standard_normal(d).astype(np.float32) for _ in range(15)]
+    for t_ in targets:
+        assert m.eval(t_) == O.eval_rule(t_, names, vecs)
 
 
 def test_cosine_nan_rules_match_scipy_and_the_reference_scan(ssp):
