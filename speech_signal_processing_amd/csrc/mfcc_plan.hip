@@ -93,17 +93,40 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     p->cache_variant = p->cache_request = -1;
     if (variant == 4) {
         // 2048-point wave-stream kernel: first pass only (log filterbank rows + utterance maxima); chunks of 64 frames, one wave each
+        // (small batches: shorter chunks, so that a single utterance is spread over many waves instead of walked by one; they always
+        //  take the second-pass kernel for the clamp + DCT: the same bits for an utterance alone and in any small batch)
         ch = 128;
+        bool s2k_small = false;
+        {
+            const int64_t total = fseg->host.back() - fseg->host.front(), want = (int64_t)p->ctx->num_cu * 12;
+            if ((total + ch - 1) / ch < want) {
+                ch = (int)std::min<int64_t>(128, std::max<int64_t>(4, (total + want - 1) / want));
+                s2k_small = true;
+            }
+        }
         split_topdb = true;  // (the rows always go through the global scratch; whether a second pass follows: cache_s2k_fused)
         whole = false;
-        p->cache_s2k_fused = mfcc_s2k_fuses(p, max_T, ch);
+        p->cache_s2k_fused = !s2k_small && mfcc_s2k_fuses(p, max_T, ch);
     } else if (variant == 3) {
         // wave-stream kernel: a chunk is a run of frames one WAVE walks alone (no LDS bound); whole utterances up to 512 frames, longer ones
         // in 512-frame chunks with a recomputed 4-frame halo.  CMVN needs the whole utterance: inside the kernel when every utterance is a
         // single chunk (and the dialect has a scaling instance), the stand-alone kernel afterwards otherwise.
         // (utterances may start at any sample: the 16-byte LDS-DMA loads of the sample stage only need dword-aligned addresses)
         ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
-        split_cmvn = c.cmvn != 0 && !(max_T <= 512 && mfcc_stream_fuses_cmvn(p));
+        bool small_batch = false;
+        {
+            // small batches (the reference calls these functions one utterance at a time): a chunk per wave would leave most of the
+            // machine idle, so utterances are cut into shorter chunks (multiples of 16 frames, >= 32; each recomputes a 4-frame halo)
+            // until there are about 12 waves' worth per CU.  The values do not depend on the cut (mfcc_stream.hip: H)
+            const int64_t total = fseg->host.back() - fseg->host.front(), want = (int64_t)p->ctx->num_cu * 12;
+            if ((total + ch - 1) / ch < want) {
+                const int64_t per = (total + want - 1) / want;
+                ch = (int)std::min<int64_t>(ch, std::max<int64_t>(32, (per + 15) / 16 * 16));
+                small_batch = true;
+            }
+        }
+        // (small batches always scale with the stand-alone kernel: an utterance then gets the same bits alone and in any small batch)
+        split_cmvn = c.cmvn != 0 && !(!small_batch && max_T <= ch && mfcc_stream_fuses_cmvn(p));
         whole = false;
     } else if (variant == 2) {
         // persistent workgroups with a fixed LDS footprint; a chunk's cepstra (+ delta halo) and a block of output rows

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         const int64_t f0 = a.frame_off[ch.utt];
         const int T = __builtin_amdgcn_readfirstlane((int)(a.frame_off[ch.utt + 1] - f0));
         const int t0 = __builtin_amdgcn_readfirstlane(ch.t0), n = __builtin_amdgcn_readfirstlane(ch.n);
-        const int H = 2 * dord;
+        const int H = dord > 0 ? 4 : 0;  // (a multiple of 4 for every delta order: a frame meets the same 4-frame k-groups of the time
+                                         // products wherever its chunk starts, so the values do not depend on how an utterance is cut)
         const int ta = max(t0 - H, 0), tb = min(t0 + n + H, T);
         const int R = tb - ta;                     // frames computed (relative index r = t - ta)
         const int nquads = (R + 3) >> 2;

@@ -436,7 +436,7 @@ int launch_mfcc_s2k(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStr
     SSP_TRY(p->f_counter.reserve(64));
     s.work_counter = p->f_counter.as<int32_t>();
     // waves per workgroup: 12 (one workgroup per CU, three waves per SIMD) where the tables leave room, else 8 or 4
-    int waves = S2K_WAVES;
+    int waves = n_chunks >= p->ctx->num_cu * S2K_WAVES ? S2K_WAVES : 4;  // (small batches: 4-wave workgroups spread the chunks over more CUs)
     while (waves > 4 && (size_t)s.table_bytes + dct_bytes + (size_t)waves * S2K_WAVE_BYTES > 160 * 1024) waves -= 4;
     const size_t lds = (size_t)s.table_bytes + dct_bytes + (size_t)waves * S2K_WAVE_BYTES;
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream2048): LDS footprint %zu B exceeds 160 KiB", lds);

@@ -162,11 +162,17 @@ def test_stream_kernel_scales_single_chunk_utterances_itself(ssp, delta_order):
     workgroup kernel's fused scaling and the stand-alone kernel; 1- and 2-frame utterances (a zero deviation scales by 1)."""
     pkg, api = ssp
     from oracle import ref_cpu as O
+    # (the kernel scales by itself only when the batch is large enough to fill the machine with whole-utterance chunks: 14 distinct
+    #  signals repeated to 4200 utterances; small batches are cut into short chunks and scaled by the stand-alone kernel)
     lens = [48000, 16000 + 37, 400, 560, 719, 1040, 3000, 4801, 8000, 20003, 82000, 81999, 405, 880]
-    sigs = [synth_audio(u, n, 16000) for u, n in enumerate(lens)]
+    base = [synth_audio(u, n, 16000) for u, n in enumerate(lens)]
+    sigs = base * 300
     tables = pkg.preset_sidekit(delta_order=delta_order, cmvn=1)
     got, fseg = _run_plan(api, tables, sigs, variant=3)
     assert max(np.diff(fseg.offsets)) <= 512
+    for u in range(len(base), len(sigs)):
+        assert np.array_equal(got[u], got[u % len(base)]), u   # position independent
+    got, sigs = got[:len(base)], base
     cfg, w, fb, dct = O.sidekit_tables(delta_order=delta_order, cmvn=1)
     g2, _ = _run_plan(api, tables, sigs, variant=2)
     raw, _ = _run_plan(api, pkg.preset_sidekit(delta_order=delta_order, cmvn=0), sigs, variant=3)
@@ -176,14 +182,18 @@ def test_stream_kernel_scales_single_chunk_utterances_itself(ssp, delta_order):
         assert np.abs(got[u] - g2[u]).max() <= 1e-4 * max(1.0, np.abs(g2[u]).max())
         alone = np.asarray(api.cmvn_features(ctx, raw[u], api.Segments.from_lengths(ctx, [raw[u].shape[0]])))
         assert np.abs(got[u] - alone).max() <= 1e-4 * max(1.0, np.abs(alone).max())
-        single, _ = _run_plan(api, tables, [s], variant=3)
-        assert np.array_equal(single[0], got[u]), u   # position independent
-    # one utterance longer than a chunk: the whole batch goes through the stand-alone scaling kernel, same values
+    # small batches (an utterance alone, a handful, one longer than a chunk): the stand-alone scaling kernel behind short chunks; an
+    # utterance gets the same bits alone and in any small batch, and the large batch's values to rounding
+    small, _ = _run_plan(api, tables, sigs, variant=3)
     long_sigs = sigs[:4] + [synth_audio(77, 100000, 16000)]
     gl, fl = _run_plan(api, tables, long_sigs, variant=3)
     assert max(np.diff(fl.offsets)) > 512
-    for u in range(4):
-        assert np.abs(gl[u] - got[u]).max() <= 1e-4 * max(1.0, np.abs(got[u]).max())
+    for u, s in enumerate(sigs):
+        single, _ = _run_plan(api, tables, [s], variant=3)
+        assert np.array_equal(single[0], small[u]), u
+        assert np.abs(small[u] - got[u]).max() <= 1e-4 * max(1.0, np.abs(got[u]).max())
+        if u < 4:
+            assert np.array_equal(gl[u], small[u]), u
 
 
 def test_stream_kernel_dense_bands_plp_front_end(ssp):
@@ -240,18 +250,23 @@ def test_stream2048_kernel_vs_oracle_and_generic(ssp, dialect):
         worst = max(worst, float(np.abs(g4[u] - g1[u]).max() / max(1.0, np.abs(g1[u]).max())))
     observe("2048-point stream kernel vs generic kernel, " + dialect, worst, FEAT_TOL)
     assert worst <= FEAT_TOL
-    # a batch whose utterances are all single chunks (<= 128 frames): the wave that walked an utterance also clamps its rows at the
-    # utterance maximum and takes the DCT (no second pass) — same values
-    short = [s_ for s_ in sigs if len(s_) <= 60000] + [synth_audio(31, 65000, fs)]
+    # a LARGE batch whose utterances are all single chunks (<= 128 frames; 3200 of them, enough whole-utterance chunks to fill the
+    # machine): the wave that walked an utterance also clamps its rows at the utterance maximum and takes the DCT (no second pass) —
+    # same values; small batches are cut into short chunks and always take the second-pass kernel (same bits alone and in a small batch)
+    base = [synth_audio(40 + u, n, fs) for u, n in enumerate([24000, 16037, 2049, 3000, 4801, 1025 + 7, 8000, 65000])]
+    short = base * 400
     h4, hseg = _run_plan(api, tables, short, variant=4)
-    h1, _ = _run_plan(api, tables, short, variant=1)
     assert max(np.diff(hseg.offsets)) <= 128
-    for u, s_ in enumerate(short):
+    for u in range(len(base), len(short), 97):
+        assert np.array_equal(h4[u], h4[u % len(base)]), u   # position independent
+    s4, _ = _run_plan(api, tables, base, variant=4)
+    h1, _ = _run_plan(api, tables, base, variant=1)
+    for u, s_ in enumerate(base):
         assert_feat_close(h4[u], O.mfcc_pipeline(s_, cfg, w, fb, dct), what=f"{dialect} single-chunk utt {u} len {len(s_)}")
         assert np.abs(h4[u] - h1[u]).max() <= FEAT_TOL * max(1.0, np.abs(h1[u]).max())
+        assert np.abs(h4[u] - s4[u]).max() <= FEAT_TOL * max(1.0, np.abs(s4[u]).max())
         single, _ = _run_plan(api, tables, [s_], variant=4)
-        assert np.array_equal(single[0], h4[u]), u   # position independent (in a batch with longer utterances the clamp + DCT run as the
-                                                     # second-pass kernel, whose summation order differs in the last bit)
+        assert np.array_equal(single[0], s4[u]), u
     # a dialect it does not cover (deltas) answers UNSUPPORTED for an explicit request
     with pytest.raises(Exception):
         _run_plan(api, pkg.preset_inrepo(fs, 2048, 512, delta_order=2), sigs[:2], variant=4)
