@@ -152,5 +152,5 @@ int launch_mfcc_s2k(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, hip
 bool mfcc_stream_dense(const ssp_mfcc_plan* plan);      // ... by the dense-band instance (identity DCT over <= 24 dense filterbank rows: the PLP front end)
 bool mfcc_stream_fuses_cmvn(const ssp_mfcc_plan* plan); // ... by an instance that scales the features itself (cmvn) when every utterance is one chunk
 int build_stream_tables(ssp_mfcc_plan* plan);
-int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, hipStream_t stream);
+int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* plan, int n_chunks, hipStream_t stream, bool dry_run = false);
 }  // namespace ssp

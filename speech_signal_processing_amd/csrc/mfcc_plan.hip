@@ -128,6 +128,14 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         // (small batches always scale with the stand-alone kernel: an utterance then gets the same bits alone and in any small batch)
         split_cmvn = c.cmvn != 0 && !(!small_batch && max_T <= ch && mfcc_stream_fuses_cmvn(p));
         whole = false;
+        {
+            // mfcc_stream_supported() is wider than the set of compiled instances (e.g. win <= 416 with hop > 160 needs the two-per-CU
+            // LDS layout, which only some dialects have): ask the launcher itself; auto mode then falls back to the workgroup kernel
+            MfccArgs probe = p->args;
+            probe.cmvn = (c.cmvn != 0 && !split_cmvn) ? 1 : 0;
+            const int prc = launch_mfcc_stream(probe, p, 0, nullptr, /*dry_run=*/true);
+            if (prc != SSP_OK) return prc;
+        }
     } else if (variant == 2) {
         // persistent workgroups with a fixed LDS footprint; a chunk's cepstra (+ delta halo) and a block of output rows
         // share the wave regions in the delta tail, which bounds the chunk: whole utterances up to 512 frames, else chunks

@@ -675,8 +675,10 @@ int build_stream_tables(ssp_mfcc_plan* p) {
     return SSP_OK;
 }
 
-int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStream_t stream) {
-    if (n_chunks <= 0) return SSP_OK;
+// dry_run: only answers whether an instance of the kernel exists for (cfg, in-kernel scaling) — the work-table builder asks before it
+// commits a batch to this kernel, so that auto mode falls back to the workgroup kernel instead of failing at launch
+int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStream_t stream, bool dry_run) {
+    if (n_chunks <= 0 && !dry_run) return SSP_OK;
     FastArgs f = p->fast;
     const ssp_mfcc_cfg& c = p->cfg;
     StreamArgs sa{};
@@ -693,8 +695,10 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
     sa.wave_bytes = 4 * ZFRAME + sa.stage_bytes + RING_FRAMES * RING_ROW;
     sa.table_bytes = 0;
     sa.n_chunks = n_chunks;
-    SSP_TRY(p->f_counter.reserve(64));
-    sa.work_counter = p->f_counter.as<int32_t>();
+    if (!dry_run) {
+        SSP_TRY(p->f_counter.reserve(64));
+        sa.work_counter = p->f_counter.as<int32_t>();
+    }
     size_t lds = (size_t)sa.table_bytes + (size_t)STREAM_WAVES * sa.wave_bytes;
     if (const char* e = getenv("SSP_MFCC_LDS_PAD")) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(e));  // diagnostic: caps the workgroups per CU
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): LDS footprint %zu B exceeds 160 KiB", lds);
@@ -710,6 +714,8 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
     bool launched = false;
 #define SSP_STREAM_CASE(NZ_, PW_, PR_, MV_, KS_, OCC_) SSP_STREAM_CASE_CM(NZ_, PW_, PR_, MV_, KS_, OCC_, 0)
 #define SSP_STREAM_CASE_CM(NZ_, PW_, PR_, MV_, KS_, OCC_, CM_)                                                        \
+    if (!launched && dry_run && nz == NZ_ && pw == PW_ && pr == PR_ && f.melv == MV_ && KS == KS_ && occ == OCC_ && cm == CM_) \
+        launched = true;                                                                                                \
     if (!launched && nz == NZ_ && pw == PW_ && pr == PR_ && f.melv == MV_ && KS == KS_ && occ == OCC_ && cm == CM_) {   \
         auto* kfn = f.mel_ns <= 2 ? mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 2, OCC_, CM_>                        \
                                   : mfcc_stream512_kernel<NZ_, PW_, PR_, MV_, KS_, 4, OCC_, CM_>;                       \
@@ -750,6 +756,7 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
 #undef SSP_STREAM_CASE
 #undef SSP_STREAM_CASE_CM
     if (!launched) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): no kernel instance for this cfg");
+    if (dry_run) return SSP_OK;
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }

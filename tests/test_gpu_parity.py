@@ -323,6 +323,44 @@ def test_stream_kernel_other_geometries(ssp, nwin, shift):
         _run_plan(api, pkg.preset_sidekit(nceps=20), [synth_audio(0, 16000, 16000)], variant=3)
 
 
+@pytest.mark.parametrize("shift", [0.0125, 0.016])
+@pytest.mark.parametrize("cmvn", [0, 1])
+def test_auto_mode_falls_back_where_the_stream_kernel_has_no_instance(ssp, shift, cmvn):
+    """win <= 416 with hop > 160 needs the two-per-CU LDS layout, for which only some dialects have a stream instance: auto mode
+    (variant 0) must answer through the workgroup kernel instead of failing at launch, also on the second (cached) call."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    sigs = [synth_audio(u, n, 16000) for u, n in enumerate([16000, 48000, 4444, 700])]
+    tables = pkg.preset_sidekit(nwin=0.025, shift=shift, delta_order=2, cmvn=cmvn)
+    cfg, w, fb, dct = O.sidekit_tables(nwin=0.025, shift=shift, delta_order=2, cmvn=cmvn)
+    for _ in range(2):
+        got, _ = _run_plan(api, tables, sigs, variant=0)
+        for u, s in enumerate(sigs):
+            assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"auto {shift} cmvn {cmvn} utt {u}")
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_partially_silent_utterance_nonfinite_pattern(ssp, variant):
+    """Digital silence inside an utterance: ln 0 = -inf in the silent frames (sidekit has no floor).  The reference's delta touches
+    frames within +-2 (delta) / +-4 (delta-delta) of a non-finite cepstrum; every frame outside that reach must stay finite and
+    equal to the oracle, and every frame the oracle marks non-finite must be non-finite here."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    x = synth_audio(9, 16000, 16000).copy()
+    x[6000:6000 + 160 * 10 + 400] = 0.0  # >= 10 wholly silent frames
+    tables = pkg.preset_sidekit(delta_order=2)
+    got, _ = _run_plan(api, tables, [x, synth_audio(10, 8000, 16000)], variant=variant)
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=2)
+    with np.errstate(all="ignore"):
+        ref = O.mfcc_pipeline(x, cfg, w, fb, dct)
+    bad_ref = ~np.isfinite(ref)
+    bad_got = ~np.isfinite(got[0])
+    assert bad_ref.any() and (bad_got | ~bad_ref).all(), "a frame the reference makes non-finite came out finite"
+    assert (bad_got == bad_ref).all(), "non-finite pattern differs from the reference: %d vs %d entries" % (bad_got.sum(), bad_ref.sum())
+    ok = ~bad_ref
+    assert np.abs(got[0][ok] - ref[ok]).max() <= 1e-4 * max(1.0, np.abs(ref[ok]).max())
+
+
 def test_sidekit_shape_fact(ssp):
     """report/final.pdf IV-B-2: 1 s @ 16 kHz -> 98 x 13."""
     pkg, api = ssp
