@@ -49,11 +49,26 @@ __device__ __forceinline__ void dft4(v2f& a, v2f& b, v2f& c, v2f& d) {
     d = sub_neg_i(t1, u);
 }
 
-// forward 16-point DFT, natural order in, natural order out (4 x 4 Cooley-Tukey, constant twiddles)
-__device__ __forceinline__ void fft16(v2f (&z)[16]) {
+// dft4 whose fourth input is known to be zero (t2 = u = b): 6 packed instructions instead of 8
+__device__ __forceinline__ void dft4_d0(v2f& a, v2f& b, v2f& c, v2f& d) {
+    const v2f t0 = a + c, t1 = a - c, u = b;
+    a = t0 + u;
+    c = t0 - u;
+    b = add_neg_i(t1, u);
+    d = sub_neg_i(t1, u);
+}
+
+// forward 16-point DFT, natural order in, natural order out (4 x 4 Cooley-Tukey, constant twiddles).
+// TAIL0: inputs 13, 14, 15 are known to be zero (a 400-sample window in a 512-point frame) — their butterflies lose an operand
+template <bool TAIL0 = false>
+__device__ __forceinline__ void fft16_in(v2f (&z)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+    dft4(z[0], z[4], z[8], z[12]);
 #pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) dft4(z[n2], z[n2 + 4], z[n2 + 8], z[n2 + 12]);  // -> a[k1][n2] at z[n2 + 4 k1]
+    for (int n2 = 1; n2 < 4; ++n2) {  // -> a[k1][n2] at z[n2 + 4 k1]
+        if (TAIL0) dft4_d0(z[n2], z[n2 + 4], z[n2 + 8], z[n2 + 12]);
+        else dft4(z[n2], z[n2 + 4], z[n2 + 8], z[n2 + 12]);
+    }
     // twiddle W16^(n2 k1)
     z[5] = cmulc(z[5], C1, -S1);                  // n2=1,k1=1: W^1
     z[6] = cmulc(z[6], R, -R);                    // n2=2,k1=1: W^2
@@ -74,6 +89,7 @@ __device__ __forceinline__ void fft16(v2f (&z)[16]) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[i] = o[i];
 }
+__device__ __forceinline__ void fft16(v2f (&z)[16]) { fft16_in<false>(z); }
 
 // forward 8-point DFT, natural order in and out (even / odd 4-point transforms, X[k] = E[k] + W8^k O[k], X[k+4] = E[k] - W8^k O[k])
 __device__ __forceinline__ void fft8(v2f (&z)[8]) {

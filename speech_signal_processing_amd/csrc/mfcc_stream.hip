@@ -28,6 +28,8 @@ namespace ssp {
 
 namespace {
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const volatile v2f* lds_cv2f_t;
+typedef __attribute__((address_space(3))) const volatile float* lds_cvf_t;
 constexpr int ZROW = 128;          // bytes per 16-complex row of a frame's transpose image (chunks XOR-swizzled, see mfcc_fast.hip)
 constexpr int ZFRAME = 16 * ZROW;  // 2048 B per frame
 constexpr int LM_OFF = 1792;       // log-mel row of frame g sits at LM_OFF - 64 g inside its image (behind the P row)
@@ -75,16 +77,16 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
 #pragma unroll
     for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
     // Register diet (168 VGPRs = three waves per SIMD, and 52 KiB of LDS per workgroup = three workgroups per CU, leave no room for
-    // tables anywhere else): twiddles W_256^(k1 j) are resident for k1 <= 8 and W^(k1 j) = W^((k1 - 8) j) W^(8 j) above; split twiddles
-    // W_512^(j + 16 i) for i < 4 and times W_8 above; that pays for the DCT matrix as resident MFMA A operand
+    // tables anywhere else): twiddles W_256^(k1 j) are resident for k1 <= NTW and W^(k1 j) = W^((k1 - 8) j) W^(8 j) above; split twiddles
+    // W_512^(j + 16 i) resident for i < NWP and times W_8 above; that pays for the DCT matrix as resident MFMA A operand
     // (lane (ceps = j, kq = g), k-step s <-> filter KS g + s)
 #ifndef SSP_STREAM_NTW
-#define SSP_STREAM_NTW 10  // resident twiddles W_256^(k1 j), k1 <= NTW (the largest sets that leave no spill inside the loop; a spill
+#define SSP_STREAM_NTW 13  // resident twiddles W_256^(k1 j), k1 <= NTW (the largest sets that leave no spill inside the loop; a spill
 #endif                     // reload there waits on vmcnt behind the sample DMA and exposes its whole latency every quad)
 #ifndef SSP_STREAM_NWP
 #define SSP_STREAM_NWP 8   // resident split twiddles
 #endif
-    constexpr int NTW = OCC >= 3 ? SSP_STREAM_NTW : 15, NWP = OCC >= 3 ? SSP_STREAM_NWP : 8;
+    constexpr int NTW = OCC >= 3 ? ((MELV <= 3 && NS <= 2) ? SSP_STREAM_NTW : ((MELV >= 4 && NS >= 4) ? 8 : 10)) : 15, NWP = OCC >= 3 ? SSP_STREAM_NWP : 8;
     v2f twr[NTW], wpr[NWP];
 #pragma unroll
     for (int k1 = 1; k1 <= NTW; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
@@ -191,353 +193,458 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         int stores_pending = 0;  // buffer stores issued behind the DMA that is waited for at the top of the next iteration
         double cs1[CM ? 3 : 1] = {}, cs2[CM ? 3 : 1] = {};  // CM: sums of this lane's stored values per block (column = lane & 15)
 
-        for (int q = 0; q < Q; ++q) {
-            if (q < nquads) {
-                v2f z[16];
-                v2f pf[NZ];
-                v2f pm[PRE ? NZ : 1];
-                // the quad's DMA has landed; the stores of a preceding step were issued behind it and may still be in flight
+        // ---- the phases of one quad (lambdas: the dense-band instance runs them in sequence, every other instance software-pipelined)
+        // (z / pf / pm are declared inside the loop bodies: declared out here they would be loop-carried through the wave-uniform branches
+        //  of the pipelined loop and stay live — 32 + 52 registers — across the back phases)
+        typedef v2f zarr_t[16];
+        typedef v2f pfarr_t[NZ];
+        typedef float pmarr_t[PRE ? NZ : 1];  // x[e - 1], the pre-emphasis partner of the pair (x[e], x[e + 1])
+        constexpr int NH = (NZ + 1) / 2;
+        // the quad's DMA has landed; the stores of a preceding step were issued behind it and may still be in flight
+        auto wait_dma = [&]() {
 #ifndef SSP_S_NOWAIT  // (ablation, wrong results: what the wait for the sample DMA costs)
-                if (stores_pending == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (stores_pending == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (stores_pending == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (stores_pending == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            if (stores_pending == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (stores_pending == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (stores_pending == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (stores_pending == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
 #endif
-                stores_pending = 0;
-                // the stage comes to registers in two halves (the first is windowed into z while the second is in flight: all of it
-                // at once is the register peak of the kernel)
-                constexpr int NH = (NZ + 1) / 2;
-                const float* sp = stage + g * hop + 2 * j;
+            stores_pending = 0;
+        };
+        // the stage comes to registers in two halves (the first is windowed into z while the second is in flight: all of it at once is
+        // the register peak of the kernel)
+        auto stage_read_a = [&](pfarr_t& pf, pmarr_t& pm) {
+            const uint32_t sp = stage_lds + (g * hop + 2 * j) * 4;  // (LDS byte address: a volatile access through a generic pointer would be a flat load)
 #pragma unroll
-                for (int n1 = 0; n1 < NH; ++n1) {
-                    pf[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1);
-                    if (PRE) pm[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1 - 2);
+            for (int n1 = 0; n1 < NH; ++n1) {
+                // (volatile: one ds_read_b64 + one ds_read_b32 per row, 2 + 2 LDS cycles.  Left to itself the compiler merges the pair
+                //  with its pre-emphasis partner into a ds_read2_b64 — 8 LDS cycles — and spends an address VGPR + add per row on it)
+                pf[n1] = *(lds_cv2f_t)(uintptr_t)(sp + 128 * n1);
+                if (PRE) pm[n1] = *(lds_cvf_t)(uintptr_t)(sp + 128 * n1 - 4);
+            }
+        };
+        auto stage_read_b = [&](pfarr_t& pf, pmarr_t& pm) {
+            const uint32_t sp = stage_lds + (g * hop + 2 * j) * 4;
+#pragma unroll
+            for (int n1 = NH; n1 < NZ; ++n1) {
+                pf[n1] = *(lds_cv2f_t)(uintptr_t)(sp + 128 * n1);
+                if (PRE) pm[n1] = *(lds_cvf_t)(uintptr_t)(sp + 128 * n1 - 4);
+            }
+        };
+        auto window_a = [&](zarr_t& z, pfarr_t& pf, pmarr_t& pm) {
+            if (PRE) pm[0] = (j == 0) ? pf[0].x : pm[0];     // y[0] = x[0] - a x[0]
+#pragma unroll
+            for (int n1 = 0; n1 < NH; ++n1) {
+                v2f y = pf[n1];
+                if (PRE) {
+                    const float xm1 = pm[n1], x0 = y.x, x1 = y.y;
+                    y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (PRE) pm[0].y = (j == 0) ? pf[0].x : pm[0].y;     // y[0] = x[0] - a x[0]
+                z[n1] = y * wreg[n1];
+            }
+        };
+        auto window_b = [&](zarr_t& z, pfarr_t& pf, pmarr_t& pm) {
 #pragma unroll
-                for (int n1 = 0; n1 < NH; ++n1) {
-                    v2f y = pf[n1];
+            for (int n1 = NH; n1 < 16; ++n1) {
+                if (n1 < NZ) {
+                    v2f y = pf[n1 < NZ ? n1 : 0];
                     if (PRE) {
-                        const float xm1 = pm[n1].y, x0 = y.x, x1 = y.y;
+                        const float xm1 = pm[n1 < NZ ? n1 : 0], x0 = y.x, x1 = y.y;
                         y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
                     }
-                    z[n1] = y * wreg[n1];
+                    z[n1] = y * wreg[n1 < NZ ? n1 : 0];
+                } else {
+                    z[n1] = v2f{0.f, 0.f};
                 }
+            }
+        };
+        // FFT16 over n1, twiddle W_256^(n2 k1), transpose through LDS, FFT16 over n2, split step -> P row of the frame's image
+        auto fft_front = [&](zarr_t& z) {
+            fft16_in<(NZ <= 13)>(z);  // a 400-sample window leaves rows 13..15 of the 16 x 32 sample matrix zero
 #pragma unroll
-                for (int n1 = NH; n1 < NZ; ++n1) {
-                    pf[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1);
-                    if (PRE) pm[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1 - 2);
+            for (int k1 = 1; k1 < 16; ++k1) {
+                if (k1 <= NTW) {
+                    z[k1] = cmul(z[k1], twr[(k1 - 1) % NTW]);
+                } else {  // W^(k1 j) = W^((k1 - 8) j) W^(8 j)
+                    z[k1] = cmul(cmul(z[k1], twr[(k1 - 9) % NTW]), twr[7]);
                 }
+            }
+            // ---- transpose through LDS (rows of 128 B, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
+            char* zf = zbuf + g * ZFRAME;
+            {
+                int wb0 = ((j >> 1) << 4) | ((j & 1) << 3);
+                asm volatile("" : "+v"(wb0));
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    char* wp = zf + (wb0 ^ (m << 4));
+                    *reinterpret_cast<v2f*>(wp + (2 * m) * ZROW) = z[2 * m];
+                    *reinterpret_cast<v2f*>(wp + (2 * m + 1) * ZROW) = z[2 * m + 1];
+                }
+                int rb0 = j * ZROW + (((j >> 1) & 7) << 4);
+                asm volatile("" : "+v"(rb0));
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const v4f r = *reinterpret_cast<const v4f*>(zf + (rb0 ^ (c << 4)));
+                    z[2 * c] = v2f{r.x, r.y};
+                    z[2 * c + 1] = v2f{r.z, r.w};
+                }
+            }
+            // ---- FFT16 over n2: lane j = k1, register = k2
+            fft16(z);
+            // ---- split step of the real FFT (partners from lane 16 - j), power / magnitude -> P row
+            {
+                float* P = reinterpret_cast<float*>(zf);
+                float* Pm = P + 144 - j;
+                float pa_prev = 0.f, pb_prev = 0.f;
+                (void)pa_prev;
+                (void)pb_prev;
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const float sx = z[15 - k2].x, sy = z[15 - k2].y;
+                    const v2f own = z[(16 - k2) & 15];
+                    const float ox = own.x, oy = own.y;
+                    // partner Z[256 - k] from lane 16 - j (lane 0: its own register 16 - k2): row_mirror, then row_shr:1 with `old`
+                    float mx = __builtin_amdgcn_update_dpp(sx, sx, 0x140 /*row_mirror*/, 0xF, 0xF, true);
+                    float my = __builtin_amdgcn_update_dpp(sy, sy, 0x140 /*row_mirror*/, 0xF, 0xF, true);
+                    mx = __builtin_amdgcn_update_dpp(ox, mx, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+                    my = __builtin_amdgcn_update_dpp(oy, my, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+                    const v2f zmk = v2f{mx, my};
+                    const v2f zk = z[k2];
+                    v2f w = wpr[k2 < NWP ? k2 : k2 - 4];
+                    if (k2 >= NWP) w = cmulc(w, 0.70710678118654752f, -0.70710678118654752f);  // W_512^64 = W_8
+                    const v2f e = __builtin_elementwise_fma(zmk, v2f{1.f, -1.f}, zk);
+                    const v2f d = __builtin_elementwise_fma(zmk, v2f{-1.f, 1.f}, zk);
+                    const v2f o = cmul_negi(d, w);
+                    const v2f Rr = __builtin_elementwise_fma(xx(o), v2f{1.f, -1.f}, xx(e));
+                    const v2f Ii = __builtin_elementwise_fma(yy(o), v2f{1.f, -1.f}, yy(e));
+                    const v2f pw = __builtin_elementwise_fma(Rr, Rr, Ii * Ii);
+                    float pa = pw.x, pb = pw.y;
+                    if (POWER == 1) {
+                        pa = __builtin_sqrtf(pa);
+                        pb = __builtin_sqrtf(pb);
+                    }
+#ifndef SSP_S_NOPW2
+                    // (two bins of each stream per LDS instruction: the pair of a stream goes out back to back so that it merges into
+                    //  one ds_write2_b32)
+                    if (k2 & 1) {
+                        P[j + 16 * (k2 - 1)] = pa_prev;
+                        P[j + 16 * k2] = pa;
+                        Pm[16 * (7 - k2)] = pb;
+                        Pm[16 * (8 - k2)] = pb_prev;
+                    } else {
+                        pa_prev = pa;
+                        pb_prev = pb;
+                    }
+#else
+                    P[j + 16 * k2] = pa;
+                    Pm[16 * (7 - k2)] = pb;
+#endif
+                }
+                const v2f s8 = z[8] * z[8];
+                float p128 = 4.f * (s8.x + s8.y);
+                if (POWER == 1) p128 = __builtin_sqrtf(p128);
+                if (j == 0) P[128] = p128;
+            }
+        };
+        // ---- piece filterbank + log of the four frames whose P rows are in the images: all 64 lanes on one frame at a time
+        //      (see mfcc_fast.hip step 7); the log-mel rows go behind the P rows
+        auto mel = [&]() {
+#ifndef SSP_S_NOMEL
+            float* lm = reinterpret_cast<float*>(zbuf + g * ZFRAME + LM_OFF - 64 * g);
+            if (j < f.lm_pad) lm[a.n_filt + j] = 0.f;
+            float sfr[4];
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) {
+                const char* pr = zbuf + fr * ZFRAME;
+                v4f acc = *reinterpret_cast<const v4f*>(pr + mofs[0]) * mw[0];
+#pragma unroll
+                for (int i = 1; i < MV; ++i) acc = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(pr + mofs[i]), mw[i], acc);
+                const v2f h = v2f{acc.x, acc.y} + v2f{acc.z, acc.w};
+                sfr[fr] = h.x + h.y;
+            }
+            v2f s01 = v2f{sfr[0], sfr[1]}, s23 = v2f{sfr[2], sfr[3]};
+#define SSP_SCAN_STEP(CTRL, MK)                                                                     \
+            {                                                                                           \
+                const float a0 = s01.x, a1 = s01.y, a2 = s23.x, a3 = s23.y;                             \
+                const float b0 = __builtin_amdgcn_update_dpp(a0, a0, CTRL, 0xF, 0xF, true);           \
+                const float b1 = __builtin_amdgcn_update_dpp(a1, a1, CTRL, 0xF, 0xF, true);           \
+                const float b2 = __builtin_amdgcn_update_dpp(a2, a2, CTRL, 0xF, 0xF, true);           \
+                const float b3 = __builtin_amdgcn_update_dpp(a3, a3, CTRL, 0xF, 0xF, true);           \
+                s01 = __builtin_elementwise_fma(v2f{b0, b1}, MK, s01);                                  \
+                s23 = __builtin_elementwise_fma(v2f{b2, b3}, MK, s23);                                  \
+            }
+            if (mel_ns > 0) SSP_SCAN_STEP(0x101 /*row_shl:1*/, xx(mk01))
+            if (mel_ns > 1) SSP_SCAN_STEP(0x102 /*row_shl:2*/, yy(mk01))
+            if (mel_ns > 2) SSP_SCAN_STEP(0x104 /*row_shl:4*/, xx(mk23))
+            if (mel_ns > 3) SSP_SCAN_STEP(0x108 /*row_shl:8*/, yy(mk23))
+#undef SSP_SCAN_STEP
+            if (mfid >= 0) {
+                float* lmf = reinterpret_cast<float*>(zbuf + LM_OFF) + mfid;
+                lmf[0 * (ZFRAME - 64) / 4] = stream_log(f, s01.x);
+                lmf[1 * (ZFRAME - 64) / 4] = stream_log(f, s01.y);
+                lmf[2 * (ZFRAME - 64) / 4] = stream_log(f, s23.x);
+                lmf[3 * (ZFRAME - 64) / 4] = stream_log(f, s23.y);
+            }
+#endif
+        };
+        // ---- DCT on the matrix cores: C[ceps][frame] over the four frames whose log-mel rows are in the images (columns 4..15 repeat them)
+        auto dct_mfma = [&]() -> v4f {
+            v4f cq = v4f{0.f, 0.f, 0.f, 0.f};
+#ifndef SSP_S_NODCT
+            // (lane-derived addresses are recomputed from an opaque copy of the lane id: hoisted out of the loop they would
+            //  sit in registers the FFT phases need)
+            int ol = lane;
+            asm volatile("" : "+v"(ol));
+            const int g = ol >> 4, j = ol & 15;
+            const char* lmrow = zbuf + (j & 3) * (ZFRAME - 64) + LM_OFF + g * (KS * 4);
+            float lb[KS];
+#pragma unroll
+            for (int s = 0; s < KS; s += 2) {
+                const v2f v = *reinterpret_cast<const v2f*>(lmrow + 4 * s);
+                lb[s] = v.x;
+                lb[s + 1] = v.y;
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) cq = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[s], lb[s], cq, 0, 0, 0);
+#endif
+            return cq;
+        };
+        // cepstra of quad qq -> ring: lane (g, j): cepstra 4 g .. 4 g + 3 of frame ta + 4 qq + j (j < 4); frames past the chunk's last one
+        // and virtual quads behind it store zeros (their ring rows must read as finite values)
+        auto ring_put = [&](int qq, v4f cq, bool real) {
+            int ol = lane;
+            asm volatile("" : "+v"(ol));
+            const int g = ol >> 4, j = ol & 15;
+            if (j < 4) {
+                const bool ok = real && ta + 4 * qq + j < tb;
+                const v4f cv = ok ? cq : v4f{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<v4f*>(ring + ((((qq + 6) % 6) * 4 + j) * RING_ROW) + g * 16) = cv;
+            }
+        };
+        // ================= time step b: rows [16 b - 4, 16 b + 12) of (c, delta, delta-delta) leave =================
+        auto time_step = [&](int b) {
+            const int rb = 16 * b;
+            int ol = lane;
+            asm volatile("" : "+v"(ol));
+            const int g = ol >> 4, j = ol & 15;
+            // B operands: cepstra of ring frames rb - 8 + 4 s + g, column j (lane (g, j)), s = 0..5
+            float cb[6];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int m = (rb + 16 + 4 * s) % RING_FRAMES;  // (rb - 8 + 4 s) mod 24, a multiple of 4
+                cb[s] = *reinterpret_cast<const float*>(ring + (m + g) * RING_ROW + j * 4);
+            }
+            const float tg = (float)(ta + rb);  // utterance frame index of relative frame rb
+            // A operands = regression weights of frame (tg + tpr) in delta[tg + tr].  Steps whose 24-frame window lies strictly
+            // inside the utterance (all but the first and the last one or two) take them from the lane-constant distance
+            // d = tpr - tr: d / denom for |d| <= 2; at the utterance ends the edge-replicated form folds the outside weights
+            // onto frame 0 / T - 1.
+            const bool interior = ta + rb - 8 >= 1 && ta + rb + 16 <= T - 2;  // wave-uniform
+            const float inv = 2.f * half_inv;
+            auto W = [&](float tr, float tpr) -> float {
+                if (interior) {
+                    const float d = tpr - tr;
+                    return __builtin_fabsf(d) <= 2.f ? d * inv : 0.f;
+                }
+                return delta_weight(tg + tr, tg + tpr, Tm1, half_inv);
+            };
+            const float fj = (float)j, fg = (float)g;
+            // rows leave with bounds-checked 4-byte buffer stores; a lane that has nothing to store aims out of bounds.  The
+            // instruction count per step is fixed (the wait at the top of the next quad counts them)
+            const int Fo = ta + rb - 4 + 4 * g;  // first output frame of this lane group (registers r = 0..3 follow)
+            const bool full = ta + rb - 4 >= t0 && ta + rb + 12 <= t0 + n;  // wave-uniform: every row of the window is emitted
+            const int lane_off = j < nc ? (Fo * Dd + j) * 4 : 0x7ffffff0;
+            auto put = [&](int rrel, int blk, float v, bool lane_on) {
+                // row Fo + rrel, block blk (0 cepstra | 1 delta | 2 delta-delta)
+                int off;
+                if (full) {
+                    off = lane_on ? lane_off + (rrel * Dd + blk * nc) * 4 : 0x7ffffff0;
+                } else {
+                    const int F = Fo + rrel;
+                    off = (lane_on && F >= t0 && F < t0 + n) ? lane_off + (rrel * Dd + blk * nc) * 4 : 0x7ffffff0;
+                }
+#ifdef SSP_S_NOSTORE  // ablation: the products stay live, nothing leaves
+                asm volatile("" ::"v"(v), "v"(off));
+#else
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off, 0, 0);
+#endif
+                if (CM) {
+                    const double dv = off != 0x7ffffff0 ? (double)v : 0.0;
+                    cs1[CM ? blk : 0] += dv;
+                    cs2[CM ? blk : 0] = __builtin_fma(dv, dv, cs2[CM ? blk : 0]);
+                }
+            };
+            // cepstra of the output rows straight from the ring
+            {
+                const int m4 = (rb + 20) % RING_FRAMES;  // (rb - 4) mod 24
+                int slot = m4 + 4 * g;
+                slot = slot >= RING_FRAMES ? slot - RING_FRAMES : slot;
+                const float* cr = reinterpret_cast<const float*>(ring + slot * RING_ROW + j * 4);
+                const v4f o0 = v4f{cr[0], cr[16], cr[32], cr[48]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put(r, 0, o0[r], true);
+            }
+            if (dord >= 1) {
+                // delta tile 0: rows i = j <-> frame rb - 6 + i; contraction over ring frames rb - 8 + 4 s + g, s = 0..4
+                v4f d0 = v4f{0.f, 0.f, 0.f, 0.f}, d1 = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 5; ++s) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W(fj - 6.f, fg + (float)(4 * s - 8)), cb[s], d0, 0, 0, 0);
+                // delta tile 1: rows i = 0, 4, 8, 12 <-> frames rb + 10 + i / 4 (the other rows are zero); s = 4, 5
+                const float fr1 = (float)(j >> 2) + 10.f;
+#pragma unroll
+                for (int s = 4; s < 6; ++s) {
+                    float w = W(fr1, fg + (float)(4 * s - 8));
+                    w = (j & 3) == 0 ? w : 0.f;
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, cb[s], d1, 0, 0, 0);
+                }
+                // delta rows leave from their own layout: tile 0 register r <-> frame rb - 6 + 4 g + r = row Fo + r - 2 (the first two
+                // belong to the previous step's window), tile 1 register 0 <-> frame rb + 10 + g = row Fo + 14 - 3 g (g < 2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put(r - 2, 1, d0[r], r >= 2 || g > 0);
+                put(14 - 3 * g, 1, d1[0], g < 2);
+                if (dord >= 2) {
+                    // delta-delta: rows i = j <-> frame rb - 4 + i; B = delta tile 0 register s (frame rb - 6 + 4 g + s) and
+                    // delta tile 1 register 0 (frame rb + 10 + g)
+                    v4f dd = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) dd = __builtin_amdgcn_mfma_f32_16x16x4f32(W(fj - 4.f, 4.f * fg + (float)(s - 6)), d0[s], dd, 0, 0, 0);
+                    dd = __builtin_amdgcn_mfma_f32_16x16x4f32(W(fj - 4.f, fg + 10.f), d1[0], dd, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) put(r, 2, dd[r], true);
+                }
+            }
+            stores_pending = dord >= 2 ? 13 : (dord == 1 ? 9 : 4);
+        };
+
+        if constexpr (DENSE) {
+            for (int q = 0; q < nquads; ++q) {
+                zarr_t z;
+                pfarr_t pf;
+                pmarr_t pm;
+                wait_dma();
+                stage_read_a(pf, pm);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                window_a(z, pf, pm);
+                stage_read_b(pf, pm);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is in registers: the next quad may overwrite it
 #ifndef SSP_S_NODMA
                 prefetch(q + 1);                                     // flies under this whole iteration (past the end: zeros)
 #endif
-#pragma unroll
-                for (int n1 = NH; n1 < 16; ++n1) {
-                    if (n1 < NZ) {
-                        v2f y = pf[n1 < NZ ? n1 : 0];
-                        if (PRE) {
-                            const float xm1 = pm[n1 < NZ ? n1 : 0].y, x0 = y.x, x1 = y.y;
-                            y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
-                        }
-                        z[n1] = y * wreg[n1 < NZ ? n1 : 0];
-                    } else {
-                        z[n1] = v2f{0.f, 0.f};
-                    }
-                }
-                // ---- FFT16 over n1, twiddle W_256^(n2 k1)
-                fft16(z);
-#pragma unroll
-                for (int k1 = 1; k1 < 16; ++k1) {
-                    if (k1 <= NTW) {
-                        z[k1] = cmul(z[k1], twr[(k1 - 1) % NTW]);
-                    } else {  // W^(k1 j) = W^((k1 - 8) j) W^(8 j)
-                        z[k1] = cmul(cmul(z[k1], twr[(k1 - 9) % NTW]), twr[7]);
-                    }
-                }
-                // ---- transpose through LDS (rows of 128 B, 16-byte chunks XOR-swizzled by (row >> 1) & 7)
-                char* zf = zbuf + g * ZFRAME;
-                {
-                    int wb0 = ((j >> 1) << 4) | ((j & 1) << 3);
-                    asm volatile("" : "+v"(wb0));
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        char* wp = zf + (wb0 ^ (m << 4));
-                        *reinterpret_cast<v2f*>(wp + (2 * m) * ZROW) = z[2 * m];
-                        *reinterpret_cast<v2f*>(wp + (2 * m + 1) * ZROW) = z[2 * m + 1];
-                    }
-                    int rb0 = j * ZROW + (((j >> 1) & 7) << 4);
-                    asm volatile("" : "+v"(rb0));
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const v4f r = *reinterpret_cast<const v4f*>(zf + (rb0 ^ (c << 4)));
-                        z[2 * c] = v2f{r.x, r.y};
-                        z[2 * c + 1] = v2f{r.z, r.w};
-                    }
-                }
-                // ---- FFT16 over n2: lane j = k1, register = k2
-                fft16(z);
-                // ---- split step of the real FFT (partners from lane 16 - j by two DPP row permutes), power / magnitude -> P row
-                {
-                    float* P = reinterpret_cast<float*>(zf);
-                    float* Pm = P + 144 - j;
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; ++k2) {
-                        // partner Z[256 - k] from lane 16 - j (lane 0: its own register 16 - k2): row_mirror, then row_shr:1 with `old`
-                        const float sx = z[15 - k2].x, sy = z[15 - k2].y;
-                        const v2f own = z[(16 - k2) & 15];
-                        const float ox = own.x, oy = own.y;
-                        float mx = __builtin_amdgcn_update_dpp(sx, sx, 0x140 /*row_mirror*/, 0xF, 0xF, true);
-                        float my = __builtin_amdgcn_update_dpp(sy, sy, 0x140 /*row_mirror*/, 0xF, 0xF, true);
-                        mx = __builtin_amdgcn_update_dpp(ox, mx, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
-                        my = __builtin_amdgcn_update_dpp(oy, my, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
-                        const v2f zmk = v2f{mx, my};
-                        const v2f zk = z[k2];
-                        v2f w = wpr[k2 < NWP ? k2 : k2 - 4];
-                        if (k2 >= NWP) w = cmulc(w, 0.70710678118654752f, -0.70710678118654752f);  // W_512^64 = W_8
-                        const v2f e = __builtin_elementwise_fma(zmk, v2f{1.f, -1.f}, zk);
-                        const v2f d = __builtin_elementwise_fma(zmk, v2f{-1.f, 1.f}, zk);
-                        const v2f o = cmul_negi(d, w);
-                        const v2f Rr = __builtin_elementwise_fma(xx(o), v2f{1.f, -1.f}, xx(e));
-                        const v2f Ii = __builtin_elementwise_fma(yy(o), v2f{1.f, -1.f}, yy(e));
-                        const v2f pw = __builtin_elementwise_fma(Rr, Rr, Ii * Ii);
-                        float pa = pw.x, pb = pw.y;
-                        if (POWER == 1) {
-                            pa = __builtin_sqrtf(pa);
-                            pb = __builtin_sqrtf(pb);
-                        }
-                        P[j + 16 * k2] = pa;
-                        Pm[16 * (7 - k2)] = pb;
-                    }
-                    const v2f s8 = z[8] * z[8];
-                    float p128 = 4.f * (s8.x + s8.y);
-                    if (POWER == 1) p128 = __builtin_sqrtf(p128);
-                    if (j == 0) P[128] = p128;
-                }
-                if (DENSE) {
-                    // ---- dense bands: partial sums of this lane's 17 bins for 6 bands and the quad's 4 frames ...
-                    int ol = lane;
-                    asm volatile("" : "+v"(ol));
-                    const int c = ol & 15;
-                    float r[4][6];
-#pragma unroll
-                    for (int fr = 0; fr < 4; ++fr) {
-                        const char* pr = zbuf + fr * ZFRAME;
-                        const v4f p0 = *reinterpret_cast<const v4f*>(pr + 64 * c), p1 = *reinterpret_cast<const v4f*>(pr + 64 * c + 16);
-                        const v4f p2 = *reinterpret_cast<const v4f*>(pr + 64 * c + 32), p3 = *reinterpret_cast<const v4f*>(pr + 64 * c + 48);
-                        const float p256 = *reinterpret_cast<const float*>(pr + 1024);
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            v4f acc = p0 * dw[DENSE ? k : 0][0];
-                            acc = __builtin_elementwise_fma(p1, dw[DENSE ? k : 0][1], acc);
-                            acc = __builtin_elementwise_fma(p2, dw[DENSE ? k : 0][2], acc);
-                            acc = __builtin_elementwise_fma(p3, dw[DENSE ? k : 0][3], acc);
-                            const v2f hs = v2f{acc.x, acc.y} + v2f{acc.z, acc.w};
-                            r[fr][k] = __builtin_fmaf(p256, dw256[DENSE ? k : 0], hs.x + hs.y);
-                        }
-                    }
-                    // ... meet through LDS ([frame][band of the group][lane] over the frame images, whose P rows are consumed): output
-                    // o = frame * n_bands + band sums the 16 bin-chunk lanes of its band group
-                    float* sc = reinterpret_cast<float*>(zbuf);
-#pragma unroll
-                    for (int fr = 0; fr < 4; ++fr)
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) sc[(fr * 6 + k) * 64 + ol] = r[fr][k];
-                    const int nb = a.n_filt;
-#pragma unroll
-                    for (int rd = 0; rd < 2; ++rd) {
-                        const int o = rd * 64 + ol;
-                        const int fr = (o >= nb) + (o >= 2 * nb) + (o >= 3 * nb);
-                        const int band = o - fr * nb;
-                        const int bg = (band * 43) >> 8, k = band - 6 * bg;  // band / 6 for band < 24
-                        const bool valid = o < 4 * nb;
-                        const float* src = sc + ((valid ? fr * 6 + k : 0) * 64 + (valid ? 16 * bg : 0));
-                        const v4f s0 = *reinterpret_cast<const v4f*>(src), s1 = *reinterpret_cast<const v4f*>(src + 4);
-                        const v4f s2 = *reinterpret_cast<const v4f*>(src + 8), s3 = *reinterpret_cast<const v4f*>(src + 12);
-                        const v4f s4 = (s0 + s1) + (s2 + s3);
-                        const float val = stream_log(f, (s4.x + s4.y) + (s4.z + s4.w));
-                        const bool ok = valid && ta + 4 * q + fr < tb;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, ok ? ((ta + 4 * q) * Dd + o) * 4 : 0x7ffffff0, 0, 0);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch is read: the next quad's transposes may overwrite it
-                    stores_pending = 2;
-                    continue;
-                }
-                // ---- piece filterbank + log: all 64 lanes on one frame at a time (see mfcc_fast.hip step 7)
-#ifndef SSP_S_NOMEL
-                {
-                    float* lm = reinterpret_cast<float*>(zf + LM_OFF - 64 * g);
-                    if (j < f.lm_pad) lm[a.n_filt + j] = 0.f;
-                    float sfr[4];
-#pragma unroll
-                    for (int fr = 0; fr < 4; ++fr) {
-                        const char* pr = zbuf + fr * ZFRAME;
-                        v4f acc = *reinterpret_cast<const v4f*>(pr + mofs[0]) * mw[0];
-#pragma unroll
-                        for (int i = 1; i < MV; ++i) acc = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(pr + mofs[i]), mw[i], acc);
-                        const v2f h = v2f{acc.x, acc.y} + v2f{acc.z, acc.w};
-                        sfr[fr] = h.x + h.y;
-                    }
-                    v2f s01 = v2f{sfr[0], sfr[1]}, s23 = v2f{sfr[2], sfr[3]};
-#define SSP_SCAN_STEP(CTRL, MK)                                                                             \
-                    {                                                                                           \
-                        const float a0 = s01.x, a1 = s01.y, a2 = s23.x, a3 = s23.y;                             \
-                        const float b0 = __builtin_amdgcn_update_dpp(a0, a0, CTRL, 0xF, 0xF, true);           \
-                        const float b1 = __builtin_amdgcn_update_dpp(a1, a1, CTRL, 0xF, 0xF, true);           \
-                        const float b2 = __builtin_amdgcn_update_dpp(a2, a2, CTRL, 0xF, 0xF, true);           \
-                        const float b3 = __builtin_amdgcn_update_dpp(a3, a3, CTRL, 0xF, 0xF, true);           \
-                        s01 = __builtin_elementwise_fma(v2f{b0, b1}, MK, s01);                                  \
-                        s23 = __builtin_elementwise_fma(v2f{b2, b3}, MK, s23);                                  \
-                    }
-                    if (mel_ns > 0) SSP_SCAN_STEP(0x101 /*row_shl:1*/, xx(mk01))
-                    if (mel_ns > 1) SSP_SCAN_STEP(0x102 /*row_shl:2*/, yy(mk01))
-                    if (mel_ns > 2) SSP_SCAN_STEP(0x104 /*row_shl:4*/, xx(mk23))
-                    if (mel_ns > 3) SSP_SCAN_STEP(0x108 /*row_shl:8*/, yy(mk23))
-#undef SSP_SCAN_STEP
-                    if (mfid >= 0) {
-                        float* lmf = reinterpret_cast<float*>(zbuf + LM_OFF) + mfid;
-                        lmf[0 * (ZFRAME - 64) / 4] = stream_log(f, s01.x);
-                        lmf[1 * (ZFRAME - 64) / 4] = stream_log(f, s01.y);
-                        lmf[2 * (ZFRAME - 64) / 4] = stream_log(f, s23.x);
-                        lmf[3 * (ZFRAME - 64) / 4] = stream_log(f, s23.y);
-                    }
-                }
-#endif
-                // ---- DCT on the matrix cores: C[ceps][frame] over the quad's 4 frames (columns 4..15 repeat them)
-#ifndef SSP_S_NODCT
-                {
-                    // (lane-derived addresses are recomputed from an opaque copy of the lane id: hoisted out of the loop they would
-                    //  sit in registers the FFT phases need)
-                    int ol = lane;
-                    asm volatile("" : "+v"(ol));
-                    const int g = ol >> 4, j = ol & 15;
-                    const char* lmrow = zbuf + (j & 3) * (ZFRAME - 64) + LM_OFF + g * (KS * 4);
-                    float lb[KS];
-#pragma unroll
-                    for (int s = 0; s < KS; s += 2) {
-                        const v2f v = *reinterpret_cast<const v2f*>(lmrow + 4 * s);
-                        lb[s] = v.x;
-                        lb[s + 1] = v.y;
-                    }
-                    v4f cq = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) cq = __builtin_amdgcn_mfma_f32_16x16x4f32(dA[s], lb[s], cq, 0, 0, 0);
-                    // lane (g, j): cepstra 4 g .. 4 g + 3 of frame ta + 4 q + j (j < 4); frames past the chunk's last one store zeros
-                    if (j < 4) {
-                        const bool ok = ta + 4 * q + j < tb;
-                        const v4f cv = ok ? cq : v4f{0.f, 0.f, 0.f, 0.f};
-                        *reinterpret_cast<v4f*>(ring + (((q % 6) * 4 + j) * RING_ROW) + g * 16) = cv;
-                    }
-                }
-#endif
-            } else {
-                // virtual quad behind the chunk's last frame: its ring rows must read as finite values
+                window_b(z, pf, pm);
+                fft_front(z);
+                // ---- dense bands: partial sums of this lane's 17 bins for 6 bands and the quad's 4 frames ...
                 int ol = lane;
                 asm volatile("" : "+v"(ol));
-                const int g = ol >> 4, j = ol & 15;
-                if (j < 4) *reinterpret_cast<v4f*>(ring + (((q % 6) * 4 + j) * RING_ROW) + g * 16) = v4f{0.f, 0.f, 0.f, 0.f};
+                const int c = ol & 15;
+                float r[4][6];
+#pragma unroll
+                for (int fr = 0; fr < 4; ++fr) {
+                    const char* pr = zbuf + fr * ZFRAME;
+                    const v4f p0 = *reinterpret_cast<const v4f*>(pr + 64 * c), p1 = *reinterpret_cast<const v4f*>(pr + 64 * c + 16);
+                    const v4f p2 = *reinterpret_cast<const v4f*>(pr + 64 * c + 32), p3 = *reinterpret_cast<const v4f*>(pr + 64 * c + 48);
+                    const float p256 = *reinterpret_cast<const float*>(pr + 1024);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        v4f acc = p0 * dw[DENSE ? k : 0][0];
+                        acc = __builtin_elementwise_fma(p1, dw[DENSE ? k : 0][1], acc);
+                        acc = __builtin_elementwise_fma(p2, dw[DENSE ? k : 0][2], acc);
+                        acc = __builtin_elementwise_fma(p3, dw[DENSE ? k : 0][3], acc);
+                        const v2f hs = v2f{acc.x, acc.y} + v2f{acc.z, acc.w};
+                        r[fr][k] = __builtin_fmaf(p256, dw256[DENSE ? k : 0], hs.x + hs.y);
+                    }
+                }
+                // ... meet through LDS ([frame][band of the group][lane] over the frame images, whose P rows are consumed): output
+                // o = frame * n_bands + band sums the 16 bin-chunk lanes of its band group
+                float* sc = reinterpret_cast<float*>(zbuf);
+#pragma unroll
+                for (int fr = 0; fr < 4; ++fr)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) sc[(fr * 6 + k) * 64 + ol] = r[fr][k];
+                const int nb = a.n_filt;
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int o = rd * 64 + ol;
+                    const int fr = (o >= nb) + (o >= 2 * nb) + (o >= 3 * nb);
+                    const int band = o - fr * nb;
+                    const int bg = (band * 43) >> 8, k = band - 6 * bg;  // band / 6 for band < 24
+                    const bool valid = o < 4 * nb;
+                    const float* src = sc + ((valid ? fr * 6 + k : 0) * 64 + (valid ? 16 * bg : 0));
+                    const v4f s0 = *reinterpret_cast<const v4f*>(src), s1 = *reinterpret_cast<const v4f*>(src + 4);
+                    const v4f s2 = *reinterpret_cast<const v4f*>(src + 8), s3 = *reinterpret_cast<const v4f*>(src + 12);
+                    const v4f s4 = (s0 + s1) + (s2 + s3);
+                    const float val = stream_log(f, (s4.x + s4.y) + (s4.z + s4.w));
+                    const bool ok = valid && ta + 4 * q + fr < tb;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, ok ? ((ta + 4 * q) * Dd + o) * 4 : 0x7ffffff0, 0, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the scratch is read: the next quad's transposes may overwrite it
+                stores_pending = 2;
             }
-#ifdef SSP_S_NOSTEP
-            continue;
+        } else {
+#ifdef SSP_S_SEQ  // (A/B: the phases of a quad in sequence, as before round 3)
+            for (int q = 0; q < Q; ++q) {
+                zarr_t z;
+                pfarr_t pf;
+                pmarr_t pm;
+                if (q < nquads) {
+                    wait_dma();
+                    stage_read_a(pf, pm);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    window_a(z, pf, pm);
+                    stage_read_b(pf, pm);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef SSP_S_NODMA
+                    prefetch(q + 1);
 #endif
-            if ((q & 3) != 3) continue;
-            // ================= time step b: rows [16 b - 4, 16 b + 12) of (c, delta, delta-delta) leave =================
-            {
-                const int b = q >> 2;
-                const int rb = 16 * b;
-                int ol = lane;
-                asm volatile("" : "+v"(ol));
-                const int g = ol >> 4, j = ol & 15;
-                // B operands: cepstra of ring frames rb - 8 + 4 s + g, column j (lane (g, j)), s = 0..5
-                float cb[6];
-#pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    const int m = (rb + 16 + 4 * s) % RING_FRAMES;  // (rb - 8 + 4 s) mod 24, a multiple of 4
-                    cb[s] = *reinterpret_cast<const float*>(ring + (m + g) * RING_ROW + j * 4);
+                    window_b(z, pf, pm);
+                    fft_front(z);
+                    mel();
+                    const v4f cq = dct_mfma();
+                    ring_put(q, cq, true);
+                } else {
+                    ring_put(q, v4f{0.f, 0.f, 0.f, 0.f}, false);
                 }
-                const float tg = (float)(ta + rb);  // utterance frame index of relative frame rb
-                // A operands = regression weights of frame (tg + tpr) in delta[tg + tr].  Steps whose 24-frame window lies strictly
-                // inside the utterance (all but the first and the last one or two) take them from the lane-constant distance
-                // d = tpr - tr: d / denom for |d| <= 2; at the utterance ends the edge-replicated form folds the outside weights
-                // onto frame 0 / T - 1.
-                const bool interior = ta + rb - 8 >= 1 && ta + rb + 16 <= T - 2;  // wave-uniform
-                const float inv = 2.f * half_inv;
-                auto W = [&](float tr, float tpr) -> float {
-                    if (interior) {
-                        const float d = tpr - tr;
-                        return __builtin_fabsf(d) <= 2.f ? d * inv : 0.f;
-                    }
-                    return delta_weight(tg + tr, tg + tpr, Tm1, half_inv);
-                };
-                const float fj = (float)j, fg = (float)g;
-                // rows leave with bounds-checked 4-byte buffer stores; a lane that has nothing to store aims out of bounds.  The
-                // instruction count per step is fixed (the wait at the top of the next quad counts them)
-                const int Fo = ta + rb - 4 + 4 * g;  // first output frame of this lane group (registers r = 0..3 follow)
-                const bool full = ta + rb - 4 >= t0 && ta + rb + 12 <= t0 + n;  // wave-uniform: every row of the window is emitted
-                const int lane_off = j < nc ? (Fo * Dd + j) * 4 : 0x7ffffff0;
-                auto put = [&](int rrel, int blk, float v, bool lane_on) {
-                    // row Fo + rrel, block blk (0 cepstra | 1 delta | 2 delta-delta)
-                    int off;
-                    if (full) {
-                        off = lane_on ? lane_off + (rrel * Dd + blk * nc) * 4 : 0x7ffffff0;
-                    } else {
-                        const int F = Fo + rrel;
-                        off = (lane_on && F >= t0 && F < t0 + n) ? lane_off + (rrel * Dd + blk * nc) * 4 : 0x7ffffff0;
-                    }
-#ifdef SSP_S_NOSTORE  // ablation: the products stay live, nothing leaves
-                    asm volatile("" ::"v"(v), "v"(off));
+#ifndef SSP_S_NOSTEP
+                if ((q & 3) == 3) time_step(q >> 2);
+#endif
+            }
 #else
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off, 0, 0);
+            // Software-pipelined quad loop: iteration q runs the FRONT of quad q (stage -> window -> FFT -> split -> P rows) and the BACK of
+            // quad q - 1 (filterbank + log -> DCT -> ring -> time step).  The back's LDS round trips ride under the front's: the P reads
+            // of the filterbank are issued behind the first half of the stage reads and return with them, the log-mel reads of the DCT
+            // behind the second half, and the DCT's dependent MFMA chain runs while the second half is windowed.  LDS operations of a
+            // wave execute in order, and the back's reads of the images are all issued before the front's transposes overwrite them.
+            for (int q = 0; q < nquads; ++q) {
+                zarr_t z;
+                pfarr_t pf;
+                pmarr_t pm;
+                wait_dma();
+                stage_read_a(pf, pm);
+                const v4f cq = dct_mfma();  // quad q - 1 (q = 0: whatever the images hold; masked in ring_put)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                window_a(z, pf, pm);
+                stage_read_b(pf, pm);
+                ring_put(q - 1, cq, q > 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is in registers: the next quad may overwrite it
+#ifndef SSP_S_NODMA
+                prefetch(q + 1);                                     // flies under this whole iteration (past the end: zeros)
 #endif
-                    if (CM) {
-                        const double dv = off != 0x7ffffff0 ? (double)v : 0.0;
-                        cs1[CM ? blk : 0] += dv;
-                        cs2[CM ? blk : 0] = __builtin_fma(dv, dv, cs2[CM ? blk : 0]);
-                    }
-                };
-                // cepstra of the output rows straight from the ring
-                {
-                    const int m4 = (rb + 20) % RING_FRAMES;  // (rb - 4) mod 24
-                    int slot = m4 + 4 * g;
-                    slot = slot >= RING_FRAMES ? slot - RING_FRAMES : slot;
-                    const float* cr = reinterpret_cast<const float*>(ring + slot * RING_ROW + j * 4);
-                    const v4f o0 = v4f{cr[0], cr[16], cr[32], cr[48]};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) put(r, 0, o0[r], true);
-                }
-                if (dord >= 1) {
-                    // delta tile 0: rows i = j <-> frame rb - 6 + i; contraction over ring frames rb - 8 + 4 s + g, s = 0..4
-                    v4f d0 = v4f{0.f, 0.f, 0.f, 0.f}, d1 = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < 5; ++s) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W(fj - 6.f, fg + (float)(4 * s - 8)), cb[s], d0, 0, 0, 0);
-                    // delta tile 1: rows i = 0, 4, 8, 12 <-> frames rb + 10 + i / 4 (the other rows are zero); s = 4, 5
-                    const float fr1 = (float)(j >> 2) + 10.f;
-#pragma unroll
-                    for (int s = 4; s < 6; ++s) {
-                        float w = W(fr1, fg + (float)(4 * s - 8));
-                        w = (j & 3) == 0 ? w : 0.f;
-                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, cb[s], d1, 0, 0, 0);
-                    }
-                    // delta rows leave from their own layout: tile 0 register r <-> frame rb - 6 + 4 g + r = row Fo + r - 2 (the first two
-                    // belong to the previous step's window), tile 1 register 0 <-> frame rb + 10 + g = row Fo + 14 - 3 g (g < 2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) put(r - 2, 1, d0[r], r >= 2 || g > 0);
-                    put(14 - 3 * g, 1, d1[0], g < 2);
-                    if (dord >= 2) {
-                        // delta-delta: rows i = j <-> frame rb - 4 + i; B = delta tile 0 register s (frame rb - 6 + 4 g + s) and
-                        // delta tile 1 register 0 (frame rb + 10 + g)
-                        v4f dd = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) dd = __builtin_amdgcn_mfma_f32_16x16x4f32(W(fj - 4.f, 4.f * fg + (float)(s - 6)), d0[s], dd, 0, 0, 0);
-                        dd = __builtin_amdgcn_mfma_f32_16x16x4f32(W(fj - 4.f, fg + 10.f), d1[0], dd, 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) put(r, 2, dd[r], true);
-                    }
-                }
-                stores_pending = dord >= 2 ? 13 : (dord == 1 ? 9 : 4);
+                window_b(z, pf, pm);
+                fft_front(z);
+                mel();
+#ifndef SSP_S_NOSTEP
+                if ((q & 3) == 0 && q > 0) time_step((q - 1) >> 2);  // (here, where no FFT register is live)
+#endif
             }
+            // drain: the back of the last quad, then the virtual quads behind the chunk's last frame
+            for (int qb = nquads - 1; qb < Q; ++qb) {
+                v4f cq = v4f{0.f, 0.f, 0.f, 0.f};
+                if (qb < nquads) cq = dct_mfma();
+                ring_put(qb, cq, qb < nquads);
+#ifndef SSP_S_NOSTEP
+                if ((qb & 3) == 3) time_step(qb >> 2);
+#endif
+            }
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetch (zeros) and every store have completed
         if (CM) {
