@@ -158,6 +158,70 @@ def cpu_baseline_cosine(d, S, budget_s=5.0):
             "sample": "scipy.spatial.distance.cosine per pair (the reference's own call, d_vector.py:317), d=%d, %.1f s" % (d, dt)}
 
 
+def _timed_loop(fn, budget_s):
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        n += fn()
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline_em(D, K, budget_s=3.0):
+    """one EM iteration's sufficient statistics (E step + M sums) on the oracle's float64 restatement of sklearn's diag EM"""
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(21)
+    w, mu, cov = rng.dirichlet(5 * np.ones(K)), rng.standard_normal((K, D)), rng.uniform(0.5, 2, (K, D))
+    X = rng.standard_normal((20000, D))
+    n, dt = _timed_loop(lambda: (O.gmm_em_stats(w, mu, cov, X), len(X))[1], budget_s)
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "oracle.ref_cpu.gmm_em_stats (numpy float64 restatement of sklearn's diag-covariance E step + M sums, "
+                      "sk:mixture/_gaussian_mixture.py), 20000 x %d frames per call, K=%d, one process (BLAS threads = host default), %.1f s" % (D, K, dt)}
+
+
+def cpu_baseline_dnn(dims, budget_s=3.0):
+    """the d-vector network forward (d_vector.py:171-189: Dense(256) x 4) as numpy float32 matmuls — what Keras' predict computes"""
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(22)
+    layers = [((rng.standard_normal((dims[i], dims[i + 1])) / dims[i] ** 0.5).astype(np.float32), None, "relu" if i < len(dims) - 2 else None)
+              for i in range(len(dims) - 1)]
+    X = rng.standard_normal((4096, dims[0])).astype(np.float32)
+    n, dt = _timed_loop(lambda: (O.dense_net_forward(X, layers), len(X))[1], budget_s)
+    return {"value": n / dt, "unit": "embeddings/s", "cores": 1, "kind": "port",
+            "sample": "oracle.ref_cpu.dense_net_forward (numpy matmul + bias + ReLU per layer, %s), batches of 4096, one process "
+                      "(BLAS threads = host default), %.1f s" % ("-".join(str(d) for d in dims), dt)}
+
+
+def cpu_baseline_dtw(L, budget_s=4.0):
+    """one DTW distance per call on 1222-element flattened MFCC sequences (MFCC_DTW.py:57-108: accelerated_dtw on (-1, 1) sequences)"""
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(23)
+    a, b = rng.standard_normal(L), rng.standard_normal(L)
+    n, dt = _timed_loop(lambda: (O.dtw_distance(a, b), 1)[1], budget_s)
+    return {"value": n / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "oracle.ref_cpu.dtw_distance (numpy anti-diagonal sweep of the dtw package's recurrence; the package itself is absent), "
+                      "%d x %d cells per pair, 1 thread, %.1f s" % (L, L, dt)}
+
+
+def cpu_baseline_plp(n_samp, fs, budget_s=4.0):
+    from oracle import ref_cpu as O
+    rng = np.random.default_rng(24)
+    x = np.clip(0.3 * np.sin(2 * np.pi * 120 * np.arange(n_samp) / fs) + 0.05 * rng.standard_normal(n_samp), -1, 1).astype(np.float32)
+    n, dt = _timed_loop(lambda: O.sidekit_plp(x, fs)[0].shape[0], budget_s)
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "oracle.ref_cpu.sidekit_plp (numpy float64 restatement of sidekit's plp: Bark front end + RASTA + Levinson + cepstrum) on "
+                      "%d-sample utterances, one process, %.1f s" % (n_samp, dt)}
+
+
+def kernel_source_sha256(names=("mfcc_stream.hip", "cplx.hpp", "mfcc.hpp", "common.hpp")):
+    """identity of the headline kernel's source: the PMC files under profiles/ record the value they were taken on, and a counter
+    reading is only quoted for the binary built from the same source"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(ROOT, "speech_signal_processing_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def launch_ranks(n_ranks):
     """`python bench.py --gpus N` outside a torch.distributed launch: this process never touches the GPU (no HIP call, no
     torch.cuda) — it starts `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a CHILD process (one rank per
@@ -188,6 +252,7 @@ def main():
     ap.add_argument("--inrepo-variant", type=int, default=0, help="kernel variant of the in-repo MFCC stage (as --variant)")
     ap.add_argument("--stages", default="mfcc,ref26,inrepo,librosa,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
     ap.add_argument("--gmm4-utts", type=int, default=12000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU; SURVEY.md 8(d) asks for >= 12000)")
+    ap.add_argument("--no-gmm4-full", dest="gmm4_full", action="store_false", help="skip the measured full per-GPU share of configs[3] (150000 utterances, bf16x3 path, ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
     args = ap.parse_args()
@@ -220,7 +285,7 @@ def main():
 
     import speech_signal_processing_amd as pkg
     from speech_signal_processing_amd import api
-    from speech_signal_processing_amd.dist import all_gather_rows, max_over_ranks
+    from speech_signal_processing_amd.dist import all_gather_rows, decision_records, max_over_ranks
 
     def barrier():
         if world > 1:
@@ -267,10 +332,16 @@ def main():
     algo_bytes = n_utt * n_samp * 4 + n_frames * plan.d_out * 4      # exact per launch: every sample read once, every feature written once
     achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9
     traffic = None
+    ksha = kernel_source_sha256()
     pmc_file = os.path.join(ROOT, "profiles", "mfcc_hbm_traffic.json")
+    traffic_source = {"file": "profiles/mfcc_hbm_traffic.json", "kernel_source_sha256_now": ksha, "taken_on": None, "matches_this_build": False}
     if os.path.exists(pmc_file) and n_utt == 100000 and n_samp == 48000:  # the PMC passes were taken on exactly this workload
         try:
-            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc_file))
+            traffic_source["taken_on"] = pj.get("kernel_source_sha256")
+            traffic_source["matches_this_build"] = pj.get("kernel_source_sha256") == ksha
+            if traffic_source["matches_this_build"]:   # a counter reading of another kernel version is not quoted
+                traffic = pj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     # second bound of the same kernel: VALU issue.  cycles per quad (4 frames) = instruction census of the shipped kernel x the issue
@@ -280,12 +351,14 @@ def main():
     if os.path.exists(census_file):
         try:
             cj = json.load(open(census_file))
-            cyc = float(cj["valu_issue_cycles_per_quad"])
-            peak = 256 * 4 * 2.4e9
-            ach = (n_frames / 4.0) * cyc / (ms_kernel * 1e-3)
-            valu = {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G issue-cycles/s", "frac": ach / peak,
-                    "issue_cycles_per_quad": cyc, "floor_ms_at_2.4GHz": (n_frames / 4.0) * cyc / peak * 1e3,
-                    "sustained_clock_ghz": cj.get("sustained_clock_ghz"), "source": "profiles/mfcc_valu_lds_pmc.json"}
+            if cj.get("kernel_source_sha256") == ksha:
+                cyc = float(cj["valu_issue_cycles_per_quad"])
+                peak = 256 * 4 * 2.4e9
+                ach = (n_frames / 4.0) * cyc / (ms_kernel * 1e-3)
+                valu = {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G issue-cycles/s", "frac": ach / peak,
+                        "issue_cycles_per_quad": cyc, "floor_ms_at_2.4GHz": (n_frames / 4.0) * cyc / peak * 1e3,
+                        "sustained_clock_ghz": cj.get("sustained_clock_ghz"), "source": "profiles/mfcc_valu_lds_pmc.json",
+                        "census_workload": cj.get("workload")}
         except Exception:
             valu = None
     result = {
@@ -300,7 +373,7 @@ def main():
                    "world_size_observed": (dist.get_world_size() if world > 1 else 1),
                    "backend": (dist.get_backend() if world > 1 else None), "kernel_ms_per_rank": per_rank_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "mfcc_stream512_kernel" if args.variant in (0, 3) else "mfcc fused pass", "kernel_ms": ms_kernel,
                      "kernel_ms_stat": "median of the timed launches (hipEvents on the launch stream)",
                      "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame},
@@ -324,7 +397,7 @@ def main():
             "value": n_frames / (r_ms * 1e-3), "unit": "frames/s", "d_out": rplan.d_out, "dtype": "f32",
             "roofline": {"bound": "hbm", "achieved": r_bytes / (r_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": r_bytes / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "mfcc_stream512_kernel + cmvn_kernel (the scaling pass re-reads and re-writes the features)",
+                         "kernel": "mfcc_stream512_kernel<..., CM = 1> (the wave that walked an utterance sums its columns and rescales its own rows through L2; batches with multi-chunk utterances take cmvn_kernel instead)",
                          "kernel_ms": r_ms, "algorithmic_bytes_per_launch": r_bytes, "bytes_per_frame": tables.cfg.hop * 4 + rplan.d_out * 4}}
         del rplan, rfeat
 
@@ -412,8 +485,8 @@ def main():
             for _ in range(g_steps):
                 r = scorer.score(feats, fseg, precision=precision, timing=True)
                 gms.append(r["kernel_ms"])
-                decisions = torch.stack([r["argmax"].to(torch.float32), r["scores"][:, 0]], dim=1)
-                gathered = all_gather_rows(decisions)  # RCCL all-gather of the compact per-utterance result
+                # RCCL all-gather of the compact per-utterance record (int32 argmax, fp32 best, fp32 ubm): 12 B per utterance
+                gathered = all_gather_rows(decision_records(r))
             torch.cuda.synchronize()
             barrier()
             g_elapsed = max_over_ranks(time.perf_counter() - t0, device)
@@ -424,7 +497,8 @@ def main():
         result["gmm"] = {
             "metric": "GMM frame-scores/s (diag, K=%d, D=%d, %d models)" % (K, D, S + 1),
             "value": fscores / g_elapsed, "unit": "frame-scores/s", "ms_per_step": g_elapsed / g_steps * 1e3,
-            "steps": g_steps, "dtype": "f32", "gathered_rows": n_gath,
+            "steps": g_steps, "dtype": "f32", "gathered_rows": n_gath, "record_bytes": 12,
+            "record": "(int32 argmax, fp32 best score - ubm, fp32 ubm) per utterance, one all-gather",
             "config": {"workload": "configs[2]: the MFCC stream above vs 64-mix diag UBM + 50 speaker GMMs"},
             "roofline": {"bound": "mfma", "achieved": flop / (g_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": flop / (g_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
@@ -481,7 +555,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             r4 = scorer4.score(feats[:f4], seg4, precision=prec, timing=True)
-            gathered = all_gather_rows(torch.stack([r4["argmax"].to(torch.float32), r4["scores"][:, 0]], dim=1))
+            gathered = all_gather_rows(decision_records(r4))
             torch.cuda.synchronize()
             barrier()
             dt4 = max_over_ranks(time.perf_counter() - t0, device)
@@ -498,6 +572,42 @@ def main():
             "frames_per_gpu": f4, "full_config_utterances_per_gpu": 150000, "fraction_of_full_config": u4 / 150000.0,
             "measured_s_for_this_sample": {t: out4[t]["kernel_ms"] * 1e-3 for t in out4},
             "extrapolated_full_config_s_per_gpu": {t: 150000.0 / u4 * out4[t]["kernel_ms"] * 1e-3 for t in out4}, **out4}
+        # ---- configs[3]'s FULL per-GPU share, measured: 150 000 utterances x 298 frames against the 1252 models on the bf16x3 path with
+        # fp32 re-scoring of close calls (the fp32 path would take ~35 s per GPU: it stays a 12 000-utterance sample above).  The 50 000
+        # utterances beyond the resident configs[1] batch are synthesised and run through the same MFCC plan here, outside the timing.
+        if args.gmm4_full and n_utt >= 100000 and n_samp == 48000:
+            U_full = 150000
+            extra = U_full - n_utt
+            T_utt = int(fseg.offsets[1])
+            feats_full = torch.empty((U_full * T_utt, plan.d_out), dtype=torch.float32, device=device)
+            feats_full[:n_frames] = feats
+            if extra > 0:
+                audio_x = synth_audio_device(torch, extra, n_samp, fs, seed=4321 + rank, device=device)
+                seg_x = api.Segments.from_lengths(ctx, np.full(extra, n_samp, dtype=np.int64))
+                fseg_x = plan.frame_segments(seg_x)
+                plan.run(audio_x.view(-1), seg_x, fseg_x, out=feats_full[n_frames:], variant=args.variant)
+                torch.cuda.synchronize()
+                del audio_x
+            seg_full = api.Segments.from_lengths(ctx, np.full(U_full, T_utt, dtype=np.int64))
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rf = scorer4.score(feats_full, seg_full, precision=1, timing=True)
+            gathered = all_gather_rows(decision_records(rf))
+            torch.cuda.synchronize()
+            barrier()
+            dtf = max_over_ranks(time.perf_counter() - t0, device)
+            ff = U_full * T_utt
+            flopf = 4.0 * D * K * ff * (S + 1)
+            result["gmm_cfg3_shape"]["bf16x3_full_share"] = {
+                "metric": "configs[3] per-GPU share, measured whole: %d utterances x %d frames vs 512-mix UBM + 1251 speaker models" % (U_full, T_utt),
+                "utterances_per_gpu": U_full, "frames_per_gpu": ff, "fraction_of_full_config": 1.0,
+                "measured_s": dtf, "kernel_s": rf["kernel_ms"] * 1e-3, "value": ff * (S + 1) * world / dtf, "unit": "frame-scores/s",
+                "tflops_algorithmic": flopf / (rf["kernel_ms"] * 1e-3) / 1e12, "frac_of_bf16_peak": flopf / (rf["kernel_ms"] * 1e-3) / 1e12 / 2500.0,
+                "utterances_rescored_in_fp32": int(scorer4.last_rescored), "gathered_rows": int(gathered.shape[0]),
+                "argmax_mismatches_vs_fp32_sample": int((am4 != rf["argmax"][:u4]).sum().item()), "fp32_sample_utterances": u4,
+                "dtype": "bf16x3->f32"}
+            del feats_full, rf
         del scorer4, r4
 
     # ------------------------------------------------------------------ cosine stage (configs[4])
@@ -549,7 +659,13 @@ def main():
         dt = time.perf_counter() - t0
         result["gmm_em"] = {"metric": "GMM EM iteration (E step + M sums), frames/s (K=%d, D=%d)" % (K, D), "value": n_em / dt,
                             "unit": "frames/s", "kernel_ms": r["kernel_ms"], "frames": n_em,
-                            "tflops": 12.0 * D * K * n_em / r["kernel_ms"] / 1e9, "dtype": "f32"}
+                            "tflops": 12.0 * D * K * n_em / r["kernel_ms"] / 1e9, "dtype": "f32",
+                            "roofline": {"bound": "mfma", "achieved": 12.0 * D * K * n_em / r["kernel_ms"] / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                         "frac": 12.0 * D * K * n_em / r["kernel_ms"] / 1e9 / MFMA_F32_PEAK_TF, "traffic": None,
+                                         "kernel": "gmm_em_lse_kernel + gmm_em_acc_kernel + gmm_em_reduce_kernel (v_mfma_f32_32x32x2_f32)",
+                                         "kernel_ms": r["kernel_ms"],
+                                         "algorithmic_flop_per_launch": 12.0 * D * K * n_em,
+                                         "flop_per_frame": "12 D K: log-probability 4 D K (two D x K multiply-adds) + responsibility-weighted sums of x and x^2 8 D K"}}
     if "dnn" in stages:
         # the reference's fully connected d-vector network (d_vector.py:171-189) as one packed object: input layer (1274 -> 256) on the
         # tiled MFMA GEMM, the three following layers chained inside one kernel with the activations kept in registers
@@ -615,7 +731,10 @@ def main():
         api.dtw_distances(ctx, Q[:4], T[:4])
         _, ms = api.dtw_distances(ctx, Q, T, timing=True)
         result["dtw"] = {"metric": "DTW matcher, pairs/s (1222-element flattened MFCC sequences)", "value": nq * nt / ms * 1e3,
-                         "unit": "pairs/s", "kernel_ms": ms, "cell_updates_per_s": nq * nt * L * L / ms * 1e3, "dtype": "f32"}
+                         "unit": "pairs/s", "kernel_ms": ms, "cell_updates_per_s": nq * nt * L * L / ms * 1e3, "dtype": "f32",
+                         "roofline": {"bound": "valu", "achieved": 4.0 * nq * nt * L * L / ms / 1e9, "peak": MFMA_F32_PEAK_TF / 2, "unit": "Tops/s",
+                                      "frac": 4.0 * nq * nt * L * L / ms / 1e9 / (MFMA_F32_PEAK_TF / 2), "traffic": None, "kernel": "dtw_kernel",
+                                      "kernel_ms": ms, "ops_per_cell": "4 (|x - y|, two mins, one add): not FMA work, so the peak is half the fp32 vector FLOP rate"}}
 
     if "plp" in stages:
         # PLP features (sidekit plp): Bark front end through the MFCC pass (the wave-stream kernel's dense-band instance) + RASTA /
@@ -655,6 +774,14 @@ def main():
             result["gmm"]["cpu_baseline_reference_loop"] = cpu_baseline_gmm_loop(plan.d_out, 64, 50)
         if "cosine" in result:
             result["cosine"]["cpu_baseline"] = cpu_baseline_cosine(256, 1251)
+        if "gmm_em" in result:
+            result["gmm_em"]["cpu_baseline"] = cpu_baseline_em(plan.d_out, 64)
+        if "dvector_dnn" in result:
+            result["dvector_dnn"]["cpu_baseline"] = cpu_baseline_dnn([1274, 256, 256, 256, 256])
+        if "dtw" in result:
+            result["dtw"]["cpu_baseline"] = cpu_baseline_dtw(1222)
+        if "plp" in result:
+            result["plp"]["cpu_baseline"] = cpu_baseline_plp(n_samp, fs)
     try:  # how the shipped libsspgpu.so came to be (speech_signal_processing_amd/build.py records it)
         result["build"] = {k: v for k, v in json.load(open(os.path.join(ROOT, "speech_signal_processing_amd", "build_info.json"))).items()
                            if k in ("build_mode", "compiled_sources", "lib_bytes")}

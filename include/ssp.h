@@ -21,13 +21,14 @@
 #ifndef SSP_H_
 #define SSP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define SSP_ABI_VERSION 1
+#define SSP_ABI_VERSION 2 /* 2: ssp_comm_* / ssp_allgather / ssp_allreduce_sum; ssp_gmm_score precision = 1 re-scores close calls in fp32 (host sync) */
 
 typedef enum {
     SSP_OK = 0,
@@ -83,6 +84,30 @@ int ssp_ctx_destroy(ssp_ctx* ctx);
  * deterministically in the parity tests instead of depending on what the previous kernel left behind */
 int ssp_debug_poison_lds(ssp_ctx* ctx, uint32_t pattern);
 int ssp_ctx_sync(ssp_ctx* ctx);
+/* ordering against another stream of the same device without a host wait (a ctx that owns its stream, called with device pointers
+ * produced / consumed on the caller's stream): wait = the ctx stream waits for everything queued on other_stream so far;
+ * signal = other_stream waits for everything queued on the ctx stream so far.  other_stream: hipStream_t (NULL = the default stream) */
+int ssp_ctx_wait_stream(ssp_ctx* ctx, void* other_stream);
+int ssp_ctx_signal_stream(ssp_ctx* ctx, void* other_stream);
+
+/* ---- collectives (multi-GPU: one process and one ctx per GPU) ----------
+ * Utterances shard across ranks with no data-path collective (GMM_UBM.py:183-197 and d_vector.py:315-318 have no cross-utterance
+ * term); models / centroids are replicated.  The one exchange step is the all-gather of the per-utterance decision records after
+ * scoring — (int32 argmax, float best, float ubm) = 12 bytes per utterance.  RCCL (rings over xGMI inside a node) is loaded at
+ * run time the first time a communicator is asked for; a ctx without a communicator is a world of one.
+ *   rank 0: ssp_comm_unique_id(id) -> ship the 128 bytes to every rank (file, socket, MPI, torch store: the caller's transport)
+ *   every rank: ssp_comm_init(ctx, rank, nranks, id)    (blocks until all ranks have called it)
+ *   ssp_allgather(ctx, send, recv, bytes): DEVICE pointers; recv holds nranks * bytes, rank r's block at r * bytes; asynchronous on
+ *   the ctx stream (ssp_ctx_sync before the host reads recv).  Ragged shards: gather the counts first, then padded blocks.
+ *   ssp_allreduce_sum(ctx, buf, count, is_f64): in-place sum of float / double DEVICE arrays (centroid sums d_vector.py:310-313,
+ *   EM sufficient statistics over utterance shards). */
+#define SSP_COMM_ID_BYTES 128
+int ssp_comm_unique_id(void* id_out /* HOST byte[128] */);
+int ssp_comm_init(ssp_ctx* ctx, int rank, int nranks, const void* unique_id /* HOST byte[128] */);
+int ssp_comm_destroy(ssp_ctx* ctx); /* (also done by ssp_ctx_destroy) */
+int ssp_comm_info(const ssp_ctx* ctx, int* rank, int* nranks);
+int ssp_allgather(ssp_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
+int ssp_allreduce_sum(ssp_ctx* ctx, void* buf, size_t count, int is_f64);
 
 /* ---- segments: per-utterance offsets (host metadata -> device-resident) ------------- */
 /* offsets: HOST int64[n_seg+1], non-decreasing, offsets[0] >= 0. */

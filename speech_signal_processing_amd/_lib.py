@@ -9,6 +9,8 @@ LIB_PATH = os.environ.get("SSP_LIB_PATH") or os.path.join(HERE, "libsspgpu.so") 
 
 SSP_OK, SSP_ERR_INVALID, SSP_ERR_UNSUPPORTED, SSP_ERR_HIP, SSP_ERR_NOMEM, SSP_ERR_NODEVICE = 0, -1, -2, -3, -4, -5
 HOST, DEVICE = 0, 1
+ABI_VERSION = 2
+COMM_ID_BYTES = 128
 
 
 class SspError(RuntimeError):
@@ -40,6 +42,14 @@ SIGNATURES = {
     "ssp_ctx_destroy": (C.c_int, [_P]),
     "ssp_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
     "ssp_ctx_sync": (C.c_int, [_P]),
+    "ssp_ctx_wait_stream": (C.c_int, [_P, _P]),
+    "ssp_ctx_signal_stream": (C.c_int, [_P, _P]),
+    "ssp_comm_unique_id": (C.c_int, [_P]),
+    "ssp_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "ssp_comm_destroy": (C.c_int, [_P]),
+    "ssp_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ssp_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "ssp_allreduce_sum": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
     "ssp_segments_create": (C.c_int, [_P, _I64P, C.c_int64, C.POINTER(_P)]),
     "ssp_segments_destroy": (C.c_int, [_P]),
     "ssp_segments_count": (C.c_int, [_P, _I64P, _I64P]),
@@ -94,8 +104,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.ssp_abi_version() != 1:
-        raise ImportError("libsspgpu.so ABI version %d != 1" % lib.ssp_abi_version())
+    if lib.ssp_abi_version() != ABI_VERSION:
+        raise ImportError("libsspgpu.so ABI version %d != %d (rebuild: python -m speech_signal_processing_amd.build)" % (lib.ssp_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

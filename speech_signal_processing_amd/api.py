@@ -6,6 +6,7 @@ results stay on the device).  PyTorch is used only for device memory and streams
 from __future__ import annotations
 
 import contextlib
+import os
 
 import ctypes as C
 from typing import Optional, Sequence
@@ -59,17 +60,68 @@ class Context:
     def _ordered(self, where):
         """Stream ordering around a call that takes device pointers.  A context that BORROWS torch's stream needs none (the kernels
         are queued behind the producers of their inputs and ahead of the consumers of their outputs).  A context that owns its
-        stream is ordered against nothing torch does, so device-pointer calls on it wait for torch's current stream first and are
-        complete when they return."""
+        stream is ordered against nothing torch does, so around a device-pointer call its stream first waits for torch's current
+        stream and torch's current stream then waits for it — two events, no host wait (ssp_ctx_wait_stream / _signal_stream): calls
+        on different owned-stream contexts overlap, and the host runs ahead as it does with torch's own kernels."""
         own = where == _lib.DEVICE and self.stream is None
+        ts = None
+        host_sync = own and bool(os.environ.get("SSP_ORDER_SYNC"))  # (diagnostic: host waits on both sides, as before round 3)
         if own:
             import torch
-            torch.cuda.current_stream(self.device).synchronize()
+            if host_sync:
+                torch.cuda.current_stream(self.device).synchronize()
+            else:
+                ts = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                _lib.check(self._lib.ssp_ctx_wait_stream(self._h, ts))
         try:
             yield
         finally:
             if own:
-                self.sync()
+                if host_sync:
+                    self.sync()
+                else:
+                    _lib.check(self._lib.ssp_ctx_signal_stream(self._h, ts))
+
+    # ---- collectives (include/ssp.h: ssp_comm_*): one process and one Context per GPU
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 opaque bytes made on rank 0; ship them to every rank (any transport) and pass them to comm_init."""
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.load().ssp_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank: int, nranks: int, unique_id: bytes):
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % _lib.COMM_ID_BYTES)
+        _lib.check(self._lib.ssp_comm_init(self._h, int(rank), int(nranks), C.c_char_p(unique_id)))
+
+    def comm_destroy(self):
+        _lib.check(self._lib.ssp_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, n = C.c_int(), C.c_int()
+        _lib.check(self._lib.ssp_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def allgather(self, local):
+        """All-gather of equally shaped device tensors: returns [nranks * local.shape[0], ...] in rank order (RCCL over xGMI)."""
+        import torch
+        local = local.contiguous()
+        _, n = self.comm_info()
+        out = torch.empty((n * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        with self._ordered(_lib.DEVICE):
+            _lib.check(self._lib.ssp_allgather(self._h, C.c_void_p(local.data_ptr()), C.c_void_p(out.data_ptr()),
+                                               C.c_size_t(local.numel() * local.element_size())))
+        return out
+
+    def allreduce_sum_(self, t):
+        """In-place sum over ranks of a float32 / float64 device tensor."""
+        import torch
+        if t.dtype not in (torch.float32, torch.float64) or not t.is_contiguous():
+            raise ValueError("allreduce_sum_ takes a contiguous float32 / float64 device tensor")
+        with self._ordered(_lib.DEVICE):
+            _lib.check(self._lib.ssp_allreduce_sum(self._h, C.c_void_p(t.data_ptr()), C.c_size_t(t.numel()), int(t.dtype == torch.float64)))
+        return t
 
     def close(self):
         if getattr(self, "_h", None):

@@ -115,6 +115,10 @@ struct ssp_ctx {
     // grow-only device scratch shared by the entry points that are called in a loop (one EM iteration per call): a ctx is
     // not thread-safe and its work is ordered on one stream, so consecutive calls may reuse the same buffers
     ssp::DevBuf scratch[6];
+    // RCCL communicator of this ctx (comm.hip; null = a world of one)
+    void* comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+    hipEvent_t order_ev[2] = {nullptr, nullptr};  // ssp_ctx_wait_stream / ssp_ctx_signal_stream
 };
 
 struct ssp_segments {
@@ -139,6 +143,11 @@ static inline int use_ctx(const ssp_ctx* ctx) {
     return SSP_OK;
 }
 int segments_make(ssp_ctx* ctx, const int64_t* offsets, int64_t n, ssp_segments** out);
+// Handles (plans, scorers, networks, segments) keep a pointer to their ctx and may be destroyed AFTER it (garbage collectors run
+// finalizers of dead object groups in any order — CPython at interpreter exit does).  Their destroy functions call this instead of
+// touching the ctx: it waits for the ctx's stream when the ctx is still alive and does nothing when it is gone (ssp_ctx_destroy
+// has already drained the stream); device buffers are then freed without reference to the ctx.
+void quiesce_ctx(const ssp_ctx* ctx);
 
 // Staging helper for SSP_HOST calls: device copy of a host input / device scratch for an output.
 struct Staged {

@@ -5,10 +5,15 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_set>
 
 namespace ssp {
 
 static thread_local char g_err[512] = "";
+
+void ctx_register(const ssp_ctx* c);
+void ctx_unregister(const ssp_ctx* c);
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -53,6 +58,38 @@ TraceRange::TraceRange(const char* name) : on(false) {
 }
 TraceRange::~TraceRange() {
     if (on) roctx().pop();
+}
+
+// ---- registry of live contexts (see quiesce_ctx in common.hpp)
+namespace {
+std::mutex g_live_mu;
+std::unordered_set<const ssp_ctx*>& live_set() {
+    static auto* s = new std::unordered_set<const ssp_ctx*>;  // (never destroyed: handles may be finalized during process exit)
+    return *s;
+}
+}  // namespace
+void ctx_register(const ssp_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    live_set().insert(c);
+}
+void ctx_unregister(const ssp_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    live_set().erase(c);
+}
+// hipStreamSynchronize on a stream its owner has already destroyed (a borrowed stream at process exit) does not return an error on
+// ROCm 7.2 — it throws std::bad_variant_access out of the C API; nothing may escape a destroy function
+static void sync_quietly(hipStream_t s) {
+    try {
+        (void)hipStreamSynchronize(s);
+    } catch (...) {
+    }
+}
+void quiesce_ctx(const ssp_ctx* ctx) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (!live_set().count(ctx)) return;
+    (void)hipSetDevice(ctx->device);
+    sync_quietly(ctx->stream);
 }
 
 int segments_make(ssp_ctx* ctx, const int64_t* offsets, int64_t n, ssp_segments** out) {
@@ -144,14 +181,19 @@ int ssp_ctx_create(int device, void* stream, int borrow_stream, ssp_ctx** out) {
         }
         c->owns_stream = true;
     }
+    ssp::ctx_register(c);
     *out = c;
     return SSP_OK;
 }
 
 int ssp_ctx_destroy(ssp_ctx* ctx) {
     if (!ctx) return SSP_OK;
+    ssp::ctx_unregister(ctx);
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    ssp::sync_quietly(ctx->stream);
+    (void)ssp_comm_destroy(ctx);
+    for (hipEvent_t& ev : ctx->order_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SSP_OK;
@@ -163,13 +205,34 @@ int ssp_ctx_sync(ssp_ctx* ctx) {
     return SSP_OK;
 }
 
+// stream ordering without a host wait: an event recorded on one stream, waited for by the other.  One event per ctx and direction,
+// created on first use and destroyed with the ctx (an event may be recorded again once the wait that used it has been queued)
+static int order_streams(ssp_ctx* ctx, int which, hipStream_t first, hipStream_t then) {
+    if (first == then) return SSP_OK;
+    hipEvent_t& ev = ctx->order_ev[which];
+    if (!ev) SSP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    SSP_HIP(hipEventRecord(ev, first));
+    SSP_HIP(hipStreamWaitEvent(then, ev, 0));
+    return SSP_OK;
+}
+
+int ssp_ctx_wait_stream(ssp_ctx* ctx, void* other_stream) {
+    SSP_TRY(ssp::use_ctx(ctx));
+    return order_streams(ctx, 0, static_cast<hipStream_t>(other_stream), ctx->stream);
+}
+
+int ssp_ctx_signal_stream(ssp_ctx* ctx, void* other_stream) {
+    SSP_TRY(ssp::use_ctx(ctx));
+    return order_streams(ctx, 1, ctx->stream, static_cast<hipStream_t>(other_stream));
+}
+
 int ssp_segments_create(ssp_ctx* ctx, const int64_t* offsets, int64_t n_seg, ssp_segments** out) {
     return ssp::segments_make(ctx, offsets, n_seg, out);
 }
 
 int ssp_segments_destroy(ssp_segments* seg) {
     if (!seg) return SSP_OK;
-    if (seg->ctx) (void)hipSetDevice(seg->ctx->device);
+    ssp::quiesce_ctx(seg->ctx);
     delete seg;
     return SSP_OK;
 }

@@ -232,10 +232,7 @@ int ssp_dnn_create(ssp_ctx* ctx, int32_t n_layers, const int32_t* dims, const fl
 
 int ssp_dnn_destroy(ssp_dnn* dnn) {
     if (!dnn) return SSP_OK;
-    if (dnn->ctx) {
-        (void)hipSetDevice(dnn->ctx->device);
-        (void)hipStreamSynchronize(dnn->ctx->stream);
-    }
+    ssp::quiesce_ctx(dnn->ctx);  // (the ctx may already be gone: common.hpp)
     delete dnn;
     return SSP_OK;
 }

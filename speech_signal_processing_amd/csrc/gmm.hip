@@ -792,10 +792,7 @@ int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const dou
 
 int ssp_gmm_destroy(ssp_gmm* gmm) {
     if (!gmm) return SSP_OK;
-    if (gmm->ctx) {
-        (void)hipSetDevice(gmm->ctx->device);
-        (void)hipStreamSynchronize(gmm->ctx->stream);
-    }
+    ssp::quiesce_ctx(gmm->ctx);  // (the ctx may already be gone: common.hpp)
     delete gmm;
     return SSP_OK;
 }

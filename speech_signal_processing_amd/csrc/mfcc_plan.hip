@@ -394,10 +394,7 @@ int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* win
 
 int ssp_mfcc_plan_destroy(ssp_mfcc_plan* plan) {
     if (!plan) return SSP_OK;
-    if (plan->ctx) {
-        (void)hipSetDevice(plan->ctx->device);
-        (void)hipStreamSynchronize(plan->ctx->stream);
-    }
+    ssp::quiesce_ctx(plan->ctx);  // (the ctx may already be gone: common.hpp)
     delete plan;
     return SSP_OK;
 }

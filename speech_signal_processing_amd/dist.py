@@ -40,12 +40,13 @@ def balanced_shards(lengths: Sequence[int], world: int) -> List[Tuple[int, int]]
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def all_gather_rows(local, group=None):
+def all_gather_rows(local, group=None, force=False):
     """All-gather per-utterance result rows (torch tensor, first dim = this rank's utterances; ragged across ranks).
-    Returns the concatenation in rank order on every rank.  One size exchange + one padded all_gather."""
+    Returns the concatenation in rank order on every rank.  One size exchange + one padded all_gather.
+    force: run the collectives even in a world of one (tests: the RCCL path on a one-GPU box)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     home = local.device
@@ -63,10 +64,44 @@ def all_gather_rows(local, group=None):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0).to(home)
 
 
-def max_over_ranks(value: float, device=None) -> float:
+def pack_records(argmax, best, ubm):
+    """SURVEY.md 8(e)'s compact per-utterance decision record — (int32 argmax, fp32 best, fp32 ubm), 12 bytes — as ONE int32 [n, 3]
+    tensor (the two floats travel as their bit patterns): one collective moves all three columns."""
+    import torch
+    n = argmax.shape[0]
+    rec = torch.empty((n, 3), dtype=torch.int32, device=argmax.device)
+    rec[:, 0] = argmax.to(torch.int32)
+    rec[:, 1] = best.to(torch.float32).contiguous().view(torch.int32)
+    rec[:, 2] = ubm.to(torch.float32).contiguous().view(torch.int32)
+    return rec
+
+
+def unpack_records(rec):
+    """-> (argmax int32 [n], best float32 [n], ubm float32 [n])"""
+    import torch
+    return rec[:, 0].contiguous(), rec[:, 1].contiguous().view(torch.float32), rec[:, 2].contiguous().view(torch.float32)
+
+
+def decision_records(result):
+    """Records of a GmmScorer.score result: argmax over the speaker models of (score - UBM score), that best difference (the
+    reference's pred[j, argmax], GMM_UBM.py:185), and the UBM's mean log-likelihood."""
+    import torch
+    sc, am = result["scores"], result["argmax"].to(torch.int64)
+    ubm = sc[:, 0]
+    best = sc.gather(1, (am + 1)[:, None])[:, 0] - ubm
+    return pack_records(am, best, ubm)
+
+
+def all_gather_records(argmax, best, ubm, group=None):
+    """All-gather of the decision records of this rank's utterances (ragged across ranks); every rank gets the three columns
+    of ALL utterances in rank order."""
+    return unpack_records(all_gather_rows(pack_records(argmax, best, ubm), group=group))
+
+
+def max_over_ranks(value: float, device=None, force=False) -> float:
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -87,3 +87,65 @@ def test_two_rank_gather_gloo():
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res)
     assert all(r[2] == 2.0 for r in res)
+
+
+def test_decision_records_round_trip():
+    """(int32 argmax, fp32 best, fp32 ubm) packed into one int32 [n, 3] tensor: bit-exact round trip, including -inf / NaN scores."""
+    import torch
+    from speech_signal_processing_amd.dist import decision_records, pack_records, unpack_records
+    am = torch.tensor([0, 1250, 7, 3], dtype=torch.int32)
+    best = torch.tensor([1.5, -0.0, float("-inf"), float("nan")])
+    ubm = torch.tensor([-70.25, -1e-30, 3.0, float("inf")])
+    rec = pack_records(am, best, ubm)
+    assert rec.dtype == torch.int32 and rec.shape == (4, 3) and rec.element_size() * rec.shape[1] == 12
+    a, b, u = unpack_records(rec)
+    assert torch.equal(a, am)
+    assert torch.equal(b.view(torch.int32), best.view(torch.int32)) and torch.equal(u.view(torch.int32), ubm.view(torch.int32))
+    # from a scorer result: argmax over speakers of (score - ubm), that difference, the ubm score
+    sc = torch.tensor([[-50.0, -49.0, -48.5, -51.0], [-60.0, -59.0, -61.0, -62.0]])
+    r = {"scores": sc, "argmax": (sc[:, 1:] - sc[:, :1]).argmax(1).to(torch.int32)}
+    a, b, u = unpack_records(decision_records(r))
+    assert a.tolist() == [1, 0] and b.tolist() == [1.5, 1.0] and u.tolist() == [-50.0, -60.0]
+
+
+def _worker8(rank, world, port, q, lens):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from speech_signal_processing_amd.dist import all_gather_records, balanced_shards, shard_range
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for shards in ([shard_range(len(lens), r, world) for r in range(world)], balanced_shards(lens, world)):
+            lo, hi = shards[rank]
+            # the record of utterance u is a function of u alone, so every rank can check every row it receives
+            u = torch.arange(lo, hi, dtype=torch.int64)
+            a, b, m = all_gather_records((u % 1251).to(torch.int32), u.to(torch.float32) * 0.5 - 3.0, -(u.to(torch.float32)) - 70.0)
+            U = torch.arange(len(lens), dtype=torch.int64)
+            ok = ok and a.shape[0] == len(lens) and a.dtype == torch.int32 and b.dtype == torch.float32
+            ok = ok and torch.equal(a, (U % 1251).to(torch.int32)) and torch.equal(b, U.to(torch.float32) * 0.5 - 3.0) and torch.equal(m, -(U.to(torch.float32)) - 70.0)
+        q.put((rank, bool(ok), int(a.shape[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_record_gather_gloo():
+    """The configs[3] exchange step rehearsed at the driver's largest world size: 8 ranks (gloo, CPU), utterances cut by count and by
+    frames (ragged: some ranks get different numbers of rows), one all-gather of the 12-byte records, every rank ends with every
+    utterance's record in utterance order."""
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(3)
+    lens = [int(v) for v in rng.integers(1, 900, 2403)]  # 8 does not divide 2403; frame-balanced cuts are ragged
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q, lens)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(8)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(8))
+    assert all(r[1] for r in res) and all(r[2] == len(lens) for r in res)

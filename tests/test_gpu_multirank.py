@@ -35,3 +35,104 @@ def test_bench_two_ranks_hip_scorer():
     assert r["value"] > 0 and r["gmm"]["value"] > 0
     # weak scaling bookkeeping: the whole-job frame count is both ranks' frames
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 2 * r["config"]["frames_per_gpu"]) <= 1e-6 * 2 * r["config"]["frames_per_gpu"]
+
+
+def test_bench_four_ranks_rehearsal_ragged_gather():
+    """More ranks than any earlier run: 4 ranks (the most a one-GPU box's process guard leaves room for next to the launcher), 300
+    utterances each; one JSON line from rank 0, every utterance's 12-byte decision record gathered on every rank."""
+    import torch
+    env = dict(os.environ)
+    n = 4
+    if torch.cuda.device_count() < n:
+        env["SSP_BENCH_REHEARSE"] = "1"
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--utts", "300", "--steps", "2", "--warmup", "1",
+           "--stages", "mfcc,gmm", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == n and r["config"]["world_size_observed"] == n and len(r["config"]["kernel_ms_per_rank"]) == n
+    assert r["gmm"]["gathered_rows"] == n * 300 and r["gmm"]["record_bytes"] == 12
+    assert r["scaling"] == "weak" and r["value"] > 0
+
+
+def _comm_worker(rank, world, idfile, q):
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    from speech_signal_processing_amd import api
+    torch.cuda.set_device(rank)
+    ctx = api.Context.for_torch(rank)
+    if rank == 0:
+        uid = api.Context.comm_unique_id()
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(idfile + ".tmp", idfile)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            if time.time() - t0 > 120:
+                raise TimeoutError("no unique id")
+            time.sleep(0.05)
+        uid = open(idfile, "rb").read()
+    ctx.comm_init(rank, world, uid)
+    local = torch.full((5, 3), rank + 1, dtype=torch.int32, device="cuda:%d" % rank)
+    full = ctx.allgather(local)
+    s = ctx.allreduce_sum_(torch.full((7,), float(rank + 1), dtype=torch.float64, device="cuda:%d" % rank))
+    torch.cuda.synchronize()
+    exp = torch.cat([torch.full((5, 3), r + 1, dtype=torch.int32) for r in range(world)])
+    q.put((rank, bool(torch.equal(full.cpu(), exp)), float(s[0].item()), ctx.comm_info()))
+    ctx.comm_destroy()
+
+
+def test_cabi_communicator_world_of_one_and_two():
+    """ssp_comm_* / ssp_allgather / ssp_allreduce_sum (RCCL resolved inside libsspgpu.so at run time).  A world of one always runs
+    (communicator creation, the gather and the sum through RCCL on this GPU); with two devices visible two processes exchange the
+    unique id through a file and gather / reduce across both GPUs."""
+    import torch
+    from speech_signal_processing_amd import api
+    ctx = api.Context.for_torch(0)
+    x = torch.arange(12, dtype=torch.int32, device="cuda").reshape(4, 3)
+    assert ctx.comm_info() == (0, 1)
+    assert torch.equal(ctx.allgather(x), x)            # no communicator: a copy
+    ctx.comm_init(0, 1, api.Context.comm_unique_id())
+    assert ctx.comm_info() == (0, 1)
+    assert torch.equal(ctx.allgather(x), x)            # through ncclAllGather
+    t = torch.full((9,), 2.5, dtype=torch.float32, device="cuda")
+    assert torch.equal(ctx.allreduce_sum_(t), torch.full((9,), 2.5, device="cuda"))
+    with pytest.raises(ValueError):
+        ctx.comm_init(0, 1, api.Context.comm_unique_id())  # one communicator per ctx
+    ctx.comm_destroy()
+    if torch.cuda.device_count() >= 2:
+        import tempfile
+        import torch.multiprocessing as mp
+        mpc = mp.get_context("spawn")
+        q = mpc.Queue()
+        idfile = os.path.join(tempfile.mkdtemp(), "uid")
+        procs = [mpc.Process(target=_comm_worker, args=(r, 2, idfile, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=300) for _ in range(2)]
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        assert all(r[1] and r[2] == 3.0 for r in res) and sorted(r[3] for r in res) == [(0, 2), (1, 2)]
+
+
+def test_nccl_backend_collectives_in_a_world_of_one():
+    """The RCCL ("nccl") branch of the bench's collectives on a one-GPU box: launched exactly as the driver launches ranks
+    (torch.distributed.run as a child), process group bound to the device, barrier + ragged record gather + max over ranks on
+    device tensors."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29671", os.path.join(ROOT, "tests", "_nccl_world1.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r == {"ok": True, "backend": "nccl", "rows": 37, "max": 1.25}
