@@ -83,10 +83,13 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
 #ifndef SSP_STREAM_NTW
 #define SSP_STREAM_NTW 13  // resident twiddles W_256^(k1 j), k1 <= NTW (the largest sets that leave no spill inside the loop; a spill
 #endif                     // reload there waits on vmcnt behind the sample DMA and exposes its whole latency every quad)
+#ifndef SSP_STREAM_NTW_CM
+#define SSP_STREAM_NTW_CM 9   // ... of the instances that also carry the column sums of the scaling (CM)
+#endif
 #ifndef SSP_STREAM_NWP
 #define SSP_STREAM_NWP 8   // resident split twiddles
 #endif
-    constexpr int NTW = OCC >= 3 ? ((MELV <= 3 && NS <= 2) ? SSP_STREAM_NTW : ((MELV >= 4 && NS >= 4) ? 8 : 10)) : 15, NWP = OCC >= 3 ? SSP_STREAM_NWP : 8;
+    constexpr int NTW = OCC >= 3 ? (CM ? SSP_STREAM_NTW_CM : ((MELV <= 3 && NS <= 2) ? SSP_STREAM_NTW : ((MELV >= 4 && NS >= 4) ? 8 : 10))) : 15, NWP = OCC >= 3 ? SSP_STREAM_NWP : 8;
     v2f twr[NTW], wpr[NWP];
 #pragma unroll
     for (int k1 = 1; k1 <= NTW; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
@@ -191,7 +194,12 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         }
         prefetch(0);
         int stores_pending = 0;  // buffer stores issued behind the DMA that is waited for at the top of the next iteration
-        double cs1[CM ? 3 : 1] = {}, cs2[CM ? 3 : 1] = {};  // CM: sums of this lane's stored values per block (column = lane & 15)
+        // CM: sums of this lane's stored values per block (column = lane & 15), fp32: a lane adds ~T / 4 terms, and the cepstra are
+        // summed relative to a pivot — the utterance's first frame — so that var = E[(x - p)^2] - E[x - p]^2 does not cancel when a
+        // column's mean is large against its spread (delta / delta-delta columns have no mean to speak of: pivot 0).  The four lane
+        // groups meet in float64 at the end.  (float64 sums cost 12 VGPRs and the third wave per SIMD; these cost 7.)
+        float cs1[CM ? 3 : 1] = {}, cs2[CM ? 3 : 1] = {};
+        float piv = 0.f;
 
         // ---- the phases of one quad (lambdas: the dense-band instance runs them in sequence, every other instance software-pipelined)
         // (z / pf / pm are declared inside the loop bodies: declared out here they would be loop-carried through the wave-uniform branches
@@ -469,11 +477,12 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, off, 0, 0);
 #endif
                 if (CM) {
-                    const double dv = off != 0x7ffffff0 ? (double)v : 0.0;
+                    const float dv = off != 0x7ffffff0 ? (blk == 0 ? v - piv : v) : 0.f;
                     cs1[CM ? blk : 0] += dv;
-                    cs2[CM ? blk : 0] = __builtin_fma(dv, dv, cs2[CM ? blk : 0]);
+                    cs2[CM ? blk : 0] = __builtin_fmaf(dv, dv, cs2[CM ? blk : 0]);
                 }
             };
+            if (CM && b == 0) piv = j < nc ? *reinterpret_cast<const float*>(ring + j * 4) : 0.f;  // cepstra of frame 0 (CM: ta == 0)
             // cepstra of the output rows straight from the ring
             {
                 const int m4 = (rb + 20) % RING_FRAMES;  // (rb - 4) mod 24
@@ -656,13 +665,14 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
 #pragma unroll
             for (int blk = 0; blk < 3; ++blk) {
                 if (blk > dord) break;
-                double a1 = cs1[CM ? blk : 0], a2 = cs2[CM ? blk : 0];
+                double a1 = (double)cs1[CM ? blk : 0], a2 = (double)cs2[CM ? blk : 0];
                 a1 += __shfl_xor(a1, 16);
                 a2 += __shfl_xor(a2, 16);
                 a1 += __shfl_xor(a1, 32);
                 a2 += __shfl_xor(a2, 32);
-                const double mean = a1 / (double)T;
-                const double var = a2 / (double)T - mean * mean;
+                const double m0 = a1 / (double)T;                 // mean of (x - pivot)
+                const double mean = m0 + (blk == 0 ? (double)piv : 0.0);
+                const double var = a2 / (double)T - m0 * m0;
                 double sd = __builtin_sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));  // a negative rounding residue is zero; NaN stays NaN
                 if (sd < 10.0 * 1.1920929e-07) sd = 1.0;                                 // sk: _handle_zeros_in_scale (as cmvn_kernel)
                 if (g == 0 && j < nc) {
@@ -815,8 +825,9 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
     // (measured on the in-repo dialect, 59 KiB per workgroup: 2 x 4 waves per CU with every twiddle resident 8.2 ms; 168-VGPR instances
     //  in 1- / 2- / 3-wave workgroups, 11 / 10 / 9 waves per CU, 9.1 - 9.4 ms)
     const int cm = args.cmvn != 0 ? 1 : 0;  // (the plan only leaves cmvn set when mfcc_stream_fuses_cmvn and every utterance is one chunk)
-    // (the column sums of the scaling instances and the 102 weights per lane of the dense-band instance need the registers)
-    const int occ = (nz == 13 && KS == 6 && lds <= 53248 && !cm && f.melv != 0) ? 3 : 2;
+    // (the 102 weights per lane of the dense-band instance need the registers of two waves per SIMD)
+    // (scaling instances keep three waves per SIMD only where the seven extra registers of the column sums fit without a spill)
+    const int occ = (nz == 13 && KS == 6 && lds <= 53248 && f.melv != 0 && (!cm || (f.melv <= 3 && f.mel_ns <= 2))) ? 3 : 2;
     const int wg_waves = STREAM_WAVES;
     bool launched = false;
 #define SSP_STREAM_CASE(NZ_, PW_, PR_, MV_, KS_, OCC_) SSP_STREAM_CASE_CM(NZ_, PW_, PR_, MV_, KS_, OCC_, 0)
@@ -836,6 +847,7 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * wg_waves), lds, stream, args, f, sa);                             \
         launched = true;                                                                                                \
     }
+    SSP_STREAM_CASE_CM(13, 2, 1, 2, 6, 3, 1) SSP_STREAM_CASE_CM(13, 2, 1, 3, 6, 3, 1)
     SSP_STREAM_CASE_CM(13, 2, 1, 2, 6, 2, 1) SSP_STREAM_CASE_CM(13, 2, 1, 3, 6, 2, 1) SSP_STREAM_CASE_CM(13, 2, 1, 4, 6, 2, 1)
     SSP_STREAM_CASE(13, 2, 1, 0, 6, 2)  // dense bands (the PLP front end)
 #ifdef SSP_FAST_MINIMAL
