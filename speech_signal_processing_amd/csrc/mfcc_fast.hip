@@ -468,8 +468,11 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
             if (4 * rg + 3 < n && u0 >= 4 && u0 + 7 <= T - 1) {
                 const float* cp = scr + (u0 - ta) * 13 + qq;
                 float v[12];
+                // (delta only: the chunk's halo is 2 frames, not 4 — rows u0 - 4, u0 - 3, u0 + 6, u0 + 7 feed the delta-delta alone and
+                //  lie outside this workgroup's scratch slot: for the first / last slot outside the allocation)
+                const bool dd2 = a.delta_order >= 2;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) v[k] = cp[(k - 4) * 13];
+                for (int k = 0; k < 12; ++k) v[k] = (dd2 || (k >= 2 && k < 10)) ? cp[(k - 4) * 13] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float c1 = ((v[5 + i] - v[3 + i]) + 2.f * (v[6 + i] - v[2 + i])) * invd;
@@ -605,8 +608,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                 if (a.delta_order > 0 && 4 * rg + 3 < nr && u0 >= 4 && u0 + 7 <= T - 1) {
                     const float* cp = s_ceps + (size_t)(u0 - ta) * 13 + qq;
                     float v[12];
+                    const bool dd2 = a.delta_order >= 2;  // (delta only: a 2-frame halo, see the direct tail)
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) v[k] = cp[(k - 4) * 13];
+                    for (int k = 0; k < 12; ++k) v[k] = (dd2 || (k >= 2 && k < 10)) ? cp[(k - 4) * 13] : 0.f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float c1 = ((v[5 + i] - v[3 + i]) + 2.f * (v[6 + i] - v[2 + i])) * inv;

@@ -303,50 +303,49 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             {
                 float* P = reinterpret_cast<float*>(zf);
                 float* Pm = P + 144 - j;
-                float pa_prev = 0.f, pb_prev = 0.f;
-                (void)pa_prev;
-                (void)pb_prev;
 #pragma unroll
-                for (int k2 = 0; k2 < 8; ++k2) {
-                    const float sx = z[15 - k2].x, sy = z[15 - k2].y;
-                    const v2f own = z[(16 - k2) & 15];
-                    const float ox = own.x, oy = own.y;
-                    // partner Z[256 - k] from lane 16 - j (lane 0: its own register 16 - k2): row_mirror, then row_shr:1 with `old`
-                    float mx = __builtin_amdgcn_update_dpp(sx, sx, 0x140 /*row_mirror*/, 0xF, 0xF, true);
-                    float my = __builtin_amdgcn_update_dpp(sy, sy, 0x140 /*row_mirror*/, 0xF, 0xF, true);
-                    mx = __builtin_amdgcn_update_dpp(ox, mx, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
-                    my = __builtin_amdgcn_update_dpp(oy, my, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
-                    const v2f zmk = v2f{mx, my};
-                    const v2f zk = z[k2];
-                    v2f w = wpr[k2 < NWP ? k2 : k2 - 4];
-                    if (k2 >= NWP) w = cmulc(w, 0.70710678118654752f, -0.70710678118654752f);  // W_512^64 = W_8
-                    const v2f e = __builtin_elementwise_fma(zmk, v2f{1.f, -1.f}, zk);
-                    const v2f d = __builtin_elementwise_fma(zmk, v2f{-1.f, 1.f}, zk);
-                    const v2f o = cmul_negi(d, w);
-                    const v2f Rr = __builtin_elementwise_fma(xx(o), v2f{1.f, -1.f}, xx(e));
-                    const v2f Ii = __builtin_elementwise_fma(yy(o), v2f{1.f, -1.f}, yy(e));
-                    const v2f pw = __builtin_elementwise_fma(Rr, Rr, Ii * Ii);
-                    float pa = pw.x, pb = pw.y;
-                    if (POWER == 1) {
-                        pa = __builtin_sqrtf(pa);
-                        pb = __builtin_sqrtf(pb);
+                for (int kp = 0; kp < 4; ++kp) {
+                    // two bin pairs (k2 = 2 kp, 2 kp + 1) per trip: each stream's two values leave with one ds_write2_b32
+                    v2f e[2], d[2], w[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int k2 = 2 * kp + u;
+                        // partner Z[256 - k] from lane 16 - j (lane 0: its own register 16 - k2): row_mirror, then row_shr:1 with `old`
+                        const float sx = z[15 - k2].x, sy = z[15 - k2].y;
+                        const v2f own = z[(16 - k2) & 15];
+                        const float ox = own.x, oy = own.y;
+                        float mx = __builtin_amdgcn_update_dpp(sx, sx, 0x140 /*row_mirror*/, 0xF, 0xF, true);
+                        float my = __builtin_amdgcn_update_dpp(sy, sy, 0x140 /*row_mirror*/, 0xF, 0xF, true);
+                        mx = __builtin_amdgcn_update_dpp(ox, mx, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+                        my = __builtin_amdgcn_update_dpp(oy, my, 0x111 /*row_shr:1*/, 0xF, 0xF, false);
+                        const v2f zmk = v2f{mx, my};
+                        const v2f zk = z[k2];
+                        w[u] = wpr[k2 < NWP ? k2 : k2 - 4];
+                        if (k2 >= NWP) w[u] = cmulc(w[u], 0.70710678118654752f, -0.70710678118654752f);  // W_512^64 = W_8
+                        e[u] = __builtin_elementwise_fma(zmk, v2f{1.f, -1.f}, zk);
+                        d[u] = __builtin_elementwise_fma(zmk, v2f{-1.f, 1.f}, zk);
                     }
-#ifndef SSP_S_NOPW2
-                    // (two bins of each stream per LDS instruction: the pair of a stream goes out back to back so that it merges into
-                    //  one ds_write2_b32)
-                    if (k2 & 1) {
-                        P[j + 16 * (k2 - 1)] = pa_prev;
-                        P[j + 16 * k2] = pa;
-                        Pm[16 * (7 - k2)] = pb;
-                        Pm[16 * (8 - k2)] = pb_prev;
-                    } else {
-                        pa_prev = pa;
-                        pb_prev = pb;
+                    d[0] = cmul_negi(d[0], w[0]);  // o = (-i d) w
+                    d[1] = cmul_negi(d[1], w[1]);
+                    float pa[2], pb[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const v2f o = d[u];
+                        const v2f Rr = __builtin_elementwise_fma(xx(o), v2f{1.f, -1.f}, xx(e[u]));
+                        const v2f Ii = __builtin_elementwise_fma(yy(o), v2f{1.f, -1.f}, yy(e[u]));
+                        const v2f pw = __builtin_elementwise_fma(Rr, Rr, Ii * Ii);
+                        pa[u] = pw.x;
+                        pb[u] = pw.y;
+                        if (POWER == 1) {
+                            pa[u] = __builtin_sqrtf(pa[u]);
+                            pb[u] = __builtin_sqrtf(pb[u]);
+                        }
                     }
-#else
-                    P[j + 16 * k2] = pa;
-                    Pm[16 * (7 - k2)] = pb;
-#endif
+                    const int k2 = 2 * kp;
+                    P[j + 16 * k2] = pa[0];
+                    P[j + 16 * (k2 + 1)] = pa[1];
+                    Pm[16 * (6 - k2)] = pb[1];
+                    Pm[16 * (7 - k2)] = pb[0];
                 }
                 const v2f s8 = z[8] * z[8];
                 float p128 = 4.f * (s8.x + s8.y);

@@ -9,6 +9,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# glibc reports heap corruption ("free(): invalid pointer", ...) on the controlling terminal unless told otherwise: keep such a
+# message in the captured log next to the abort it explains
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
 
 
 def pytest_configure(config):
