@@ -32,23 +32,46 @@ def _deps():
     return out
 
 
+def _cmd(src: str, obj: str) -> list:
+    return [HIPCC, *FLAGS, *SOURCE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+
+
+def _stamp_ok(src: str, obj: str) -> bool:
+    """the object was compiled with exactly today's command line (flags are part of the up-to-date check: changing SSP_EXTRA_FLAGS or
+    SOURCE_FLAGS must not silently reuse objects built with the old ones)"""
+    try:
+        with open(obj + ".cmd") as f:
+            return f.read() == " ".join(_cmd(src, obj))
+    except OSError:
+        return False
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in _deps())
+    if any(os.path.getmtime(p) > t for p in _deps()):
+        return True
+    if os.path.isdir(OBJ_DIR):  # (a shipped .so without its objects — the GPU box — is taken as it is)
+        for s in SOURCES:
+            obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
+            if os.path.exists(obj) and not _stamp_ok(s, obj):
+                return True
+    return False
 
 
 def _compile(src: str) -> str:
     obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
     srcp = os.path.join(CSRC, src)
     newest = max(os.path.getmtime(p) for p in _deps() if p.endswith((".hpp", ".h")) or p == srcp)
-    if os.path.exists(obj) and os.path.getmtime(obj) > newest:
+    if os.path.exists(obj) and os.path.getmtime(obj) > newest and _stamp_ok(src, obj):
         return obj
-    cmd = [HIPCC, *FLAGS, *SOURCE_FLAGS.get(src, []), "-c", srcp, "-o", obj]
+    cmd = _cmd(src, obj)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    with open(obj + ".cmd", "w") as f:
+        f.write(" ".join(cmd))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
     return obj
