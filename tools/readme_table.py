@@ -1,0 +1,53 @@
+"""Markdown rows of README.md's results table from a bench line:  python tools/readme_table.py profiles/r03_bench_line.json"""
+import json, sys
+d = json.load(open(sys.argv[1]))
+g = lambda *k: (lambda v: v)(__import__("functools").reduce(lambda a, b: a[b], k, d))
+rows = []
+r = d["roofline"]
+rows.append(("fused 39-d MFCC, 100k × 3 s utterances resident in HBM (configs[1]; wave-stream kernel, software-pipelined quad loop, DCT / Δ / ΔΔ on the matrix cores)",
+             "%.3g frames/s (%.2f ms/pass)" % (d["value"], r["kernel_ms"]),
+             "%.2f of 8 TB/s HBM; HBM traffic %s × algorithmic (`profiles/mfcc_hbm_traffic.json`); VALU active %s of the SIMD time (`profiles/mfcc_valu_lds_pmc.json`)" % (
+                 r["frac"], ("%.3f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])) if r.get("traffic") else "n/a",
+                 ("%.2f" % d["roofline_valu"]["frac"]) if d.get("roofline_valu") else "n/a")))
+v = d["mfcc_ref26_cmvn"]
+rows.append(("the reference's `extract_feature` output: 13 cepstra + Δ, scaled per utterance (26-d), scaling inside the same kernel at three waves per SIMD",
+             "%.3g frames/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of HBM" % v["roofline"]["frac"]))
+a, b = d["mfcc_inrepo"]["16k"], d["mfcc_inrepo"]["8k"]
+rows.append(("in-repo MFCC (arithmetic pinned to the reference's own outputs), 16 kHz 512/256 13-d / 8 kHz, same kernel",
+             "%.2g / %.2g frames/s (%.1f / %.1f ms)" % (a["value"], b["value"], a["roofline"]["kernel_ms"], b["roofline"]["kernel_ms"]),
+             "%.2f / %.2f of HBM" % (a["roofline"]["frac"], b["roofline"]["frac"])))
+v = d["mfcc_librosa"]
+rows.append(("librosa-dialect MFCC (`MFCC_DTW.MFCC_lib`: 2048 / 512, 128 mel, top_db), 200k × 3 s at 8 kHz, 2048-point wave-stream kernel",
+             "%.2g frames/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of HBM (LDS / latency bound, `profiles/mfcc_stream2048_pmc.json`)" % v["roofline"]["frac"]))
+v = d["plp"]
+rows.append(("PLP features (sidekit `plp`), 100k × 3 s: Bark front end on the wave-stream kernel's dense-band instance + RASTA / LPC-cepstrum back end",
+             "%.3g frames/s (%.1f + %.1f ms)" % (v["value"], v["front_ms"], v["back_ms"]), "front end %.2f of HBM" % v["front_roofline"]["frac"]))
+v = d["gmm"]
+rows.append(("GMM-UBM scoring, 51 models × 64 mixtures × 39-d, fp32 MFMA (parity path), one launch, per-utterance means fused; 12-byte decision records gathered",
+             "%.3g frame-scores/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
+v = d["gmm_bf16x3"]
+rows.append(("same, bf16×3 split-precision MFMA + fp32 re-scoring of close calls (%d of %d; arg-max mismatches against fp32: %d)" % (v["utterances_rescored_in_fp32"], v["utterances"], v["argmax_mismatches_vs_fp32_path"]),
+             "%.2g frame-scores/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of the dense bf16 peak on algorithmic FLOPs" % v["roofline"]["frac"]))
+c3 = d["gmm_cfg3_shape"]
+fs = c3.get("bf16x3_full_share")
+rows.append(("configs[3] model shape (K = 512, 1251 speakers + UBM): 12 000 utterances per GPU fp32 / bf16×3" + ("; the FULL per-GPU share (150 000 utterances) on bf16×3, measured" if fs else ""),
+             "%.2g / %.2g frame-scores/s (%.2f s / %.2f s)" % (c3["f32"]["value"], c3["bf16x3"]["value"], c3["f32"]["kernel_ms"] / 1e3, c3["bf16x3"]["kernel_ms"] / 1e3)
+             + ("; full share %.2f s = %.2g frame-scores/s, %d re-scored, %d arg-max mismatches vs the fp32 sample" % (fs["measured_s"], fs["value"], fs["utterances_rescored_in_fp32"], fs["argmax_mismatches_vs_fp32_sample"]) if fs else ""),
+             "%.2f of the fp32 MFMA peak (fp32 sample)" % (c3["f32"]["tflops"] / 157.3)))
+v = d["gmm_em"]
+rows.append(("GMM EM training (E step + M sums per iteration), 3e6 frames × 64 mix × 39-d", "%.2f ms per iteration" % v["kernel_ms"], "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
+v = d["cosine"]
+rows.append(("cosine scoring, 1e6 × 1251 × 256", "%.2g pair-scores/s" % v["value"], "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
+v = d["dvector_dnn"]
+rows.append(("d-vector network forward 1274→256×4 (one packed object, hidden layers chained in registers), 5e5 embeddings", "%.2g embeddings/s (%.1f ms)" % (v["value"], v["kernel_ms"]), "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
+v = d["dvector_pipeline"]
+rows.append(("d-vector recogniser end to end (1 s chunks → MFCC 98×13 → network → cosine vs 1251 → arg-min), 3e5 chunks", "%.2g chunks/s" % v["value"], "—"))
+v = d["dtw"]
+rows.append(("DTW matcher, 128 × 64 pairs of 1222-element sequences", "%.2g pairs/s" % v["value"], "%.2f of the non-FMA fp32 vector rate" % v["roofline"]["frac"]))
+if "cpu_baseline" in d:
+    rows.append(("CPU (the box's host): oracle 1 thread / 16 processes; the reference's own per-frame MFCC loop; the reference's GMM scoring loop (sklearn)",
+                 "%.2g / %.2g frames/s; %.2g frames/s; %.2g frame-scores/s" % (d["cpu_baseline"]["value"], d["cpu_baseline_parallel"]["value"],
+                                                                         d["mfcc_inrepo"]["cpu_baseline_reference_loop"]["value"], d["gmm"]["cpu_baseline_reference_loop"]["value"]), "—"))
+print("| stage (config) | throughput | roofline |\n|---|---|---|")
+for r_ in rows:
+    print("| %s | %s | %s |" % r_)
