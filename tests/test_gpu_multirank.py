@@ -136,3 +136,16 @@ def test_nccl_backend_collectives_in_a_world_of_one():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r == {"ok": True, "backend": "nccl", "rows": 37, "max": 1.25}
+
+
+def test_c_example_runs_one_rank_of_configs3(tmp_path):
+    """examples/score_shard.c — the boundary from plain C with no Python and no torch in the process: MFCC -> GMM-UBM scoring ->
+    decision records -> ssp_allgather over RCCL; built with gcc here, run as its own process."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host import _build_c_example
+    exe = str(tmp_path / "score_shard")
+    r = _build_c_example(exe)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    # (RCCL prints a version banner on stdout the first time a communicator is made)
+    assert out.returncode == 0 and any(l.startswith("OK: 64 utterances") and l.endswith("64 records gathered") for l in out.stdout.splitlines()), out.stdout + out.stderr

@@ -194,3 +194,21 @@ def test_wav_read_matches_scipy(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.wav").write_bytes(b"not a wav file at all")
         tools.read(str(tmp_path / "bad.wav"))
+
+
+def _build_c_example(out):
+    import subprocess
+    pkg = os.path.join(ROOT, "speech_signal_processing_amd")
+    cmd = ["gcc", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "examples", "score_shard.c"), "-o", out, "-L", pkg, "-lsspgpu", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"]
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+def test_c_abi_compiles_and_links_from_plain_c(tmp_path):
+    """include/ssp.h is a C header (no C++, no torch types) and every entry point examples/score_shard.c uses — context, plan, segments,
+    MFCC, GMM pack / score, communicator, all-gather — links against libsspgpu.so from gcc."""
+    from speech_signal_processing_amd import _lib
+    _lib.load()
+    r = _build_c_example(str(tmp_path / "score_shard"))
+    assert r.returncode == 0, r.stderr
