@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -212,3 +213,24 @@ def test_c_abi_compiles_and_links_from_plain_c(tmp_path):
     _lib.load()
     r = _build_c_example(str(tmp_path / "score_shard"))
     assert r.returncode == 0, r.stderr
+
+
+def test_build_stamp_and_kernel_hash(tmp_path, monkeypatch):
+    """build.py: an object is up to date only if it was compiled with today's command line; bench.py: a PMC reading is quoted only for
+    the kernel source it was taken on."""
+    from speech_signal_processing_amd import build as b
+    obj = str(tmp_path / "x.o")
+    assert not b._stamp_ok("gmm.hip", obj)                      # no stamp yet
+    open(obj + ".cmd", "w").write(" ".join(b._cmd("gmm.hip", obj)))
+    assert b._stamp_ok("gmm.hip", obj)
+    assert "-fno-slp-vectorize" in b._cmd("gmm.hip", obj) and "-fno-slp-vectorize" not in b._cmd("ctx.hip", obj)
+    monkeypatch.setattr(b, "FLAGS", b.FLAGS + ["-DSSP_SOMETHING"])
+    assert not b._stamp_ok("gmm.hip", obj)                      # a flag changed: rebuild
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.kernel_source_sha256()
+    assert len(h) == 64 and h == bench.kernel_source_sha256()
+    import json
+    for name in ("mfcc_hbm_traffic.json", "mfcc_valu_lds_pmc.json"):
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert len(j["kernel_source_sha256"]) == 64              # (whether it matches the tree is for bench.py to report, not a test)
