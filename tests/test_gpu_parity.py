@@ -368,18 +368,21 @@ def test_sidekit_shape_fact(ssp):
     assert got[0].shape == (98, 13)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_mfcc_edge_cases(ssp, variant):
-    """empty utterance, N < window, exactly one frame, ragged batch, silence (ln 0 = -inf like the reference)."""
+    """empty utterance, N < window, exactly one frame, ragged batch, silence (ln 0 = -inf like the reference); on every kernel
+    (0 = auto = the wave-stream kernel: chunks of one to three quads exercise the pipelined loop's prologue-less start and its drain)."""
     pkg, api = ssp
     from oracle import ref_cpu as O
     sigs = [np.zeros(0, np.float32), synth_audio(2, 399, 16000), synth_audio(3, 400, 16000), synth_audio(4, 559, 16000),
             synth_audio(5, 560, 16000), np.zeros(1000, np.float32), synth_audio(6, 16000, 16000)]
-    for order in (0, 2):
+    # one to nine frames (up to three quads), 15 / 16 / 17 / 20 frames (the first time step's edges)
+    sigs += [synth_audio(10 + k, 400 + 160 * (k - 1), 16000) for k in (3, 4, 5, 7, 8, 9, 15, 16, 17, 20)]
+    for order in (0, 1, 2):
         tables = pkg.preset_sidekit(delta_order=order)
         got, fseg = _run_plan(api, tables, sigs, variant=variant)
         cfg, w, fb, dct = O.sidekit_tables(delta_order=order)
-        assert [g.shape[0] for g in got] == [0, 0, 1, 1, 2, 4, 98]
+        assert [g.shape[0] for g in got] == [0, 0, 1, 1, 2, 4, 98, 3, 4, 5, 7, 8, 9, 15, 16, 17, 20]
         for u, s in enumerate(sigs):
             ref = O.mfcc_pipeline(s, cfg, w, fb, dct)
             if u == 5:  # silence: every value is -inf / nan in both
