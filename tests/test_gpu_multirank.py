@@ -130,8 +130,13 @@ def test_nccl_backend_collectives_in_a_world_of_one():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29671", os.path.join(ROOT, "tests", "_nccl_world1.py")]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_nccl_world1.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
