@@ -8,7 +8,7 @@ struct MfccChunk {
     int32_t utt;  // utterance index
     int32_t t0;   // first frame of the chunk inside the utterance
     int32_t n;    // frames in the chunk
-    int32_t pad;
+    int32_t pad;  // wave-stream kernel: extra frames of halo in front of the chunk (0, or 12: the chunk then reproduces the uncut utterance's bits)
 };
 
 struct MfccArgs {

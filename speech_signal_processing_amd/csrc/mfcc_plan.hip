@@ -117,7 +117,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         {
             // small batches (the reference calls these functions one utterance at a time): a chunk per wave would leave most of the
             // machine idle, so utterances are cut into shorter chunks (multiples of 16 frames, >= 32; each recomputes a 4-frame halo)
-            // until there are about 12 waves' worth per CU.  The values do not depend on the cut (mfcc_stream.hip: H)
+            // until there are about 12 waves' worth per CU.  Chunks cut by this rule agree with each other bit for bit, with the uncut utterance to rounding (mfcc_stream.hip: H)
             const int64_t total = fseg->host.back() - fseg->host.front(), want = (int64_t)p->ctx->num_cu * 12;
             if ((total + ch - 1) / ch < want) {
                 const int64_t per = (total + want - 1) / want;
@@ -198,11 +198,25 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     }
     std::vector<MfccChunk> chunks;
     chunks.reserve((size_t)fseg->n);
+    // wave-stream kernel, machine-filling batches: the waves claim chunks from one counter, so the launch ends with a partial round in
+    // which some waves walk one more whole utterance while the others idle (100 000 utterances over 3 072 waves: 32.55 rounds, 1.4 % of
+    // the launch).  The utterances that are claimed last are cut in two (multiples of 16 frames), which
+    // halves that quantum; the second half starts 16 frames early (pad = 12 on top of the 4-frame halo: mfcc_stream.hip) so that it
+    // reproduces the uncut utterance bit for bit.  Not with the in-kernel scaling: it needs an utterance in one chunk.
+    int64_t tail_from = fseg->n;
+#ifndef SSP_NO_TAIL_SPLIT
+    if (variant == 3 && !(c.cmvn != 0 && !split_cmvn) && !getenv("SSP_MFCC_NO_TAIL_SPLIT")) {
+        const int64_t waves = (int64_t)p->ctx->num_cu * 12;
+        if (fseg->n >= 4 * waves) tail_from = fseg->n - waves;  // (measured: halves beat thirds / quarters, one wave-set beats two)
+    }
+#endif
     for (int64_t u = 0; u < fseg->n; ++u) {
         const int64_t T = fseg->host[u + 1] - fseg->host[u];
         if (T > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: utterance %lld has too many frames", (long long)u);
-        for (int64_t t0 = 0; t0 < T; t0 += ch)
-            chunks.push_back(MfccChunk{(int32_t)u, (int32_t)t0, (int32_t)std::min<int64_t>(ch, T - t0), 0});
+        int64_t chu = ch;
+        if (u >= tail_from && T >= 64) chu = std::min<int64_t>(ch, ((T + 1) / 2 + 15) / 16 * 16);
+        for (int64_t t0 = 0; t0 < T; t0 += chu)
+            chunks.push_back(MfccChunk{(int32_t)u, (int32_t)t0, (int32_t)std::min<int64_t>(chu, T - t0), (chu != ch && t0 > 0) ? 12 : 0});
     }
     if (chunks.size() > (size_t)INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: too many chunks");
     SSP_TRY(upload(p->chunks, chunks, p->ctx->stream));

@@ -152,9 +152,15 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         const int64_t f0 = a.frame_off[ch.utt];
         const int T = __builtin_amdgcn_readfirstlane((int)(a.frame_off[ch.utt + 1] - f0));
         const int t0 = __builtin_amdgcn_readfirstlane(ch.t0), n = __builtin_amdgcn_readfirstlane(ch.n);
-        const int H = dord > 0 ? 4 : 0;  // (a multiple of 4 for every delta order: a frame meets the same 4-frame k-groups of the time
-                                         // products wherever its chunk starts, so the values do not depend on how an utterance is cut)
-        const int ta = max(t0 - H, 0), tb = min(t0 + n + H, T);
+        // halo: 4 frames either side (a multiple of 4 for every delta order: a frame meets the same 4-frame k-groups of the delta product
+        // wherever its chunk starts).  The delta-delta product's k-groups are STRIDED over the 16-row step window, so its summation
+        // order — the last bits — depends on where the step windows sit in the utterance: chunks cut with the same rule agree bit for
+        // bit, a chunk that starts at t0 = 16 m with the plain halo (windows at 8 mod 16) agrees with the uncut utterance (windows at
+        // 12 mod 16) only to rounding.  ch.pad = 12 extra frames in front (ta = t0 - 16) puts the windows where the uncut utterance
+        // has them: such a chunk reproduces the uncut bits (the work table's tail split uses it).
+        const int H = dord > 0 ? 4 : 0;
+        const int Hlo = dord > 0 ? H + __builtin_amdgcn_readfirstlane(ch.pad) : 0;
+        const int ta = max(t0 - Hlo, 0), tb = min(t0 + n + H, T);
         const int R = tb - ta;                     // frames computed (relative index r = t - ta)
         const int nquads = (R + 3) >> 2;
         const int E = t0 + n - ta;                 // emitted frames end (relative)
