@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
     // W_512^(j + 16 i) resident for i < NWP and times W_8 above; that pays for the DCT matrix as resident MFMA A operand
     // (lane (ceps = j, kq = g), k-step s <-> filter KS g + s)
 #ifndef SSP_STREAM_NTW
-#define SSP_STREAM_NTW 13  // resident twiddles W_256^(k1 j), k1 <= NTW (the largest sets that leave no spill inside the loop; a spill
+#define SSP_STREAM_NTW 12  // resident twiddles W_256^(k1 j), k1 <= NTW (the largest sets that leave no spill inside the loop; a spill
 #endif                     // reload there waits on vmcnt behind the sample DMA and exposes its whole latency every quad)
 #ifndef SSP_STREAM_NTW_CM
 #define SSP_STREAM_NTW_CM 9   // ... of the instances that also carry the column sums of the scaling (CM)
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
 #ifndef SSP_STREAM_NWP
 #define SSP_STREAM_NWP 8   // resident split twiddles
 #endif
-    constexpr int NTW = OCC >= 3 ? (CM ? SSP_STREAM_NTW_CM : ((MELV <= 3 && NS <= 2) ? SSP_STREAM_NTW : ((MELV >= 4 && NS >= 4) ? 8 : 10))) : 15, NWP = OCC >= 3 ? SSP_STREAM_NWP : 8;
+    constexpr int NTW = OCC >= 3 ? (CM ? SSP_STREAM_NTW_CM : ((MELV <= 3 && NS <= 2) ? SSP_STREAM_NTW : ((MELV >= 4 && NS >= 4) ? 8 : 9))) : 15, NWP = OCC >= 3 ? SSP_STREAM_NWP : 8;
+    static_assert(NTW >= 8, "rows above NTW take W^((k1 - 8) j) W^(8 j): W^(8 j) = twr[7] must be resident");
     v2f twr[NTW], wpr[NWP];
 #pragma unroll
     for (int k1 = 1; k1 <= NTW; ++k1) twr[k1 - 1] = *reinterpret_cast<const v2f*>(&f.tw16[k1 * 16 + j]);
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             if (stores_pending == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (stores_pending == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (stores_pending == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (stores_pending == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if (stores_pending == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
 #endif
@@ -529,6 +531,78 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             }
             stores_pending = dord >= 2 ? 13 : (dord == 1 ? 9 : 4);
         };
+        // ================= the same step in the TRANSPOSED orientation, for steps whose 24-frame window lies inside the utterance ==========
+        // D^T[ceps][frame] = c^T[ceps][t'] . T^T[t'][frame]: the ring registers are the A operand as they stand (A and B share their lane
+        // layout), the weights the B operand, and a lane ends up with FOUR CONSECUTIVE CEPSTRA of ONE frame — 16 contiguous bytes of
+        // the output row: c, delta and delta-delta leave with one 16-byte store (cepstra 0..11) + one 4-byte store (cepstrum 12) each,
+        // 6 store instructions per 16 frames instead of 13, and a frame that is not emitted is simply a lane that aims out of bounds.
+        // The accumulator of one product is no longer the operand of the next (frames sit on lanes now), so delta-delta is ONE product
+        // with the auto-convolved weights (reach +-4, N = 2: (-10, -4, 1, 4, 4) / denom^2 at |d| = 0..4 = -10 + |d| (37 - d^2) / 6) —
+        // for interior frames the same numbers as delta(delta(c)) up to the rounding of the intermediate delta.
+        auto time_step_T = [&](int b) {
+            const int rb = 16 * b;
+            int ol = lane;
+            asm volatile("" : "+v"(ol));
+            const int g = ol >> 4, j = ol & 15;
+            float cb[6];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int m = (rb + 16 + 4 * s) % RING_FRAMES;  // (rb - 8 + 4 s) mod 24, a multiple of 4
+                cb[s] = *reinterpret_cast<const float*>(ring + (m + g) * RING_ROW + j * 4);
+            }
+            const float inv = 2.f * half_inv;
+            const float ef = (float)(g - 4 - j);  // input frame (rb - 8 + 4 s + g) minus output frame (rb - 4 + j) = ef + 4 s
+            const int F = ta + rb - 4 + j;       // this lane's output frame
+            const bool emit = F >= t0 && F < t0 + n;
+            const int row16 = (emit && g < 3) ? (F * Dd + 4 * g) * 4 : 0x7ffffff0;
+            const int row4 = (emit && g == 3) ? (F * Dd + 12) * 4 : 0x7ffffff0;
+            auto store = [&](v4f v, int blk) {
+                typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), ro, row16 + blk * (nc * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.x), ro, row4 + blk * (nc * 4), 0, 0);
+            };
+            {
+                v4f c = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 1; s < 5; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[s], (ef + (float)(4 * s)) == 0.f ? 1.f : 0.f, c, 0, 0, 0);
+                store(c, 0);
+            }
+            if (dord >= 1) {
+                v4f d = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    const float ds = ef + (float)(4 * s);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[s], __builtin_fabsf(ds) <= 2.f ? ds * inv : 0.f, d, 0, 0, 0);
+                }
+                store(d, 1);
+            }
+            if (dord >= 2) {
+                v4f q = v4f{0.f, 0.f, 0.f, 0.f};
+                const float inv2 = inv * inv;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    const float a = __builtin_fabsf(ef + (float)(4 * s));
+                    const float w = __builtin_fmaf(a, __builtin_fmaf(a * a, -1.f / 6.f, 37.f / 6.f), -10.f) * inv2;
+                    q = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[s], a <= 4.f ? w : 0.f, q, 0, 0, 0);
+                }
+                store(q, 2);
+            }
+            stores_pending = 2 * (1 + dord);
+        };
+        // a step whose window (frames rb - 8 .. rb + 15) lies strictly inside the utterance takes the transposed form; utterance ends
+        // (edge-replicated weights) and the scaling instances (their column sums live in the row-major layout) the chained one
+        auto emit_step = [&](int b) {
+#ifdef SSP_S_NOTSTEP
+            time_step(b);
+#else
+            const bool interior = ta + 16 * b - 8 >= 1 && ta + 16 * b + 16 <= T - 2;  // wave-uniform
+            // (not the scaling instances — their column sums live in the row-major layout — nor the widest filterbank instance, which has no
+            //  register left for the second form)
+            constexpr bool TSTEP = !CM && !(MELV >= 4 && NS >= 4);
+            if (TSTEP && interior) time_step_T(b);
+            else time_step(b);
+#endif
+        };
 
         if constexpr (DENSE) {
             for (int q = 0; q < nquads; ++q) {
@@ -646,7 +720,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 fft_front(z);
                 mel();
 #ifndef SSP_S_NOSTEP
-                if ((q & 3) == 0 && q > 0) time_step((q - 1) >> 2);  // (here, where no FFT register is live)
+                if ((q & 3) == 0 && q > 0) emit_step((q - 1) >> 2);  // (here, where no FFT register is live)
 #endif
             }
             // drain: the back of the last quad, then the virtual quads behind the chunk's last frame
@@ -655,7 +729,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 if (qb < nquads) cq = dct_mfma();
                 ring_put(qb, cq, qb < nquads);
 #ifndef SSP_S_NOSTEP
-                if ((qb & 3) == 3) time_step(qb >> 2);
+                if ((qb & 3) == 3) emit_step(qb >> 2);
 #endif
             }
 #endif
@@ -852,7 +926,20 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * wg_waves), lds, stream, args, f, sa);                             \
         launched = true;                                                                                                \
     }
-    SSP_STREAM_CASE_CM(13, 2, 1, 2, 6, 3, 1) SSP_STREAM_CASE_CM(13, 2, 1, 3, 6, 3, 1)
+    // (scaling at three waves per SIMD exists for two scan steps only: occ above)
+#define SSP_STREAM_CASE_CM3(MV_)                                                                                          \
+    if (!launched && dry_run && nz == 13 && pw == 2 && pr == 1 && f.melv == MV_ && KS == 6 && occ == 3 && cm == 1) launched = true; \
+    if (!launched && nz == 13 && pw == 2 && pr == 1 && f.melv == MV_ && KS == 6 && occ == 3 && cm == 1) {                   \
+        auto* kfn = mfcc_stream512_kernel<13, 2, 1, MV_, 6, 2, 3, 1>;                                                     \
+        int per_cu = 0;                                                                                                   \
+        SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * wg_waves, lds));                          \
+        const int grid = std::min((n_chunks + wg_waves - 1) / wg_waves, std::max(1, per_cu) * p->ctx->num_cu);            \
+        SSP_HIP(hipMemsetAsync(sa.work_counter, 0, 64, stream));                                                          \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * wg_waves), lds, stream, args, f, sa);                               \
+        launched = true;                                                                                                  \
+    }
+    SSP_STREAM_CASE_CM3(2) SSP_STREAM_CASE_CM3(3)
+#undef SSP_STREAM_CASE_CM3
     SSP_STREAM_CASE_CM(13, 2, 1, 2, 6, 2, 1) SSP_STREAM_CASE_CM(13, 2, 1, 3, 6, 2, 1) SSP_STREAM_CASE_CM(13, 2, 1, 4, 6, 2, 1)
     SSP_STREAM_CASE(13, 2, 1, 0, 6, 2)  // dense bands (the PLP front end)
 #ifdef SSP_FAST_MINIMAL
