@@ -206,14 +206,17 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this quad's DMA has landed (issued one iteration ago)
 #endif
         STAMP(10)  // wait for the DMA
-        v2f pm[PRE ? NZ : 1];  // (x[e-2], x[e-1]): the pre-emphasis partner comes from the stage too (aligned 8-byte reads: the
-                               // 4-byte-aligned pair (x[e-1], x[e]) would be a ds_read2_b32 with 2-way bank conflicts between frames)
+        float pm[PRE ? NZ : 1];  // x[e-1]: the pre-emphasis partner comes from the stage too
         {
-            const float* sp = stage + g * hop + 2 * j;
+            // (volatile LDS-address-space loads, one ds_read_b64 + one ds_read_b32 per row: the compiler otherwise merges the pair with its
+            //  partner into a ds_read2_b64 — 8 LDS cycles against 2 + 2 — as it did in mfcc_stream.hip before round 3)
+            typedef __attribute__((address_space(3))) const volatile v2f* lds_cv2f_t;
+            typedef __attribute__((address_space(3))) const volatile float* lds_cvf_t;
+            const uint32_t sp = (uint32_t)(uintptr_t)(lds_ptr_t)stage + (g * hop + 2 * j) * 4;
 #pragma unroll
             for (int n1 = 0; n1 < NZ; ++n1) {
-                pf[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1);
-                if (PRE) pm[n1] = *reinterpret_cast<const v2f*>(sp + 32 * n1 - 2);
+                pf[n1] = *(lds_cv2f_t)(uintptr_t)(sp + 128 * n1);
+                if (PRE) pm[n1] = *(lds_cvf_t)(uintptr_t)(sp + 128 * n1 - 4);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is in registers: the next quad may overwrite it
@@ -224,13 +227,13 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
         if (cdef_off >= 0) scr[cdef_off] = cdef;
         STAMP(12)  // DMA issue
         // y[n] = x[n] - a x[n-1]; the first sample of a frame pairs with itself (y[0] = x[0] - a x[0])
-        if (PRE) pm[0].y = (j == 0) ? pf[0].x : pm[0].y;
+        if (PRE) pm[0] = (j == 0) ? pf[0].x : pm[0];
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NZ) {
                 v2f y = pf[n1 < NZ ? n1 : 0];
                 if (PRE) {
-                    const float xm1 = pm[n1 < NZ ? n1 : 0].y, x0 = y.x, x1 = y.y;
+                    const float xm1 = pm[n1 < NZ ? n1 : 0], x0 = y.x, x1 = y.y;
                     y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
                 }
                 z[n1] = y * wreg[n1 < NZ ? n1 : 0];
