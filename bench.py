@@ -457,7 +457,7 @@ def main():
             "metric": "librosa-dialect MFCC frames/s (MFCC_DTW.MFCC_lib: n_fft 2048 / hop 512, 128 mel, top_db 80, 13-d)", "value": lfseg.total / (l_ms * 1e-3),
             "unit": "frames/s", "utterances_per_gpu": l_utt, "frames_per_gpu": int(lfseg.total), "dtype": "f32",
             "roofline": {"bound": "hbm", "achieved": l_bytes / (l_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": l_bytes / (l_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "mfcc_stream2048_kernel + topdb_dct_chunk_kernel (utterance-wide clamp + DCT as a second pass)",
+                         "frac": l_bytes / (l_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "mfcc_stream2048_kernel (single-chunk utterances: the wave that walked an utterance also clamps its rows at its maximum - top_db and takes the DCT; multi-chunk batches add topdb_dct_chunk_kernel as a second pass)",
                          "kernel_ms": l_ms, "algorithmic_bytes_per_launch": l_bytes, "bytes_per_frame": 512 * 4 + 13 * 4}}
         del lplan, lfeat
 
@@ -662,7 +662,7 @@ def main():
                             "tflops": 12.0 * D * K * n_em / r["kernel_ms"] / 1e9, "dtype": "f32",
                             "roofline": {"bound": "mfma", "achieved": 12.0 * D * K * n_em / r["kernel_ms"] / 1e9, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                          "frac": 12.0 * D * K * n_em / r["kernel_ms"] / 1e9 / MFMA_F32_PEAK_TF, "traffic": None,
-                                         "kernel": "gmm_em_lse_kernel + gmm_em_acc_kernel + gmm_em_reduce_kernel (v_mfma_f32_32x32x2_f32)",
+                                         "kernel": "gmm_em_acc_mfma_kernel<3, fused log-sum-exp> (v_mfma_f32_32x32x2_f32: log-probabilities and responsibility-weighted sums in one pass, D <= 47, K <= 64) + gmm_em_reduce_kernel",
                                          "kernel_ms": r["kernel_ms"],
                                          "algorithmic_flop_per_launch": 12.0 * D * K * n_em,
                                          "flop_per_frame": "12 D K: log-probability 4 D K (two D x K multiply-adds) + responsibility-weighted sums of x and x^2 8 D K"}}
