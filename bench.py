@@ -353,11 +353,14 @@ def main():
             cj = json.load(open(census_file))
             if cj.get("kernel_source_sha256") == ksha:
                 cyc = float(cj["valu_issue_cycles_per_quad"])
+                clk = cj.get("sustained_clock_ghz") or (cj.get("derived") or {}).get("effective_clock_ghz")  # GRBM_GUI_ACTIVE / kernel time
                 peak = 256 * 4 * 2.4e9
                 ach = (n_frames / 4.0) * cyc / (ms_kernel * 1e-3)
                 valu = {"bound": "valu-issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G issue-cycles/s", "frac": ach / peak,
                         "issue_cycles_per_quad": cyc, "floor_ms_at_2.4GHz": (n_frames / 4.0) * cyc / peak * 1e3,
-                        "sustained_clock_ghz": cj.get("sustained_clock_ghz"), "source": "profiles/mfcc_valu_lds_pmc.json",
+                        "sustained_clock_ghz": clk, "frac_at_sustained_clock": (ach / (256 * 4 * clk * 1e9)) if clk else None,
+                        "power": "the pass sits on the 1400 W package cap (profiles/r03_clock_power.md: 1.96 GHz at 1385 W)",
+                        "source": "profiles/mfcc_valu_lds_pmc.json",
                         "census_workload": cj.get("workload")}
         except Exception:
             valu = None
