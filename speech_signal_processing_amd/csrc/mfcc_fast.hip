@@ -318,14 +318,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                 pa[k2] = pw.x;
                 pb[k2] = pw.y;
                 if (POWER == 1) {
-                    pa[k2] = __builtin_sqrtf(pa[k2]);
-                    pb[k2] = __builtin_sqrtf(pb[k2]);
+                    pa[k2] = __builtin_amdgcn_sqrtf(pa[k2]);
+                    pb[k2] = __builtin_amdgcn_sqrtf(pb[k2]);
                 }
             }
             // bin 128 pairs with itself: 2 X[128] = 2 conj Z[128] (lane 0, register 8)
             const v2f s8 = z[8] * z[8];
             float p128 = 4.f * (s8.x + s8.y);
-            if (POWER == 1) p128 = __builtin_sqrtf(p128);
+            if (POWER == 1) p128 = __builtin_amdgcn_sqrtf(p128);
             // the 1/4 (power) or 1/2 (magnitude) and spec_scale live in the filterbank weights
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) P[j + 16 * k2] = pa[k2];      // grouped by base so the stores pair into ds_write2_b32

@@ -344,9 +344,9 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                         const v2f pw = __builtin_elementwise_fma(Rr, Rr, Ii * Ii);
                         pa[u] = pw.x;
                         pb[u] = pw.y;
-                        if (POWER == 1) {
-                            pa[u] = __builtin_sqrtf(pa[u]);
-                            pb[u] = __builtin_sqrtf(pb[u]);
+                        if (POWER == 1) {  // v_sqrt_f32 (1 ulp), not sqrtf(): the correctly rounded expansion is ~18 instructions per bin
+                            pa[u] = __builtin_amdgcn_sqrtf(pa[u]);
+                            pb[u] = __builtin_amdgcn_sqrtf(pb[u]);
                         }
                     }
                     const int k2 = 2 * kp;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 }
                 const v2f s8 = z[8] * z[8];
                 float p128 = 4.f * (s8.x + s8.y);
-                if (POWER == 1) p128 = __builtin_sqrtf(p128);
+                if (POWER == 1) p128 = __builtin_amdgcn_sqrtf(p128);
                 if (j == 0) P[128] = p128;
             }
         };

@@ -32,7 +32,8 @@ constexpr int S2K_WAVES = SSP_2K_WAVES;
 constexpr int ROW1 = 68;                                   // complex slots per row of the first transpose image (64 + 4 pad)
 constexpr int S2K_BUF_BYTES = 16 * ROW1 * 8;               // 8.5 KiB: the first transpose image; the natural-order spectrum image (1084 slots) fits it
 constexpr int S2K_WAVE_BYTES = S2K_BUF_BYTES;
-constexpr int S2K_TWB_BYTES = 4 * 16 * 8;
+constexpr int TWB_ROW = 17;                                // second-pass twiddle rows [lb][ka], 17 slots apart: the four rows a ds_read_b64 touches sit in different banks
+constexpr int S2K_TWB_BYTES = 4 * TWB_ROW * 8;
 constexpr int S2K_WIN_BYTES = 2048 * 4, S2K_TWA_BYTES = 16 * 64 * 8;  // window and first-pass twiddles: workgroup-shared too (62 registers)
 constexpr int S2K_TWS_BYTES = 9 * 64 * 8;                  // split twiddles (workgroup-shared: 18 registers per lane otherwise, and a spill
                                                            // reload inside the frame loop waits behind the next frame's sample loads)
@@ -68,7 +69,7 @@ __device__ __forceinline__ float log2k(const MfccArgs& a, float v) {
 
 struct S2kArgs {
     const float2* twA;   // [16][64]  W_1024^(l k1)
-    const float2* twB;   // [4][16]   W_64^(lb ka)
+    const float2* twB;   // [4][TWB_ROW]   W_64^(lb ka)
     const float2* twS;   // [9][64]   W_2048^k, k = l + 64 i (k <= 512)
     const char* mel;     // [steps0 + steps1][64] 4-tap weight steps: the group of the 64 shortest filters, then the 64 longest
     const int32_t* minfo;  // [2][64][2] per group and lane: byte offset of the first step in the P row, filter id (-1: none)
@@ -78,6 +79,10 @@ struct S2kArgs {
     float top_db;        // (< 0: no clamp)
 };
 
+// POWER: 2 = power spectrum, 1 = magnitude.  A template parameter, not a.spec_power: as a run-time (wave-uniform) condition inside the
+// unrolled split loop the compiler if-converted it — BOTH sides evaluated, the magnitude side being a correctly rounded square root of
+// ~18 instructions per bin — which cost the power dialects 290 of their 845 vector instructions per frame.
+template <int POWER>
 __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(MfccArgs a, S2kArgs s) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -118,8 +123,9 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
     char* wbase = smem + s.table_bytes + (s.fuse ? 16 * 128 * 4 : 0) + wave * S2K_WAVE_BYTES;
     v2f* buf = reinterpret_cast<v2f*>(wbase);
 
-    const int mstart0 = s.minfo[lane * 2], mfid0 = s.minfo[lane * 2 + 1];
-    const int mstart1 = s.minfo[128 + lane * 2], mfid1 = s.minfo[128 + lane * 2 + 1];
+    // per group and lane (byte offset of the first step in the P row, filter id): read from the LDS copy behind the weight steps when a
+    // frame's filterbank starts — as four registers held for the kernel's life they were what the allocator spilled at 168
+    const int2* minfol = reinterpret_cast<const int2*>(melt + (s.steps0 + s.steps1) * 1024) + lane;
     const int hop = a.hop;
     const int M = 1024;
     const bool centre = a.frame_mode == 2;
@@ -136,7 +142,6 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
         const float* __restrict__ x = a.samples + s0;
         const int t0 = __builtin_amdgcn_readfirstlane(ch.t0), n = __builtin_amdgcn_readfirstlane(ch.n);
         float wave_max = -INFINITY;
-
         auto load_frame = [&](int t, v2f (&v)[16]) {
             const int64_t g0 = (int64_t)t * hop - (centre ? M : 0);
             if (g0 >= 0 && g0 + 2 * M <= N) {
@@ -151,19 +156,27 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
                 // of a lane are in flight together (a conditional load per sample serialises them: one memory latency EACH, which made
                 // the four edge frames of a 47-frame utterance cost more than the other 43)
                 const int g0i = (int)g0, Ni = (int)N;
+                // (the lane id from an opaque instruction: with the kernel's `lane` the 16 offsets 128 r + 2 lane are loop invariants,
+                //  hoisted to the kernel's top, spilled at 168 registers and reloaded here one by one — a scratch round trip in front of
+                //  every load of the edge path)
+                int lane_e;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float e[2];
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        int g = g0i + 128 * r + 2 * lane + c;
+                        int g = g0i + 128 * r + 2 * lane_e + c;
+                        // (uniform base + unsigned 32-bit byte offset: the load takes its base from SGPRs and one index register, not a
+                        //  64-bit per-lane address — 32 of those at once were the kernel's register peak)
+                        const char* xb = reinterpret_cast<const char*>(x);
                         if (centre) {  // numpy.pad(mode='reflect'), as frame_sample() of the generic kernel
                             g = g < 0 ? -g : g;
                             g = g >= Ni ? 2 * (Ni - 1) - g : g;
                             g = max(0, min(g, Ni - 1));
-                            e[c] = x[g];
+                            e[c] = *reinterpret_cast<const float*>(xb + (unsigned)(g * 4));
                         } else {
-                            const float xv = x[min(g, Ni - 1)];
+                            const float xv = *reinterpret_cast<const float*>(xb + (unsigned)(min(g, Ni - 1) * 4));
                             e[c] = g < Ni ? xv : 0.f;
                         }
                     }
@@ -196,17 +209,20 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
             // ---- pass 2: DFT16 over la, twiddle W_64^(lb ka)
             fft16(z);
 #pragma unroll
-            for (int ka = 1; ka < 16; ++ka) z[ka] = cmul(z[ka], lds_read_v2f(&twB[lb * 16 + ka]));
-            // ---- transpose 2: the four lb of a (k1, ka) pair side by side (32-byte unit, units of a row XOR-swizzled by k1)
+            for (int ka = 1; ka < 16; ++ka) z[ka] = cmul(z[ka], lds_read_v2f(&twB[lb * TWB_ROW + ka]));
+            // ---- transpose 2: the four lb of a (k1, ka) pair side by side (32-byte unit, units of a row XOR-swizzled by k1).  The
+            // reading lane (k1, kah = ka >> 2) takes a unit as two 16-byte halves; lanes kah and kah + 2 of a ds_read_b128 lane set
+            // would meet on one 16-byte slot, so the units of kah >= 2 (ka >= 8) hold their halves swapped and those lanes read the
+            // upper half first: 16 lanes, 16 slots
 #pragma unroll
-            for (int ka = 0; ka < 16; ++ka) buf[(k1p * 16 + (ka ^ k1p)) * 4 + lb] = z[ka];
+            for (int ka = 0; ka < 16; ++ka) buf[(k1p * 16 + (ka ^ k1p)) * 4 + (lb ^ ((ka >> 3) << 1))] = z[ka];
             wave_sync2k();
-            const int k1q = lane >> 2, kah = lane & 3;
+            const int k1q = lane >> 2, kah = lane & 3, swp = (kah >> 1) << 1;
             v2f y[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int unit = k1q * 16 + ((4 * kah + i) ^ k1q);
-                const v4f q0 = *reinterpret_cast<const v4f*>(&buf[unit * 4]), q1 = *reinterpret_cast<const v4f*>(&buf[unit * 4 + 2]);
+                const v4f q0 = *reinterpret_cast<const v4f*>(&buf[unit * 4 + swp]), q1 = *reinterpret_cast<const v4f*>(&buf[unit * 4 + 2 - swp]);
                 y[i][0] = v2f{q0.x, q0.y};
                 y[i][1] = v2f{q0.z, q0.w};
                 y[i][2] = v2f{q1.x, q1.y};
@@ -222,44 +238,49 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
             }
             wave_sync2k();
             // ---- split step of the real FFT (bins k and M - k from the pair Z[k], Z[M - k]), power / magnitude
-            float pa[9], pb[9];
+            // (k = lane + 64 i covers bins 0..511 and their partners 1024..513; bin 512 pairs with itself: X[512] = conj Z[512])
+            float pa[8], pb[8];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 const int k = lane + 64 * i;
-                pa[i] = pb[i] = 0.f;
-                if (k <= M / 2) {
-                    const v2f zk = lds_read_v2f(&buf[xpad(k)]);
-                    const v2f zm = lds_read_v2f(&buf[xpad((M - k) & (M - 1))]);
-                    const v2f hz = zk * 0.5f;
-                    const v2f e = __builtin_elementwise_fma(zm, v2f{0.5f, -0.5f}, hz);
-                    const v2f d = __builtin_elementwise_fma(zm, v2f{-0.5f, 0.5f}, hz);
-                    const v2f o = cmul_negi(d, lds_read_v2f(&twS[i * 64 + lane]));
-                    const v2f xa = e + o, xb = e - o;
-                    float p0 = xa.x * xa.x + xa.y * xa.y, p1 = xb.x * xb.x + xb.y * xb.y;
-                    if (a.spec_power == 1) {
-                        p0 = __builtin_sqrtf(p0);
-                        p1 = __builtin_sqrtf(p1);
-                    }
-                    pa[i] = p0 * a.spec_scale;
-                    pb[i] = p1 * a.spec_scale;
+                const v2f zk = lds_read_v2f(&buf[xpad(k)]);
+                const v2f zm = lds_read_v2f(&buf[xpad((M - k) & (M - 1))]);
+                const v2f hz = zk * 0.5f;
+                const v2f e = __builtin_elementwise_fma(zm, v2f{0.5f, -0.5f}, hz);
+                const v2f d = __builtin_elementwise_fma(zm, v2f{-0.5f, 0.5f}, hz);
+                const v2f o = cmul_negi(d, lds_read_v2f(&twS[i * 64 + lane]));
+                const v2f xa = e + o, xb = e - o;
+                float p0 = xa.x * xa.x + xa.y * xa.y, p1 = xb.x * xb.x + xb.y * xb.y;
+                if (POWER == 1) {  // v_sqrt_f32 (1 ulp): the magnitude feeds a filter sum and a logarithm
+                    p0 = __builtin_amdgcn_sqrtf(p0);
+                    p1 = __builtin_amdgcn_sqrtf(p1);
                 }
+                pa[i] = p0 * a.spec_scale;
+                pb[i] = p1 * a.spec_scale;
             }
+            const int2 mi0 = minfol[0], mi1 = minfol[64];
+            const int mstart0 = mi0.x, mfid0 = mi0.y, mstart1 = mi1.x, mfid1 = mi1.y;
+            const v2f z512 = lds_read_v2f(&buf[xpad(M / 2)]);  // (one address for the wave: a broadcast)
+            float p512 = z512.x * z512.x + z512.y * z512.y;
+            if (POWER == 1) p512 = __builtin_amdgcn_sqrtf(p512);
+            p512 *= a.spec_scale;
             wave_sync2k();
             float* P = reinterpret_cast<float*>(buf);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 const int k = lane + 64 * i;
-                if (k <= M / 2) {
-                    P[k] = pa[i];
-                    P[M - k] = pb[i];
-                }
+                P[k] = pa[i];
+                P[M - k] = pb[i];
             }
+            if (lane == 0) P[M / 2] = p512;
             if (lane < 4) P[M + 1 + lane] = 0.f;  // (16-byte reads: the taps behind bin 1024 carry zero weights)
             wave_sync2k();
             // ---- filterbank + log: a lane per filter, the 64 shortest filters then the 64 longest (each group sweeps as many 4-tap
             // steps as its longest filter needs; shorter ones carry zero weights, and start early enough to stay inside the P row);
             // fixed summation order per filter, no cross-lane traffic; the row leaves for the second pass
 #ifndef SSP_2K_NOMEL
+            const __amdgpu_buffer_rsrc_t ro =
+                __builtin_amdgcn_make_buffer_rsrc(a.lm_out + (size_t)(f0 + t) * (size_t)a.n_filt, 0, a.n_filt * 4, 0x00020000);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int nst = g == 0 ? s.steps0 : s.steps1;
@@ -281,7 +302,12 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
                 const int fid = g == 0 ? mfid0 : mfid1;
                 if (fid >= 0) {
                     const float v = log2k(a, (acc.x + acc.y) + (acc.z + acc.w));
-                    a.lm_out[(size_t)(f0 + t) * a.n_filt + fid] = v;
+                    // (a buffer store: the row base travels in SGPRs, the lane adds its filter's 4-byte column.  As a flat 64-bit per-lane
+                    //  address this was a value the register allocator spilled — reloaded from scratch before each of a frame's two
+                    //  stores, with a vmcnt(0) behind it that also waited for the next frame's 16 sample loads.  Issuing the stores one
+                    //  frame late, ahead of the next sample loads, so that the window multiply's vmcnt(0) does not cover them, was
+                    //  measured: slower)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, fid * 4, 0, 0);
                     wave_max = fmaxf(wave_max, v);
                 }
             }
@@ -347,7 +373,7 @@ int build_s2k_tables(ssp_mfcc_plan* p) {
     p->s2k_ready = false;
     if (!s2k_cfg_ok(c)) return SSP_OK;
     const int nb = 1025;
-    std::vector<float2> twA(16 * 64), twB(4 * 16), twS(9 * 64);
+    std::vector<float2> twA(16 * 64), twB(4 * TWB_ROW), twS(9 * 64);
     for (int k1 = 0; k1 < 16; ++k1)
         for (int l = 0; l < 64; ++l) {
             const double ang = -2.0 * M_PI * (double)(l * k1) / 1024.0;
@@ -356,7 +382,7 @@ int build_s2k_tables(ssp_mfcc_plan* p) {
     for (int lb = 0; lb < 4; ++lb)
         for (int ka = 0; ka < 16; ++ka) {
             const double ang = -2.0 * M_PI * (double)(lb * ka) / 64.0;
-            twB[lb * 16 + ka] = make_float2((float)cos(ang), (float)sin(ang));
+            twB[lb * TWB_ROW + ka] = make_float2((float)cos(ang), (float)sin(ang));
         }
     for (int i = 0; i < 9; ++i)
         for (int l = 0; l < 64; ++l) {
@@ -390,22 +416,72 @@ int build_s2k_tables(ssp_mfcc_plan* p) {
     std::vector<int32_t> minfo(2 * 64 * 2, 0);
     for (int i = 0; i < 128; ++i) minfo[i * 2 + 1] = -1;
     std::vector<char> mel((size_t)(gsteps[0] + gsteps[1]) * 64 * 16, 0);
-    for (int i = 0; i < c.n_filt; ++i) {
-        const int g = i >> 6, l = i & 63, j = order[i];
-        int start = lo[j] & ~3;
-        start = std::min(start, (P_END - 4 * gsteps[g]) & ~3);
-        if (start < 0 || start + 4 * gsteps[g] < lo[j] + len[j]) return SSP_OK;  // (a filter wider than the sweep: the generic kernel keeps the plan)
-        minfo[(g * 64 + l) * 2] = start * 4;
-        minfo[(g * 64 + l) * 2 + 1] = len[j] > 0 ? j : -1;
-        float* wt = reinterpret_cast<float*>(mel.data()) + (size_t)(g == 0 ? 0 : gsteps[0]) * 64 * 4;
-        for (int k = 0; k < len[j]; ++k) {
-            const int tap = lo[j] + k - start;
-            wt[((size_t)(tap / 4) * 64 + l) * 4 + (tap & 3)] = fb[(size_t)j * nb + lo[j] + k];
+    // Lane assignment inside a group.  Every step is one ds_read_b128 of the P row at a per-lane address; the LDS serves that
+    // instruction in four fixed 16-lane sets, one cycle per set when the 16 lanes sit in 16 different 16-byte slots of a 256-byte
+    // bank row (MI355X_MICROARCH.md, LDS) — and all lanes advance by the same 16 bytes per step, so a set that is conflict-free
+    // at the first step stays so.  Filters are therefore dealt to the sets so that the slots of a set differ, a filter's start
+    // moving down by whole 4-tap steps (leading zero weights) where the group's sweep leaves it the room.
+    static const int kSet[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                    {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    int slot_clashes = 0;
+    for (int g = 0; g < 2; ++g) {
+        const int i0 = g * 64, i1 = std::min(c.n_filt, i0 + 64);
+        if (i1 <= i0) break;
+        struct Cand { int j, start_hi, n_opt; };
+        std::vector<Cand> cand;
+        for (int i = i0; i < i1; ++i) {
+            const int j = order[i];
+            int start = lo[j] & ~3;
+            start = std::min(start, (P_END - 4 * gsteps[g]) & ~3);
+            if (start < 0 || start + 4 * gsteps[g] < lo[j] + len[j]) return SSP_OK;  // (a filter wider than the sweep: the generic kernel keeps the plan)
+            int n_opt = 1;  // starts start, start - 4, ... that still cover the filter
+            while (start - 4 * n_opt >= 0 && start - 4 * n_opt + 4 * gsteps[g] >= lo[j] + len[j] && n_opt < 16) ++n_opt;
+            cand.push_back({j, start, len[j] == 0 ? 16 : n_opt});
         }
+        std::stable_sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) { return x.n_opt < y.n_opt; });
+        bool used[4][16] = {}, lane_taken[64] = {};
+        int fill[4] = {0, 0, 0, 0};
+        float* wt = reinterpret_cast<float*>(mel.data()) + (size_t)(g == 0 ? 0 : gsteps[0]) * 64 * 4;
+        for (const Cand& cd : cand) {
+            int best_set = -1, best_m = 0;
+            for (int m = 0; m < cd.n_opt && best_set < 0; ++m) {
+                const int slot = ((cd.start_hi - 4 * m) / 4) & 15;
+                int pick = -1;
+                for (int q = 0; q < 4; ++q)  // the emptiest set whose slot is free
+                    if (fill[q] < 16 && !used[q][slot] && (pick < 0 || fill[q] < fill[pick])) pick = q;
+                if (pick >= 0) { best_set = pick; best_m = m; }
+            }
+            if (best_set < 0) {  // no free slot anywhere: the emptiest set, at the natural start (one extra LDS cycle per step)
+                for (int q = 0; q < 4; ++q)
+                    if (fill[q] < 16 && (best_set < 0 || fill[q] < fill[best_set])) best_set = q;
+                ++slot_clashes;
+            }
+            const int start = cd.start_hi - 4 * best_m;
+            used[best_set][(start / 4) & 15] = true;
+            const int l = kSet[best_set][fill[best_set]++];
+            lane_taken[l] = true;
+            minfo[(g * 64 + l) * 2] = start * 4;
+            // (filters with no taps at all still produce log(0 + floor): they are listed with their id and zero weights)
+            minfo[(g * 64 + l) * 2 + 1] = cd.j;
+            for (int k = 0; k < len[cd.j]; ++k) {
+                const int tap = lo[cd.j] + k - start;
+                wt[((size_t)(tap / 4) * 64 + l) * 4 + (tap & 3)] = fb[(size_t)cd.j * nb + lo[cd.j] + k];
+            }
+        }
+        // lanes without a filter read where another lane of their set reads (same address: a broadcast, no bank of its own)
+        for (int q = 0; q < 4; ++q)
+            for (int e = fill[q]; e < 16; ++e)
+                if (fill[q] > 0) minfo[(g * 64 + kSet[q][e]) * 2] = minfo[(g * 64 + kSet[q][0]) * 2];
+        (void)lane_taken;
     }
-    // (filters with no taps at all still produce log(0 + floor): they are listed with their id and zero weights)
-    for (int i = 0; i < c.n_filt; ++i)
-        if (len[order[i]] == 0) minfo[((i >> 6) * 64 + (i & 63)) * 2 + 1] = order[i];
+    if (getenv("SSP_DEBUG")) fprintf(stderr, "[ssp] mfcc stream2048 tables: %d + %d filterbank steps, %d filters without a conflict-free slot\n", gsteps[0], gsteps[1], slot_clashes);
+    {  // the lane table rides behind the weight steps (one LDS staging loop)
+        const size_t w = mel.size();
+        mel.resize(w + minfo.size() * sizeof(int32_t));
+        memcpy(mel.data() + w, minfo.data(), minfo.size() * sizeof(int32_t));
+    }
     const size_t table_bytes = S2K_TWB_BYTES + S2K_TWS_BYTES + S2K_WIN_BYTES + S2K_TWA_BYTES + mel.size();
     if (table_bytes + 16 * 128 * 4 + (size_t)4 * S2K_WAVE_BYTES > 160 * 1024) return SSP_OK;  // (filterbanks whose weight steps do not fit keep the generic kernel)
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
@@ -443,7 +519,7 @@ int launch_mfcc_s2k(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStr
     s.steps0 = p->s2k_steps;
     s.steps1 = p->s2k_steps1;
     s.n_chunks = n_chunks;
-    s.table_bytes = S2K_TWB_BYTES + S2K_TWS_BYTES + S2K_WIN_BYTES + S2K_TWA_BYTES + (p->s2k_steps + p->s2k_steps1) * 64 * 16;
+    s.table_bytes = S2K_TWB_BYTES + S2K_TWS_BYTES + S2K_WIN_BYTES + S2K_TWA_BYTES + (p->s2k_steps + p->s2k_steps1) * 64 * 16 + 2 * 64 * 8;
     const size_t dct_bytes = s.fuse ? (size_t)16 * 128 * 4 : 0;
     SSP_TRY(p->f_counter.reserve(64));
     s.work_counter = p->f_counter.as<int32_t>();
@@ -452,14 +528,15 @@ int launch_mfcc_s2k(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStr
     while (waves > 4 && (size_t)s.table_bytes + dct_bytes + (size_t)waves * S2K_WAVE_BYTES > 160 * 1024) waves -= 4;
     const size_t lds = (size_t)s.table_bytes + dct_bytes + (size_t)waves * S2K_WAVE_BYTES;
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream2048): LDS footprint %zu B exceeds 160 KiB", lds);
-    const void* kfn = reinterpret_cast<const void*>(mfcc_stream2048_kernel);
+    auto kern = p->cfg.spec_power == 1 ? mfcc_stream2048_kernel<1> : mfcc_stream2048_kernel<2>;
+    const void* kfn = reinterpret_cast<const void*>(kern);
     if (lds > 64 * 1024) SSP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
-    SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mfcc_stream2048_kernel, 64 * waves, lds));
+    SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * waves, lds));
     const int grid = std::min((n_chunks + waves - 1) / waves, std::max(1, per_cu) * p->ctx->num_cu);
     SSP_HIP(hipMemsetAsync(s.work_counter, 0, 64, stream));
     if (getenv("SSP_DEBUG")) fprintf(stderr, "[ssp] mfcc stream2048: grid %d (%d per CU), lds %zu, %d + %d filterbank steps\n", grid, per_cu, lds, p->s2k_steps, p->s2k_steps1);
-    hipLaunchKernelGGL(mfcc_stream2048_kernel, dim3(grid), dim3(64 * waves), lds, stream, args, s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), lds, stream, args, s);
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }
