@@ -292,7 +292,22 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
 #endif
                 const char* pp = reinterpret_cast<const char*>(P) + (g == 0 ? mstart0 : mstart1);
                 v4f acc0 = v4f{0.f, 0.f, 0.f, 0.f}, acc1 = v4f{0.f, 0.f, 0.f, 0.f};
-                for (int st = 0; st < nst; st += 2) {  // (step counts are even)
+                // four steps per trip while they last (eight 16-byte reads in flight behind one wait: a trip is an LDS round trip with
+                // four packed FMAs' worth of work), then two; even steps feed acc0, odd steps acc1, in step order
+                int st = 0;
+                for (; st + 4 <= nst; st += 4) {
+                    v4f w[4], q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        w[u] = wt[(st + u) * 64];
+                        q[u] = *reinterpret_cast<const v4f*>(pp + 16 * (st + u));
+                    }
+                    acc0 = __builtin_elementwise_fma(q[0], w[0], acc0);
+                    acc1 = __builtin_elementwise_fma(q[1], w[1], acc1);
+                    acc0 = __builtin_elementwise_fma(q[2], w[2], acc0);
+                    acc1 = __builtin_elementwise_fma(q[3], w[3], acc1);
+                }
+                for (; st < nst; st += 2) {  // (step counts are even)
                     const v4f w0 = wt[st * 64], w1 = wt[(st + 1) * 64];
                     const v4f p0 = *reinterpret_cast<const v4f*>(pp + 16 * st), p1 = *reinterpret_cast<const v4f*>(pp + 16 * st + 16);
                     acc0 = __builtin_elementwise_fma(p0, w0, acc0);

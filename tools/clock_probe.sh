@@ -1,6 +1,6 @@
 #!/bin/bash
 # diagnostic (GPU box): engine clock and socket power WHILE a bench stage loops, sampled through rocm-smi next to the running process
-#   tools/clock_probe.sh <stage> [steps]   ->  gpurun_out/clock_<stage>.txt
+#   tools/clock_probe.sh <stage> [steps] [stage-reps]   ->  gpurun_out/clock_<stage>.txt
 # (bench.py's timed region is ~0.2 s; this repeats the stage for several seconds so that the governor's steady state is what is read)
 cd "$(dirname "$0")/.."
 stage=${1:-mfcc}; steps=${2:-600}
@@ -9,7 +9,7 @@ out=gpurun_out/clock_$stage.txt
 : > $out
 rocm-smi --showclocks --showpower --showmaxpower >> $out 2>&1
 echo "=== idle above; running stage $stage x $steps ===" >> $out
-python3 bench.py --steps $steps --warmup 3 --stages $stage --no-cpu-baseline > gpurun_out/clock_$stage.line 2> gpurun_out/clock_$stage.err &
+SSP_BENCH_STAGE_REPS=${3:-3} python3 bench.py --steps $steps --warmup 3 --stages $stage --no-cpu-baseline > gpurun_out/clock_$stage.line 2> gpurun_out/clock_$stage.err &
 pid=$!
 while kill -0 $pid 2>/dev/null; do
     date +%s.%N >> $out
