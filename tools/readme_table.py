@@ -6,9 +6,11 @@ rows = []
 r = d["roofline"]
 rows.append(("fused 39-d MFCC, 100k × 3 s utterances resident in HBM (configs[1]; wave-stream kernel, software-pipelined quad loop, DCT / Δ / ΔΔ on the matrix cores)",
              "%.3g frames/s (%.2f ms/pass)" % (d["value"], r["kernel_ms"]),
-             "%.2f of 8 TB/s HBM; HBM traffic %s × algorithmic (`profiles/mfcc_hbm_traffic.json`); VALU active %s of the SIMD time (`profiles/mfcc_valu_lds_pmc.json`)" % (
+             "%.2f of 8 TB/s HBM; HBM traffic %s × algorithmic (`profiles/mfcc_hbm_traffic.json`); VALU issue %s of every SIMD issuing every cycle at 2.4 GHz, %s at the %s GHz the pass holds on the 1400 W package cap (`profiles/mfcc_valu_lds_pmc.json`, `profiles/r03_clock_power.md`)" % (
                  r["frac"], ("%.3f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])) if r.get("traffic") else "n/a",
-                 ("%.2f" % d["roofline_valu"]["frac"]) if d.get("roofline_valu") else "n/a")))
+                 ("%.2f" % d["roofline_valu"]["frac"]) if d.get("roofline_valu") else "n/a",
+                 ("%.2f" % d["roofline_valu"]["frac_at_sustained_clock"]) if (d.get("roofline_valu") or {}).get("frac_at_sustained_clock") else "n/a",
+                 ("%.2f" % d["roofline_valu"]["sustained_clock_ghz"]) if (d.get("roofline_valu") or {}).get("sustained_clock_ghz") else "n/a")))
 v = d["mfcc_ref26_cmvn"]
 rows.append(("the reference's `extract_feature` output: 13 cepstra + Δ, scaled per utterance (26-d), scaling inside the same kernel at three waves per SIMD",
              "%.3g frames/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of HBM" % v["roofline"]["frac"]))
@@ -18,7 +20,7 @@ rows.append(("in-repo MFCC (arithmetic pinned to the reference's own outputs), 1
              "%.2f / %.2f of HBM" % (a["roofline"]["frac"], b["roofline"]["frac"])))
 v = d["mfcc_librosa"]
 rows.append(("librosa-dialect MFCC (`MFCC_DTW.MFCC_lib`: 2048 / 512, 128 mel, top_db), 200k × 3 s at 8 kHz, 2048-point wave-stream kernel",
-             "%.2g frames/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of HBM (LDS / latency bound, `profiles/mfcc_stream2048_pmc.json`)" % v["roofline"]["frac"]))
+             "%.2g frames/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of HBM (on the package power cap at 2.1 GHz; `profiles/mfcc_stream2048_pmc.json`)" % v["roofline"]["frac"]))
 v = d["plp"]
 rows.append(("PLP features (sidekit `plp`), 100k × 3 s: Bark front end on the wave-stream kernel's dense-band instance + RASTA / LPC-cepstrum back end",
              "%.3g frames/s (%.1f + %.1f ms)" % (v["value"], v["front_ms"], v["back_ms"]), "front end %.2f of HBM" % v["front_roofline"]["frac"]))
