@@ -12,6 +12,8 @@
 //                      P LPC coefficients, P + 1 cepstra); the cosine table of the real IDFT and the equal-loudness curve come
 //                      from LDS
 #include <cmath>
+#include <cstring>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -30,17 +32,31 @@ __global__ __launch_bounds__(256) void plp_rasta_kernel(const float* __restrict_
     const float* __restrict__ xp = x + f0 * nb + b;
     float* __restrict__ yp = y + f0 * nb + b;
     float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
-    float xn = T > 0 ? xp[0] : 0.f;
-    for (int64_t t = 0; t < T; ++t) {
-        const float xv = xn;
-        if (t + 1 < T) xn = xp[(t + 1) * nb];  // next sample in flight under this step's arithmetic
-        const float a1 = t < 4 ? 0.f : -0.94f;
-        const float out = fmaf(0.2f, xv, z0);
-        z0 = fmaf(0.1f, xv, z1) - a1 * out;
-        z1 = z2;  // b2 = 0
-        z2 = fmaf(-0.1f, xv, z3);
-        z3 = -0.2f * xv;
-        yp[t * nb] = t < 4 ? 0.f : out;
+    // RB inputs per trip, the next trip's already in flight: the recursion is serial along time, and with one load ahead every step
+    // waited out most of a memory latency (1.64 ms for 100k x 298 frames x 21 bands; the traffic alone is 0.6 ms)
+    constexpr int RB = 8;
+    float cur[RB], nxt[RB];
+    if (T <= 0) return;
+    // (loads past the utterance's end re-read its last frame, unconditionally: a load under a per-lane condition sits in its own
+    //  branch with a wait behind it; the values are never stored)
+#pragma unroll
+    for (int i = 0; i < RB; ++i) cur[i] = xp[min((int64_t)i, T - 1) * nb];
+    for (int64_t t = 0; t < T; t += RB) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) nxt[i] = xp[min(t + RB + i, T - 1) * nb];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const float xv = cur[i];
+            const float a1 = t + i < 4 ? 0.f : -0.94f;
+            const float out = fmaf(0.2f, xv, z0);
+            z0 = fmaf(0.1f, xv, z1) - a1 * out;
+            z1 = z2;  // b2 = 0
+            z2 = fmaf(-0.1f, xv, z3);
+            z3 = -0.2f * xv;
+            if (t + i < T) yp[(t + i) * nb] = t + i < 4 ? 0.f : out;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) cur[i] = nxt[i];
     }
 }
 
@@ -52,25 +68,31 @@ struct PlpArgs {
     int32_t nb, P;
 };
 
-// NB / PP > 0: compile-time sizes (everything unrolled into registers); 0: runtime sizes up to the maxima
+// Tables of the fixed-size instances, passed BY VALUE in the kernel argument segment: every weight is then a scalar load into an SGPR
+// and rides as the scalar operand of its FMA (from LDS the 273 weights of the 21-band / 12th-order autocorrelation were 273 LDS
+// reads per frame, every thread fetching the same address).
 template <int NB, int PP>
-__global__ __launch_bounds__(128) void plp_cep_kernel(PlpArgs a) {
-    extern __shared__ float sh[];
-    constexpr int NBM = NB > 0 ? NB : PLP_NB_MAX, PM = PP > 0 ? PP : PLP_P_MAX;
-    const int nb = NB > 0 ? NB : a.nb, P = PP > 0 ? PP : a.P;
-    const int n_tab = nb + (P + 1) * nb + (P + 1);
-    for (int i = threadIdx.x; i < n_tab; i += 128) sh[i] = a.tab[i];
-    __syncthreads();
-    const float* eql = sh;
-    const float* cw = sh + nb;              // cw[k * nb + n]: weight of band n in lag k
-    const float* lw = sh + nb + (P + 1) * nb;
-    const int64_t f = (int64_t)blockIdx.x * 128 + threadIdx.x;
-    if (f >= a.n_frames) return;
-    const float* __restrict__ yp = a.y + f * nb;
+struct PlpTab {
+    float lq[NB];              // 0.33 log2(equal loudness) (-inf where the curve is 0)
+    float cw[(PP + 1) * NB];   // cw[k * NB + n]: weight of band n in lag k
+    float lw[PP + 1];          // lifter
+};
+
+// a / b with a hardware reciprocal and one Newton step (the correctly rounded expansion is ~10 instructions and a branchy scale fix-up)
+__device__ __forceinline__ float div_nr(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    r = fmaf(fmaf(-b, r, 1.0f), r, r);
+    return a * r;
+}
+
+// everything after the RASTA filter for one frame, in registers.  z = (exp(y) eql)^0.33 = exp2(0.33 log2(e) y + 0.33 log2(eql)): one
+// FMA and one v_exp_f32 per band (powf(expf()) is ~60 instructions)
+template <int NBM, int PM, class EQ, class CW, class LW>
+__device__ __forceinline__ void plp_frame(const float* __restrict__ yp, float* __restrict__ o, int nb, int P, EQ lq, CW cw, LW lw) {
     float z[NBM];
 #pragma unroll
     for (int n = 0; n < NBM; ++n)
-        if (n < nb) z[n] = powf(expf(yp[n]) * eql[n], 0.33f);
+        if (n < nb) z[n] = __builtin_amdgcn_exp2f(fmaf(yp[n], 0.33f * 1.4426950408889634f, lq(n)));
     // first and last band are replaced by their neighbours
     float zz[NBM];
 #pragma unroll
@@ -84,7 +106,7 @@ __global__ __launch_bounds__(128) void plp_cep_kernel(PlpArgs a) {
             float acc = 0.f;
 #pragma unroll
             for (int n = 0; n < NBM; ++n)
-                if (n < nb) acc = fmaf(zz[n], cw[k * nb + n], acc);
+                if (n < nb) acc = fmaf(zz[n], cw(k, n), acc);
             r[k] = acc;
         }
     // Levinson-Durbin
@@ -97,7 +119,7 @@ __global__ __launch_bounds__(128) void plp_cep_kernel(PlpArgs a) {
 #pragma unroll
             for (int j = 0; j < PM; ++j)
                 if (j < k) acc = fmaf(lp[j], r[k - j], acc);
-            const float refl = -acc / e;
+            const float refl = -div_nr(acc, e);
             e *= 1.0f - refl * refl;
 #pragma unroll
             for (int j = 0; j < PM / 2 + 1; ++j)
@@ -111,7 +133,7 @@ __global__ __launch_bounds__(128) void plp_cep_kernel(PlpArgs a) {
         }
     // cepstra of the gain-normalised polynomial [1, lp] / (e + 1e-8): c0 = ln(e + 1e-8), then the LPC recursion
     float c[PM + 1];
-    c[0] = logf(e + 1e-8f);
+    c[0] = __builtin_amdgcn_logf(e + 1e-8f) * 0.6931471805599453f;
 #pragma unroll
     for (int n = 1; n <= PM; ++n)
         if (n <= P) {
@@ -119,12 +141,36 @@ __global__ __launch_bounds__(128) void plp_cep_kernel(PlpArgs a) {
 #pragma unroll
             for (int m = 1; m < PM + 1; ++m)
                 if (m < n) acc = fmaf((float)(n - m) * lp[m - 1], c[n - m], acc);
-            c[n] = -(lp[n - 1] + acc / (float)n);
+            c[n] = -fmaf(acc, 1.0f / (float)n, lp[n - 1]);
         }
-    float* __restrict__ o = a.out + f * (P + 1);
 #pragma unroll
     for (int n = 0; n <= PM; ++n)
-        if (n <= P) o[n] = c[n] * lw[n];
+        if (n <= P) o[n] = c[n] * lw(n);
+}
+
+// fixed sizes: thread = frame, tables in the kernel arguments
+template <int NB, int PP>
+__global__ __launch_bounds__(128) void plp_cep_fixed_kernel(PlpArgs a, PlpTab<NB, PP> t) {
+    const int64_t f = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (f >= a.n_frames) return;
+    plp_frame<NB, PP>(a.y + f * NB, a.out + f * (PP + 1), NB, PP, [&](int n) { return t.lq[n]; }, [&](int k, int n) { return t.cw[k * NB + n]; },
+                      [&](int n) { return t.lw[n]; });
+}
+
+// runtime sizes up to the maxima: tables from LDS
+__global__ __launch_bounds__(128) void plp_cep_kernel(PlpArgs a) {
+    extern __shared__ float sh[];
+    const int nb = a.nb, P = a.P;
+    const int n_tab = nb + (P + 1) * nb + (P + 1);
+    for (int i = threadIdx.x; i < n_tab; i += 128) sh[i] = a.tab[i];
+    __syncthreads();
+    const float* lq = sh;
+    const float* cw = sh + nb;
+    const float* lw = sh + nb + (P + 1) * nb;
+    const int64_t f = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    if (f >= a.n_frames) return;
+    plp_frame<PLP_NB_MAX, PLP_P_MAX>(a.y + f * nb, a.out + f * (P + 1), nb, P, [&](int n) { return lq[n]; }, [&](int k, int n) { return cw[k * nb + n]; },
+                                     [&](int n) { return lw[n]; });
 }
 
 }  // namespace ssp
@@ -152,7 +198,8 @@ extern "C" int ssp_plp_post(ssp_ctx* ctx, const float* logspec, const ssp_segmen
     const double zmax = 6.0 * std::asinh((double)fmax_hz / 600.0);
     for (int n = 0; n < nb; ++n) {
         const double hz = 600.0 * std::sinh(zmax * n / (nb - 1) / 6.0), fsq = hz * hz, ft = fsq + 1.6e5;
-        tab[n] = (float)((fsq / ft) * (fsq / ft) * ((fsq + 1.44e6) / (fsq + 9.61e6)));
+        const double eql = (fsq / ft) * (fsq / ft) * ((fsq + 1.44e6) / (fsq + 9.61e6));
+        tab[n] = eql > 0.0 ? (float)(0.33 * std::log2(eql)) : -INFINITY;  // (the kernel forms (exp(y) eql)^0.33 as exp2(0.33 log2(e) y + this))
     }
     const int N = 2 * (nb - 1);
     for (int k = 0; k <= P; ++k)
@@ -187,9 +234,17 @@ extern "C" int ssp_plp_post(ssp_ctx* ctx, const float* logspec, const ssp_segmen
     PlpArgs a{d_in, d_out, d_tab.as<float>(), F, nb, P};
     const size_t lds = tab.size() * sizeof(float);
     const unsigned grid = (unsigned)ceil_div<int64_t>(F, 128);
-    if (nb == 21 && P == 12) hipLaunchKernelGGL((plp_cep_kernel<21, 12>), dim3(grid), dim3(128), lds, s, a);
-    else if (nb == 17 && P == 12) hipLaunchKernelGGL((plp_cep_kernel<17, 12>), dim3(grid), dim3(128), lds, s, a);
-    else hipLaunchKernelGGL((plp_cep_kernel<0, 0>), dim3(grid), dim3(128), lds, s, a);
+    auto launch_fixed = [&](auto tag_nb, auto tag_p) {
+        constexpr int NB = decltype(tag_nb)::value, PP = decltype(tag_p)::value;
+        PlpTab<NB, PP> t;
+        memcpy(t.lq, tab.data(), sizeof(t.lq));
+        memcpy(t.cw, tab.data() + NB, sizeof(t.cw));
+        memcpy(t.lw, tab.data() + NB + (PP + 1) * NB, sizeof(t.lw));
+        hipLaunchKernelGGL((plp_cep_fixed_kernel<NB, PP>), dim3(grid), dim3(128), 0, s, a, t);
+    };
+    if (nb == 21 && P == 12) launch_fixed(std::integral_constant<int, 21>{}, std::integral_constant<int, 12>{});
+    else if (nb == 17 && P == 12) launch_fixed(std::integral_constant<int, 17>{}, std::integral_constant<int, 12>{});
+    else hipLaunchKernelGGL(plp_cep_kernel, dim3(grid), dim3(128), lds, s, a);
     SSP_HIP(hipGetLastError());
     SSP_TRY(tm.stop(s, kernel_ms));
     SSP_TRY(sout.back(ctx, ceps_out, out_bytes, where));
