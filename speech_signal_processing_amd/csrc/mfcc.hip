@@ -271,13 +271,24 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
                 const v2f o = cmul_negi(d, tw[k]);
                 const v2f xa = e + o, xb = e - o;
                 float p0 = xa.x * xa.x + xa.y * xa.y, p1 = xb.x * xb.x + xb.y * xb.y;
-                if (a.spec_power == 1) {
-                    p0 = sqrtf(p0);
-                    p1 = sqrtf(p1);
-                }
-                pa[i] = p0 * a.spec_scale;
-                pb[i] = p1 * a.spec_scale;
+                pa[i] = p0;
+                pb[i] = p1;
             }
+        }
+        // magnitude dialects: v_sqrt_f32 (1 ulp) under ONE wave-uniform branch behind the loop.  (Inside the unrolled loop the
+        // compiler if-converted the test: sqrtf()'s correctly rounded expansion, ~18 instructions per bin, ran for the power
+        // dialects too and a select dropped the result.)
+        if (a.spec_power == 1) {
+#pragma unroll
+            for (int i = 0; i < NSP; ++i) {
+                pa[i] = __builtin_amdgcn_sqrtf(pa[i]);
+                pb[i] = __builtin_amdgcn_sqrtf(pb[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NSP; ++i) {
+            pa[i] *= a.spec_scale;
+            pb[i] *= a.spec_scale;
         }
         wave_lds_sync();
         float* P = reinterpret_cast<float*>(buf);
