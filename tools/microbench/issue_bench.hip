@@ -5,6 +5,8 @@
 // every wave stores its s_memtime span; the host reports  span / (REP * ITERS * waves_per_simd)  = cycles per instruction per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -19,13 +21,14 @@ constexpr int ITERS = 2000;
 #define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 enum Op { FMA, PKFMA, PKADD, PKMUL, ADD, MUL, DPPMOV, DPPADD, FMAC, LOGF, PKFMA_SEL, MIX_PK_PLAIN, DSR64, DSR128, DSW64, DSW32, DSR32,
-          MFMA16, MFMA16_V4, MFMA16_V8, MFMA16_V12, MFMA4, MFMA4_V2, PKFMA_DEP, FMA_DEP, BPERM, MFMA16_PK2, MFMA16_PK4, MFMA16_PK6, NOPS };
+          MFMA16, MFMA16_V4, MFMA16_V8, MFMA16_V12, MFMA4, MFMA4_V2, PKFMA_DEP, FMA_DEP, BPERM, MFMA16_PK2, MFMA16_PK4, MFMA16_PK6, SNOP, VMOV, NOPS };
 static const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_add_f32", "v_mul_f32", "v_mov_b32_dpp row_mirror",
                               "v_add_f32_dpp row_mirror", "v_fmac_f32", "v_log_f32", "v_pk_fma_f32 op_sel", "pk_fma + fma alternating (per pair)",
                               "ds_read_b64", "ds_read_b128", "ds_write_b64", "ds_write_b32", "ds_read_b32",
                               "mfma_16x16x4_f32 alone", "mfma_16x16x4 + 4 v_fma (per group)", "mfma_16x16x4 + 8 v_fma (per group)", "mfma_16x16x4 + 12 v_fma (per group)",
                               "mfma_4x4x1_16b_f32 alone", "mfma_4x4x1 + 2 v_fma (per group)", "v_pk_fma_f32 dependent chain", "v_fma_f32 dependent chain",
-                              "ds_bpermute_b32", "mfma_16x16x4 + 2 v_pk_fma (per group)", "mfma_16x16x4 + 4 v_pk_fma (per group)", "mfma_16x16x4 + 6 v_pk_fma (per group)"};
+                              "ds_bpermute_b32", "mfma_16x16x4 + 2 v_pk_fma (per group)", "mfma_16x16x4 + 4 v_pk_fma (per group)", "mfma_16x16x4 + 6 v_pk_fma (per group)",
+                              "s_nop 0", "v_mov_b32"};
 // instructions per body (for reporting): groups count as 1
 static int body_count(int op) { return 32; }
 
@@ -77,6 +80,14 @@ __global__ __launch_bounds__(256) void bench(unsigned long long* spans, float* s
 #undef X
             } else if constexpr (OP == ADD) {
 #define X(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(s[i]) : "v"(c.x));
+                R8(X)
+#undef X
+            } else if constexpr (OP == SNOP) {
+#define X(i) asm volatile("s_nop 0");
+                R8(X)
+#undef X
+            } else if constexpr (OP == VMOV) {
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(s[i]) : "v"(s[(i + 1) & 7]));
                 R8(X)
 #undef X
             } else if constexpr (OP == MUL) {
@@ -204,10 +215,55 @@ int run(int ncu, unsigned long long* d_spans, float* d_sink) {
     return 0;
 }
 
-int main() {
+// power mode: one instruction kind at `wps` waves per SIMD for `sec` seconds of back-to-back launches (tools/microbench/energy.sh samples
+// rocm-smi next to it); prints the wave-instruction rate of the whole chip and the clock
+template <int OP>
+int power(int ncu, unsigned long long* d_spans, float* d_sink, int wps, double sec) {
+    const int grid = ncu * wps, iters = 20000;
+    bench<OP><<<grid, 256>>>(d_spans, d_sink, 10);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    double tot_ms = 0, tot_instr = 0, cyc = 0;
+    int n = 0;
+    while (tot_ms < sec * 1e3) {
+        CK(hipEventRecord(e0));
+        bench<OP><<<grid, 256>>>(d_spans, d_sink, iters);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        tot_ms += ms;
+        tot_instr += (double)grid * 4 * 32.0 * iters;   // wave-instructions (groups count as one)
+        std::vector<unsigned long long> h(grid * 4);
+        CK(hipMemcpy(h.data(), d_spans, h.size() * 8, hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        cyc = (double)h[h.size() / 2] / (ms * 1e6);
+        ++n;
+    }
+    printf("RESULT op=\"%s\" wps=%d seconds=%.2f wave_instr_per_s=%.4e memtime_ghz=%.3f launches=%d\n", names[OP], wps, tot_ms * 1e-3, tot_instr / (tot_ms * 1e-3), cyc, n);
+    return 0;
+}
+
+int main(int argc, char** argv) {
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
     const int ncu = p.multiProcessorCount;
+    if (argc >= 5 && !strcmp(argv[1], "power")) {
+        unsigned long long* d_spans;
+        float* d_sink;
+        CK(hipMalloc(&d_spans, ncu * 4 * 4 * 8));
+        CK(hipMalloc(&d_sink, 4096));
+        const int op = atoi(argv[2]), wps = atoi(argv[3]);
+        const double sec = atof(argv[4]);
+        switch (op) {
+#define P(O) case O: return power<O>(ncu, d_spans, d_sink, wps, sec);
+            P(SNOP) P(VMOV) P(FMA) P(PKFMA) P(PKADD) P(PKMUL) P(ADD) P(DPPMOV) P(LOGF) P(DSR32) P(DSR64) P(DSR128) P(DSW32) P(DSW64) P(BPERM) P(MFMA16) P(MFMA16_PK4)
+#undef P
+            default: printf("op %d not in the power list\n", op); return 1;
+        }
+    }
     printf("%s, %d CUs; cycles per instruction (or per group) per SIMD, at 1..4 waves per SIMD (s_memtime span; 100 MHz const clock? see GHz column)\n", p.gcnArchName, ncu);
     unsigned long long* d_spans;
     float* d_sink;
