@@ -36,12 +36,18 @@ def _cmd(src: str, obj: str) -> list:
     return [HIPCC, *FLAGS, *SOURCE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
 
 
+def _stamp_text(src: str, obj: str) -> str:
+    """the command line with the package directory abstracted: the tree is copied to another path on the GPU box, and objects that travel
+    with it must still count as built with today's flags there"""
+    return " ".join(_cmd(src, obj)).replace(os.path.dirname(obj), "@OBJ@").replace(HERE, "@PKG@")
+
+
 def _stamp_ok(src: str, obj: str) -> bool:
     """the object was compiled with exactly today's command line (flags are part of the up-to-date check: changing SSP_EXTRA_FLAGS or
     SOURCE_FLAGS must not silently reuse objects built with the old ones)"""
     try:
         with open(obj + ".cmd") as f:
-            return f.read() == " ".join(_cmd(src, obj))
+            return f.read() == _stamp_text(src, obj)
     except OSError:
         return False
 
@@ -71,7 +77,7 @@ def _compile(src: str) -> str:
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     with open(obj + ".cmd", "w") as f:
-        f.write(" ".join(cmd))
+        f.write(_stamp_text(src, obj))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
     return obj
@@ -102,6 +108,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print("reused", LIB)
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
+    # one builder at a time (ranks of a multi-process launch may all arrive here): the others wait, then find everything up to date
+    import fcntl
+    lock = open(os.path.join(OBJ_DIR, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    if not force and not needs_build():
+        _record("reused", [])
+        if verbose:
+            print("reused", LIB)
+        return LIB
     if force:
         for f in os.listdir(OBJ_DIR):
             os.remove(os.path.join(OBJ_DIR, f))

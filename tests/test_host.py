@@ -221,7 +221,8 @@ def test_build_stamp_and_kernel_hash(tmp_path, monkeypatch):
     from speech_signal_processing_amd import build as b
     obj = str(tmp_path / "x.o")
     assert not b._stamp_ok("gmm.hip", obj)                      # no stamp yet
-    open(obj + ".cmd", "w").write(" ".join(b._cmd("gmm.hip", obj)))
+    open(obj + ".cmd", "w").write(b._stamp_text("gmm.hip", obj))
+    assert b.HERE not in b._stamp_text("gmm.hip", obj)          # (the stamp survives the tree being copied to another path)
     assert b._stamp_ok("gmm.hip", obj)
     assert "-fno-slp-vectorize" in b._cmd("gmm.hip", obj) and "-fno-slp-vectorize" not in b._cmd("ctx.hip", obj)
     monkeypatch.setattr(b, "FLAGS", b.FLAGS + ["-DSSP_SOMETHING"])
