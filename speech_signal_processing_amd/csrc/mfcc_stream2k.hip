@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "mfcc.hpp"
@@ -82,7 +83,11 @@ struct S2kArgs {
 // POWER: 2 = power spectrum, 1 = magnitude.  A template parameter, not a.spec_power: as a run-time (wave-uniform) condition inside the
 // unrolled split loop the compiler if-converted it — BOTH sides evaluated, the magnitude side being a correctly rounded square root of
 // ~18 instructions per bin — which cost the power dialects 290 of their 845 vector instructions per frame.
-template <int POWER>
+// SH: rows of 128 samples by which consecutive frames advance when the hop is a whole number of rows (hop = 128 SH: 4 for the librosa
+// dialect's 512, 8 for 1024; 0: any other hop).  A lane's 16 sample pairs of the next frame are then its pairs SH..15 of this frame
+// (in padded-signal coordinates, so at the utterance ends too) plus SH new ones: 16 - SH of the 16 eight-byte loads per frame — every
+// sample was fetched 2048 / hop times through L2 — become register moves.
+template <int POWER, int SH>
 __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(MfccArgs a, S2kArgs s) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,12 +147,14 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
         const float* __restrict__ x = a.samples + s0;
         const int t0 = __builtin_amdgcn_readfirstlane(ch.t0), n = __builtin_amdgcn_readfirstlane(ch.n);
         float wave_max = -INFINITY;
-        auto load_frame = [&](int t, v2f (&v)[16]) {
+        // rows R0..15 of frame t
+        auto load_frame = [&](int t, v2f (&v)[16], auto r0tag) {
+            constexpr int R0 = decltype(r0tag)::value;
             const int64_t g0 = (int64_t)t * hop - (centre ? M : 0);
-            if (g0 >= 0 && g0 + 2 * M <= N) {
+            if (g0 + 128 * R0 >= 0 && g0 + 2 * M <= N) {
                 const float* __restrict__ xp = x + g0 + 2 * lane;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = R0; r < 16; ++r) {
                     const f2u t2 = *reinterpret_cast<const f2u*>(xp + 128 * r);
                     v[r] = v2f{t2.x, t2.y};
                 }
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
                 int lane_e;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = R0; r < 16; ++r) {
                     float e[2];
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
@@ -186,13 +193,19 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
         };
 
         v2f nx[16];
-        load_frame(t0, nx);
+        load_frame(t0, nx, std::integral_constant<int, 0>{});
         for (int t = t0; t < t0 + n; ++t) {
             v2f z[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = nx[r] * lds_read_v2f(&winl[64 * r]);
 #ifndef SSP_2K_NOPREFETCH  // (ablation, wrong results: every frame transforms the chunk's first one)
-            if (t + 1 < t0 + n) load_frame(t + 1, nx);
+            if (t + 1 < t0 + n) {
+                if constexpr (SH > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16 - SH; ++r) nx[r] = nx[r + SH];
+                }
+                load_frame(t + 1, nx, std::integral_constant<int, (SH > 0 ? 16 - SH : 0)>{});
+            }
 #endif
             // ---- pass 1: DFT16 over r (points 64 r + l), twiddle W_1024^(l k1)
             fft16(z);
@@ -543,7 +556,12 @@ int launch_mfcc_s2k(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStr
     while (waves > 4 && (size_t)s.table_bytes + dct_bytes + (size_t)waves * S2K_WAVE_BYTES > 160 * 1024) waves -= 4;
     const size_t lds = (size_t)s.table_bytes + dct_bytes + (size_t)waves * S2K_WAVE_BYTES;
     if (lds > 160 * 1024) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream2048): LDS footprint %zu B exceeds 160 KiB", lds);
-    auto kern = p->cfg.spec_power == 1 ? mfcc_stream2048_kernel<1> : mfcc_stream2048_kernel<2>;
+    const int sh = p->cfg.hop == 512 ? 4 : (p->cfg.hop == 1024 ? 8 : 0);
+    const bool mag = p->cfg.spec_power == 1;
+    auto kern = sh == 4 ? (mag ? mfcc_stream2048_kernel<1, 4> : mfcc_stream2048_kernel<2, 4>)
+                        : (sh == 8 ? (mag ? mfcc_stream2048_kernel<1, 8> : mfcc_stream2048_kernel<2, 8>)
+                                   : (mag ? mfcc_stream2048_kernel<1, 0> : mfcc_stream2048_kernel<2, 0>));
+    if (getenv("SSP_2K_NO_SLIDE")) kern = mag ? mfcc_stream2048_kernel<1, 0> : mfcc_stream2048_kernel<2, 0>;
     const void* kfn = reinterpret_cast<const void*>(kern);
     if (lds > 64 * 1024) SSP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
