@@ -222,6 +222,40 @@ def test_stream_kernel_dense_bands_plp_front_end(ssp):
         assert_feat_close(g3[u], O.mfcc_pipeline(sigs[u], cfg, w, fb, dct), what=f"plp front end utt {u}")
 
 
+@pytest.mark.parametrize("hop", [512, 1024, 256, 700])
+@pytest.mark.parametrize("dialect", ["librosa", "inrepo"])
+def test_stream2048_kernel_hops_and_sliding_rows(ssp, dialect, hop, monkeypatch):
+    """The 2048-point kernel keeps a lane's sample pairs in registers from frame to frame when the hop is a whole number of 128-sample rows
+    (hop 512: 4 rows, hop 1024: 8 rows) and loads whole frames otherwise (256, 700).  Every hop against the oracle and the generic
+    kernel; for the sliding hops the result is bit-identical to the same kernel with sliding switched off (the samples are the same
+    numbers, fetched once instead of 2048 / hop times) — on centred (reflect-padded) and on zero-padded framing, single- and
+    multi-chunk utterances, utterances shorter than a window."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    fs = 8000
+    if dialect == "librosa":
+        tables = pkg.preset_librosa(fs, 13, hop=hop)
+        cfg, w, fb, dct = O.librosa_tables(fs, 13, hop=hop)
+    else:
+        tables = pkg.preset_inrepo(fs, 2048, hop)
+        cfg, w, fb, dct = O.inrepo_tables(fs, 2048, hop)
+    sigs = [synth_audio(u, n, fs) for u, n in enumerate([24000, 2049, 1500, 70001, 2048 * 3, 4097, 150000])]
+    g4, fseg = _run_plan(api, tables, sigs, variant=4)
+    g1, _ = _run_plan(api, tables, sigs, variant=1)
+    worst = 0.0
+    for u, s_ in enumerate(sigs):
+        ref = O.mfcc_pipeline(s_, cfg, w, fb, dct)
+        assert g4[u].shape == ref.shape, (u, g4[u].shape, ref.shape)
+        assert_feat_close(g4[u], ref, what=f"2048 kernel {dialect} hop {hop} utt {u}")
+        worst = max(worst, float(np.abs(g4[u] - g1[u]).max() / max(1.0, np.abs(g1[u]).max())))
+    assert worst <= FEAT_TOL, worst
+    if hop in (512, 1024):
+        monkeypatch.setenv("SSP_2K_NO_SLIDE", "1")
+        g4n, _ = _run_plan(api, tables, sigs, variant=4)
+        for u in range(len(sigs)):
+            assert np.array_equal(g4[u], g4n[u]), (u, float(np.abs(g4[u] - g4n[u]).max()))
+
+
 @pytest.mark.parametrize("dialect", ["librosa8k", "librosa16k", "inrepo2048"])
 def test_stream2048_kernel_vs_oracle_and_generic(ssp, dialect):
     """n_fft == 2048 dialects on the 2048-point wave-stream kernel (variant 4; first pass) + the clamp / DCT pass: MFCC_DTW.MFCC_lib's
