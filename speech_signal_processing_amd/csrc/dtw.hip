@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(DtwArgs a) {
 
 
 // dim == 1 all-pairs matcher, tuned: the lane's previous row is updated in place (three scalars carry diagonal / left / new
-// value along the row), x[i + 1] is fetched one step ahead (the plain kernel stalls a full memory latency per step on x[i]),
-// columns past the end propagate the last valid value so that the lane's hand-over value is always prev[W - 1].
+// value along the row), x[i + 1] is fetched one step ahead (the plain kernel stalls a full memory latency per step on x[i]);
+// three instructions per cell (subtract, min3, add with |.| on its operand).
 template <int W>
 __global__ __launch_bounds__(256) void dtw1_kernel(DtwArgs a) {
     const int lane = threadIdx.x & 63;
@@ -178,16 +178,20 @@ __global__ __launch_bounds__(256) void dtw1_kernel(DtwArgs a) {
                         const float up = prev[k];
                         const float v = fabsf(xi - yreg[k]) + fminf(d, fminf(up, l));
                         d = up;
-                        l = k < nvalid ? v : l;  // past the end: carry the last valid value
-                        prev[k] = l;
+                        l = v;  // (columns past the template's end compute on: a cell depends on columns <= its own, so what they hold never
+                        prev[k] = v;  //  reaches a valid one; a per-cell select to freeze them was a quarter of the loop's instructions)
                     }
                     diagl = left;
                     last = l;
-                    if (lane == lanes - 1) {
-                        if (more) __hip_atomic_store(&bnd[i], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (i == r - 1 && !more) result = l;
-                    }
+                    // (a block that hands over to a next one is full: its last lane's last column is valid)
+                    if (more && lane == lanes - 1) __hip_atomic_store(&bnd[i], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            }
+            if (!more && lane == lanes - 1) {  // D[r - 1][c - 1]: the last valid column of the last lane, after its last row
+                float lv = prev[0];
+#pragma unroll
+                for (int k = 1; k < W; ++k) lv = k == nvalid - 1 ? prev[k] : lv;
+                result = lv;
             }
             if (more) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         }
