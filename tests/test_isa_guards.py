@@ -1,0 +1,83 @@
+"""Guards on the generated gfx950 ISA (hipcc cross-compiles here, no GPU): the instruction classes that round 3 found hiding in hot loops —
+a library expansion nobody asked for (an if-converted `sqrtf`, `powf(expf())`, the division expansion) or a spill reload in a frame
+loop — must not come back unnoticed.  Each check compiles ONE small source to assembly (seconds)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "speech_signal_processing_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _isa(src, tmp_path):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = str(tmp_path / (src + ".s"))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-munsafe-fp-atomics", "-Wno-pass-failed",
+                        "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in open(out):
+        m = re.match(r"^(_Z\S+):", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+            continue
+        t = line.strip()
+        if cur is None or not t or t.startswith((";", ".")):
+            continue
+        op = t.split()[0]
+        if op == "s_endpgm":
+            cur = None
+            continue
+        kernels[cur].append(t)
+    return kernels
+
+
+def _count(instrs, pattern):
+    return sum(1 for t in instrs if re.match(pattern, t.split()[0]))
+
+
+def test_stream2048_power_dialects_carry_no_square_root(tmp_path):
+    """mfcc_stream2048_kernel<POWER = 2, *>: no v_sqrt (the magnitude branch was once if-converted into the power dialects: 290 of 845
+    vector instructions per frame); the magnitude instances use the hardware instruction without libm's fix-up sequence; and the frame
+    loop of every instance is free of scratch traffic (at most the one spill outside it)."""
+    k = _isa("mfcc_stream2k.hip", tmp_path)
+    inst = {n: v for n, v in k.items() if "mfcc_stream2048_kernel" in n}
+    assert len(inst) == 6, list(inst)
+    for n, v in inst.items():
+        power = int(re.search(r"kernelILi(\d)ELi", n).group(1))
+        n_sqrt = _count(v, r"v_sqrt_f32")
+        if power == 2:
+            assert n_sqrt == 0, (n, n_sqrt)
+        else:
+            assert 0 < n_sqrt <= 20 and _count(v, r"v_cmp_class_f32") == 0, (n, n_sqrt)   # 17 bins per lane, no denormal rescue
+        assert _count(v, r"scratch_load") <= 2, (n, _count(v, r"scratch_load"))
+        assert _count(v, r"v_div_(scale|fmas|fixup)") == 0, n
+
+
+def test_plp_cepstrum_kernel_is_lean(tmp_path):
+    """plp_cep_fixed_kernel<21, 12>: a frame is ~800 instructions — one v_exp per band, twelve reciprocals, one logarithm; no division
+    expansion, no ldexp / frexp (powf), no LDS reads for the tables (they are scalar operands)."""
+    k = _isa("plp.hip", tmp_path)
+    name = [n for n in k if "plp_cep_fixed_kernelILi21ELi12E" in n]
+    assert len(name) == 1, list(k)
+    v = k[name[0]]
+    assert len(v) < 1000, len(v)
+    assert _count(v, r"v_div_(scale|fmas|fixup)") == 0 and _count(v, r"v_(ldexp|frexp)") == 0
+    assert _count(v, r"ds_read") == 0
+    assert _count(v, r"v_exp_f32") == 19 and _count(v, r"v_rcp_f32") == 12 and _count(v, r"v_log_f32") == 1
+
+
+def test_dtw_cell_is_three_instructions(tmp_path):
+    """dtw1_kernel<20>: the recurrence loop holds no per-cell select (the kernel's selects are the 20 of the template load's bounds and
+    the 20 of the final pick of the last valid column)."""
+    k = _isa("dtw.hip", tmp_path)
+    name = [n for n in k if "dtw1_kernelILi20E" in n]
+    assert len(name) == 1, list(k)
+    v = k[name[0]]
+    assert _count(v, r"v_cndmask") <= 45, _count(v, r"v_cndmask")
+    assert _count(v, r"v_min3_f32") >= 20
