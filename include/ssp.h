@@ -124,6 +124,15 @@ int ssp_segments_read(const ssp_segments* seg, int64_t* offsets_out /* HOST int6
 int ssp_mfcc_plan_create(ssp_ctx* ctx, const ssp_mfcc_cfg* cfg, const float* window, const float* fbank,
                          const float* dct, ssp_mfcc_plan** out);
 int ssp_mfcc_plan_destroy(ssp_mfcc_plan* plan);
+/* SSP_MFCC_REPRODUCIBLE: the float32 bits of an utterance's features do not depend on the batch it is in, its place in it, or the
+ * machine's CU count.  By default small batches cut utterances into short chunks for latency (each agrees with the uncut utterance to
+ * rounding in the delta-delta block) and machine-filling batches scale inside the kernel (cmvn; rounding again): with the flag every
+ * cut chunk recomputes 16 frames of history, which reproduces the uncut bits, scaling always runs as the stand-alone kernel and the
+ * 2048-point dialects always take the second-pass clamp + DCT.  Costs latency on single-utterance calls (about 30 % more frames per
+ * chunk) and about 15 % on machine-filling batches with cmvn.  (Holds for finite features: a step whose window holds a non-finite
+ * cepstrum takes a term-by-term path whose finite rows agree with the matrix-core path to rounding.) */
+#define SSP_MFCC_REPRODUCIBLE 1u
+int ssp_mfcc_plan_set_flags(ssp_mfcc_plan* plan, uint32_t flags);
 int ssp_mfcc_num_frames(const ssp_mfcc_cfg* cfg, int64_t n_samples, int64_t* n_frames);
 int ssp_mfcc_out_dim(const ssp_mfcc_cfg* cfg, int32_t* d_out);
 /* frame segments derived from sample segments with the plan's framing rule */

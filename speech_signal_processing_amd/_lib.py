@@ -56,6 +56,7 @@ SIGNATURES = {
     "ssp_segments_read": (C.c_int, [_P, _I64P]),
     "ssp_mfcc_plan_create": (C.c_int, [_P, C.POINTER(ssp_mfcc_cfg), _F32P, _F32P, _F32P, C.POINTER(_P)]),
     "ssp_mfcc_plan_destroy": (C.c_int, [_P]),
+    "ssp_mfcc_plan_set_flags": (C.c_int, [_P, C.c_uint32]),
     "ssp_mfcc_num_frames": (C.c_int, [C.POINTER(ssp_mfcc_cfg), C.c_int64, _I64P]),
     "ssp_mfcc_out_dim": (C.c_int, [C.POINTER(ssp_mfcc_cfg), C.POINTER(C.c_int32)]),
     "ssp_mfcc_frame_segments": (C.c_int, [_P, _P, C.POINTER(_P)]),

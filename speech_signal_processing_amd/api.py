@@ -224,6 +224,11 @@ class MfccPlan:
     def d_out(self) -> int:
         return self.cfg.d_out
 
+    def set_reproducible(self, on: bool = True) -> "MfccPlan":
+        """SSP_MFCC_REPRODUCIBLE (include/ssp.h): an utterance's float32 bits no longer depend on the batch or the machine."""
+        _lib.check(self._lib.ssp_mfcc_plan_set_flags(self._h, 1 if on else 0))
+        return self
+
     def num_frames(self, n_samples: int) -> int:
         out = C.c_int64()
         _lib.check(self._lib.ssp_mfcc_num_frames(C.byref(self._cs), int(n_samples), C.byref(out)))

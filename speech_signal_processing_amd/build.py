@@ -110,7 +110,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     # one builder at a time (ranks of a multi-process launch may all arrive here): the others wait, then find everything up to date
     import fcntl
-    lock = open(os.path.join(OBJ_DIR, ".lock"), "w")
+    lock = open(os.path.join(HERE, ".build.lock"), "w")  # (outside OBJ_DIR: the force path empties that directory under the lock)
     fcntl.flock(lock, fcntl.LOCK_EX)
     if not force and not needs_build():
         _record("reused", [])
@@ -125,10 +125,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(_compile, SOURCES))
     compiled = [s for s, o in zip(SOURCES, objs) if os.path.getmtime(o) > before[s]]
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    tmp = LIB + ".tmp.%d" % os.getpid()  # link beside the target, then rename: a reader never maps a half-written library
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    os.replace(tmp, LIB)
     _record("forced" if force else "compiled", compiled)
     if verbose:
         print("built", LIB, "(%d of %d sources compiled)" % (len(compiled), len(SOURCES)))

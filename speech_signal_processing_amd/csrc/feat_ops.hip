@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ in
         int u = base;
         while (off[u + 1] <= row) ++u;  // (empty utterances are skipped too)
         const int64_t a = off[u], b = off[u + 1] - 1;  // edge padding inside the utterance (GMM_UBM.py:64)
-        float acc = 0.f;
+        // (the n = 0 term of GMM_UBM.py:68's numpy.dot: 0 . c[t] — nothing for a finite cepstrum, NaN for a non-finite one, which is how
+        //  the reference's delta comes out non-finite AT a silent frame whose neighbours are not)
+        float acc = 0.f * in[row * dim + d];
         if (NC > 0) {
             float vp[NC > 0 ? NC : 1], vm[NC > 0 ? NC : 1];
 #pragma unroll
@@ -89,31 +91,46 @@ __global__ __launch_bounds__(256) void cmvn_kernel(const float* in, float* out, 
     for (int c0 = 0; c0 < dim; c0 += 256) {  // one trip unless dim > 256
         const int c = c0 + (dim <= 256 ? tid % dim : tid), ph = dim <= 256 ? tid / dim : 0;
         const bool act = c < dim && ph < R;
-        float s = 0.f;
+        // sklearn.preprocessing.scale takes the statistics over the entries that are not NaN (nanmean / nanstd) and leaves the NaN
+        // entries as they are: a digitally silent frame of a dialect without a log floor is such a row (GMM_UBM.py:89-93)
+        const int rs = dim <= 256 ? dim : 256;
+        float s = 0.f, cn = 0.f;
         if (act)
-            for (int t = ph; t < T; t += R) s += src[(size_t)t * dim + c];
-        if (act) red[ph * (dim <= 256 ? dim : 256) + (c - c0)] = s;
+            for (int t = ph; t < T; t += R) {
+                const float x = src[(size_t)t * dim + c];
+                const bool ok = x == x;
+                s += ok ? x : 0.f;
+                cn += ok ? 1.f : 0.f;
+            }
+        if (act) red[ph * rs + (c - c0)] = cn;
+        __syncthreads();
+        float n_ok = 0.f;
+        if (act)
+            for (int k = 0; k < R; ++k) n_ok += red[k * rs + (c - c0)];
+        __syncthreads();
+        if (act) red[ph * rs + (c - c0)] = s;
         __syncthreads();
         if (act && ph == 0) {
             float tot_s = 0.f;
-            for (int k = 0; k < R; ++k) tot_s += red[k * (dim <= 256 ? dim : 256) + (c - c0)];
-            mean[c] = tot_s / (float)T;
+            for (int k = 0; k < R; ++k) tot_s += red[k * rs + (c - c0)];
+            mean[c] = tot_s / n_ok;  // (no entry at all: NaN, as nanmean has it)
         }
         __syncthreads();
         float v = 0.f;
         if (act) {
             const float m = mean[c];
             for (int t = ph; t < T; t += R) {
-                const float e = src[(size_t)t * dim + c] - m;
+                const float x = src[(size_t)t * dim + c];
+                const float e = x == x ? x - m : 0.f;
                 v = fmaf(e, e, v);
             }
-            red[ph * (dim <= 256 ? dim : 256) + (c - c0)] = v;
+            red[ph * rs + (c - c0)] = v;
         }
         __syncthreads();
         if (act && ph == 0) {
             float tot_v = 0.f;
-            for (int k = 0; k < R; ++k) tot_v += red[k * (dim <= 256 ? dim : 256) + (c - c0)];
-            float sd = sqrtf(tot_v / (float)T);
+            for (int k = 0; k < R; ++k) tot_v += red[k * rs + (c - c0)];
+            float sd = sqrtf(tot_v / n_ok);
             if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;  // sk: _handle_zeros_in_scale
             istd[c] = 1.0f / sd;
         }

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
         for (int i = tid; i < (db - da) * nc; i += nt) {
             const int r = i / nc, q = i - r * nc;
             const int u = da + r;
-            float acc = 0.f;
+            float acc = 0.f * ceps[(size_t)(u - ta) * nc + q];  // (the n = 0 term of numpy.dot, GMM_UBM.py:68: 0 . NaN = NaN)
             for (int m = 1; m <= Nd; ++m) {
                 const int up = min(u + m, T - 1), um = max(u - m, 0);
                 acc += (float)m * (ceps[(size_t)(up - ta) * nc + q] - ceps[(size_t)(um - ta) * nc + q]);
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
         for (int i = tid; i < n * nc; i += nt) {
             const int r = i / nc, q = i - r * nc;
             const int u = t0 + r;
-            float acc = 0.f;
+            float acc = 0.f * dlt[(size_t)(u - da) * nc + q];
             for (int m = 1; m <= Nd; ++m) {
                 const int up = min(u + m, T - 1), um = max(u - m, 0);
                 acc += (float)m * (dlt[(size_t)(up - da) * nc + q] - dlt[(size_t)(um - da) * nc + q]);
@@ -508,17 +508,27 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
 
     if (a.cmvn) {  // per-utterance, per-dimension (x - mean) / std, ddof = 0, std < 10 eps -> 1 (sklearn scale)
         for (int d = wave; d < D; d += nw) {
-            float s = 0.f;
-            for (int r = lane; r < n; r += 64) s += value(r, d);
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            const float mean = s / (float)n;
+            // (statistics over the entries that are not NaN, which stay NaN: sklearn's nanmean / nanstd — see cmvn_kernel)
+            float s = 0.f, cn = 0.f;
+            for (int r = lane; r < n; r += 64) {
+                const float x = value(r, d);
+                const bool ok = x == x;
+                s += ok ? x : 0.f;
+                cn += ok ? 1.f : 0.f;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                s += __shfl_xor(s, o);
+                cn += __shfl_xor(cn, o);
+            }
+            const float mean = s / cn;
             float v = 0.f;
             for (int r = lane; r < n; r += 64) {
-                const float e = value(r, d) - mean;
+                const float x = value(r, d);
+                const float e = x == x ? x - mean : 0.f;
                 v = fmaf(e, e, v);
             }
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            float sd = sqrtf(v / (float)n);
+            float sd = sqrtf(v / cn);
             if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;
             if (lane == 0) {
                 stats[d] = mean;

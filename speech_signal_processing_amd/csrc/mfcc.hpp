@@ -107,6 +107,7 @@ struct ssp_mfcc_plan {
     ssp_ctx* ctx = nullptr;
     ssp_mfcc_cfg cfg{};
     int32_t d_out = 0;
+    bool reproducible = false;  // SSP_MFCC_REPRODUCIBLE: chunking / scaling choices that depend on the batch or the machine are pinned
     ssp::DevBuf window, twiddle, filt_lo4, filt_grp, filt_wT, dct, dctT, fbank_dense;
     int32_t max_filt_len = 0;
     // cached work table for the last (sample_seg, frame_seg, variant) seen

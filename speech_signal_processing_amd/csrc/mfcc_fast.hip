@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                 for (int k = 0; k < 12; ++k) v[k] = (dd2 || (k >= 2 && k < 10)) ? cp[(k - 4) * 13] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float c1 = ((v[5 + i] - v[3 + i]) + 2.f * (v[6 + i] - v[2 + i])) * invd;
+                    const float c1 = __builtin_fmaf(0.f, v[4 + i], ((v[5 + i] - v[3 + i]) + 2.f * (v[6 + i] - v[2 + i])) * invd);
                     const float c2 = f.ddw[0] * (v[i] + v[8 + i]) + f.ddw[1] * (v[1 + i] + v[7 + i]) + f.ddw[2] * (v[2 + i] + v[6 + i]) +
                                      f.ddw[3] * (v[3 + i] + v[5 + i]) + f.ddw[4] * v[4 + i];
                     const int oi = (u0 + i) * Dd + qq;
@@ -512,12 +512,12 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
     const int D = a.d_out;
     auto cep = [&](int u, int qq) -> float { return s_ceps[(size_t)(u - ta) * nc + qq]; };
     auto dl = [&](int u, int qq) -> float {
-        float acc = 0.f;
+        float acc = 0.f * cep(u, qq);  // (the n = 0 term of numpy.dot, GMM_UBM.py:68: 0 . NaN = NaN)
         for (int m = 1; m <= Nd; ++m) acc += (float)m * (cep(min(u + m, T - 1), qq) - cep(max(u - m, 0), qq));
         return acc * inv;
     };
     auto ddl = [&](int u, int qq) -> float {
-        float acc = 0.f;
+        float acc = 0.f * dl(u, qq);
         for (int m = 1; m <= Nd; ++m) acc += (float)m * (dl(min(u + m, T - 1), qq) - dl(max(u - m, 0), qq));
         return acc * inv;
     };
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
             const float* cp = s_ceps + (size_t)(u - ta) * nc + qq;
             const float m4 = cp[-4 * nc], m3 = cp[-3 * nc], m2 = cp[-2 * nc], m1 = cp[-nc], p1 = cp[nc], p2 = cp[2 * nc],
                         p3 = cp[3 * nc], p4 = cp[4 * nc];
-            c1 = ((p1 - m1) + 2.f * (p2 - m2)) * inv;
+            c1 = __builtin_fmaf(0.f, c0, ((p1 - m1) + 2.f * (p2 - m2)) * inv);  // (+ the n = 0 term: 0 . NaN = NaN)
             c2 = f.ddw[0] * (m4 + p4) + f.ddw[1] * (m3 + p3) + f.ddw[2] * (m2 + p2) + f.ddw[3] * (m1 + p1) + f.ddw[4] * c0;
         } else if (u - 2 * Nd >= 0 && u + 2 * Nd <= T - 1) {
             // all 4N+1 neighbours are fetched first (one LDS round trip), then reduced from registers (delta_N <= 4)
@@ -566,17 +566,27 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
             return blk == 0 ? c0 : (blk == 1 ? c1 : c2);
         };
         for (int d = wave; d < D; d += FAST_WAVES) {
-            float s = 0.f;
-            for (int r = lane; r < n; r += 64) s += value(r, d);
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            const float mean = s / (float)n;
+            // (statistics over the entries that are not NaN, which stay NaN: sklearn's nanmean / nanstd — see cmvn_kernel)
+            float s = 0.f, cn = 0.f;
+            for (int r = lane; r < n; r += 64) {
+                const float x = value(r, d);
+                const bool ok = x == x;
+                s += ok ? x : 0.f;
+                cn += ok ? 1.f : 0.f;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                s += __shfl_xor(s, o);
+                cn += __shfl_xor(cn, o);
+            }
+            const float mean = s / cn;
             float v = 0.f;
             for (int r = lane; r < n; r += 64) {
-                const float e = value(r, d) - mean;
+                const float x = value(r, d);
+                const float e = x == x ? x - mean : 0.f;
                 v = fmaf(e, e, v);
             }
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            float sd = sqrtf(v / (float)n);
+            float sd = sqrtf(v / cn);
             if (sd < 10.0f * 1.1920929e-07f) sd = 1.0f;
             if (lane == 0) {
                 s_stats[d] = mean;
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                     for (int k = 0; k < 12; ++k) v[k] = (dd2 || (k >= 2 && k < 10)) ? cp[(k - 4) * 13] : 0.f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float c1 = ((v[5 + i] - v[3 + i]) + 2.f * (v[6 + i] - v[2 + i])) * inv;
+                        const float c1 = __builtin_fmaf(0.f, v[4 + i], ((v[5 + i] - v[3 + i]) + 2.f * (v[6 + i] - v[2 + i])) * inv);
                         const float c2 = f.ddw[0] * (v[i] + v[8 + i]) + f.ddw[1] * (v[1 + i] + v[7 + i]) + f.ddw[2] * (v[2 + i] + v[6 + i]) +
                                          f.ddw[3] * (v[3 + i] + v[5 + i]) + f.ddw[4] * v[4 + i];
                         put(4 * rg + i, qq, v[4 + i], c1, c2);

@@ -87,6 +87,8 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
     const size_t lds_cap = 160 * 1024;
     int ch, nw = 4;
     size_t lds = 0;
+    bool small_batch = false;
+    const bool repro = p->reproducible;  // ssp_mfcc_plan_set_flags(SSP_MFCC_REPRODUCIBLE): an utterance's bits must not depend on the batch
     // a failed build must not leave a half-written layout behind a valid cache key (the next run of the cached segment pair would launch
     // with it): the key is dropped first and only restored at the end
     p->cache_sseg = p->cache_fseg = 0;
@@ -95,6 +97,8 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         // 2048-point wave-stream kernel: first pass only (log filterbank rows + utterance maxima); chunks of 64 frames, one wave each
         // (small batches: shorter chunks, so that a single utterance is spread over many waves instead of walked by one; they always
         //  take the second-pass kernel for the clamp + DCT: the same bits for an utterance alone and in any small batch)
+        // (the kernel forms 32-bit byte offsets from sample indices: longer utterances stay with the generic kernel)
+        if (sseg->max_len() * 4 > (int64_t)INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream2048): utterance too long for 32-bit offsets");
         ch = 128;
         bool s2k_small = false;
         {
@@ -106,14 +110,13 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         }
         split_topdb = true;  // (the rows always go through the global scratch; whether a second pass follows: cache_s2k_fused)
         whole = false;
-        p->cache_s2k_fused = !s2k_small && mfcc_s2k_fuses(p, max_T, ch);
+        p->cache_s2k_fused = !s2k_small && !repro && mfcc_s2k_fuses(p, max_T, ch);
     } else if (variant == 3) {
         // wave-stream kernel: a chunk is a run of frames one WAVE walks alone (no LDS bound); whole utterances up to 512 frames, longer ones
         // in 512-frame chunks with a recomputed 4-frame halo.  CMVN needs the whole utterance: inside the kernel when every utterance is a
         // single chunk (and the dialect has a scaling instance), the stand-alone kernel afterwards otherwise.
         // (utterances may start at any sample: the 16-byte LDS-DMA loads of the sample stage only need dword-aligned addresses)
         ch = (int)std::min<int64_t>(std::max<int64_t>(max_T, 1), 512);
-        bool small_batch = false;
         {
             // small batches (the reference calls these functions one utterance at a time): a chunk per wave would leave most of the
             // machine idle, so utterances are cut into shorter chunks (multiples of 16 frames, >= 32; each recomputes a 4-frame halo)
@@ -125,8 +128,9 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
                 small_batch = true;
             }
         }
-        // (small batches always scale with the stand-alone kernel: an utterance then gets the same bits alone and in any small batch)
-        split_cmvn = c.cmvn != 0 && !(!small_batch && max_T <= ch && mfcc_stream_fuses_cmvn(p));
+        // (small batches always scale with the stand-alone kernel: an utterance then gets the same bits alone and in any small batch;
+        //  reproducible plans in every batch)
+        split_cmvn = c.cmvn != 0 && !(!small_batch && !repro && max_T <= ch && mfcc_stream_fuses_cmvn(p));
         whole = false;
         {
             // mfcc_stream_supported() is wider than the set of compiled instances (e.g. win <= 416 with hop > 160 needs the two-per-CU
@@ -215,8 +219,13 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         if (T > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: utterance %lld has too many frames", (long long)u);
         int64_t chu = ch;
         if (u >= tail_from && T >= 64) chu = std::min<int64_t>(ch, ((T + 1) / 2 + 15) / 16 * 16);
+        // wave-stream kernel: a cut chunk starts 16 frames early (pad = 12 on top of the 4-frame halo) and then reproduces the uncut
+        // utterance's bits — every cut of a machine-filling batch (the 512-frame cuts of long utterances and the tail split: an utterance's
+        // bits do not depend on its place in the batch), and the short latency cuts of small batches as well when the plan is reproducible
+        // (they are multiples of 16 frames; 12 more frames per 32-frame chunk is why that is not the default)
+        const int pad = (variant == 3 && (!small_batch || repro)) ? 12 : 0;
         for (int64_t t0 = 0; t0 < T; t0 += chu)
-            chunks.push_back(MfccChunk{(int32_t)u, (int32_t)t0, (int32_t)std::min<int64_t>(chu, T - t0), (chu != ch && t0 > 0) ? 12 : 0});
+            chunks.push_back(MfccChunk{(int32_t)u, (int32_t)t0, (int32_t)std::min<int64_t>(chu, T - t0), t0 > 0 ? pad : 0});
     }
     if (chunks.size() > (size_t)INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: too many chunks");
     SSP_TRY(upload(p->chunks, chunks, p->ctx->stream));
@@ -413,6 +422,18 @@ int ssp_mfcc_plan_destroy(ssp_mfcc_plan* plan) {
     return SSP_OK;
 }
 
+int ssp_mfcc_plan_set_flags(ssp_mfcc_plan* plan, uint32_t flags) {
+    if (!plan) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_plan_set_flags: null");
+    if (flags & ~(uint32_t)SSP_MFCC_REPRODUCIBLE) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_plan_set_flags: unknown flag 0x%x", flags);
+    const bool r = (flags & SSP_MFCC_REPRODUCIBLE) != 0;
+    if (r != plan->reproducible) {
+        plan->reproducible = r;
+        plan->cache_sseg = plan->cache_fseg = 0;  // the cached work table was laid out under the other rule
+        plan->cache_variant = plan->cache_request = -1;
+    }
+    return SSP_OK;
+}
+
 int ssp_mfcc_frame_segments(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, ssp_segments** frame_seg_out) {
     if (!plan || !sample_seg || !frame_seg_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_frame_segments: null");
     std::vector<int64_t> fo((size_t)sample_seg->n + 1);
@@ -471,6 +492,10 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
         int brc = build_work(plan, sample_seg, frame_seg, v);
         if (brc == SSP_ERR_UNSUPPORTED && variant == 0 && v == 3) {  // auto: a batch the stream kernel cannot lay out goes to the workgroup kernel
             v = 2;
+            brc = build_work(plan, sample_seg, frame_seg, v);
+        }
+        if (brc == SSP_ERR_UNSUPPORTED && variant == 0 && v == 4) {  // auto: ... the 2048-point stream kernel cannot lay out goes to the generic one
+            v = 1;
             brc = build_work(plan, sample_seg, frame_seg, v);
         }
         if (brc == SSP_ERR_UNSUPPORTED && variant == 0 && v == 2) {  // auto: a batch the fused kernel cannot lay out goes to the generic one

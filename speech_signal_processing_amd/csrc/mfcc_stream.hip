@@ -201,6 +201,10 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         }
         prefetch(0);
         int stores_pending = 0;  // buffer stores issued behind the DMA that is waited for at the top of the next iteration
+        // non-finite cepstra (a digitally silent frame: ln 0 = -inf in the dialects without a floor, GMM_UBM.py:89 / d_vector.py:96-98): the
+        // time products would spread one over the whole 16-row step (0 . inf = NaN); emit_step looks at the step's ring window and sends
+        // such a step to time_step_nf, which forms the reference's sums term by term
+        int cm_nf = 0;  // CM: a step of this utterance took that path (its column sums are incomplete: the scaling pass recounts)
         // CM: sums of this lane's stored values per block (column = lane & 15), fp32: a lane adds ~T / 4 terms, and the cepstra are
         // summed relative to a pivot — the utterance's first frame — so that var = E[(x - p)^2] - E[x - p]^2 does not cancel when a
         // column's mean is large against its spread (delta / delta-delta columns have no mean to speak of: pivot 0).  The four lane
@@ -365,8 +369,11 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         //      (see mfcc_fast.hip step 7); the log-mel rows go behind the P rows
         auto mel = [&]() {
 #ifndef SSP_S_NOMEL
-            float* lm = reinterpret_cast<float*>(zbuf + g * ZFRAME + LM_OFF - 64 * g);
-            if (j < f.lm_pad) lm[a.n_filt + j] = 0.f;
+            if (j < f.lm_pad) {  // (the address from an opaque copy of the lane id: hoisted out of the loop it costs the register that spills)
+                int ol = lane;
+                asm volatile("" : "+v"(ol));
+                reinterpret_cast<float*>(zbuf + (ol >> 4) * (ZFRAME - 64) + LM_OFF)[a.n_filt + (ol & 15)] = 0.f;
+            }
             float sfr[4];
 #pragma unroll
             for (int fr = 0; fr < 4; ++fr) {
@@ -437,18 +444,24 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             }
         };
         // ================= time step b: rows [16 b - 4, 16 b + 12) of (c, delta, delta-delta) leave =================
-        auto time_step = [&](int b) {
+        typedef float cbarr_t[6];
+        // B operands of a step: cepstra of ring frames rb - 8 + 4 s + g, column j (lane (g, j)), s = 0..5
+        auto ring_window = [&](int b, cbarr_t& cb) {
             const int rb = 16 * b;
             int ol = lane;
             asm volatile("" : "+v"(ol));
             const int g = ol >> 4, j = ol & 15;
-            // B operands: cepstra of ring frames rb - 8 + 4 s + g, column j (lane (g, j)), s = 0..5
-            float cb[6];
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
                 const int m = (rb + 16 + 4 * s) % RING_FRAMES;  // (rb - 8 + 4 s) mod 24, a multiple of 4
                 cb[s] = *reinterpret_cast<const float*>(ring + (m + g) * RING_ROW + j * 4);
             }
+        };
+        auto time_step = [&](int b, const cbarr_t& cb) {
+            const int rb = 16 * b;
+            int ol = lane;
+            asm volatile("" : "+v"(ol));
+            const int g = ol >> 4, j = ol & 15;
             const float tg = (float)(ta + rb);  // utterance frame index of relative frame rb
             // A operands = regression weights of frame (tg + tpr) in delta[tg + tr].  Steps whose 24-frame window lies strictly
             // inside the utterance (all but the first and the last one or two) take them from the lane-constant distance
@@ -539,17 +552,11 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         // The accumulator of one product is no longer the operand of the next (frames sit on lanes now), so delta-delta is ONE product
         // with the auto-convolved weights (reach +-4, N = 2: (-10, -4, 1, 4, 4) / denom^2 at |d| = 0..4 = -10 + |d| (37 - d^2) / 6) —
         // for interior frames the same numbers as delta(delta(c)) up to the rounding of the intermediate delta.
-        auto time_step_T = [&](int b) {
+        auto time_step_T = [&](int b, const cbarr_t& cb) {
             const int rb = 16 * b;
             int ol = lane;
             asm volatile("" : "+v"(ol));
             const int g = ol >> 4, j = ol & 15;
-            float cb[6];
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const int m = (rb + 16 + 4 * s) % RING_FRAMES;  // (rb - 8 + 4 s) mod 24, a multiple of 4
-                cb[s] = *reinterpret_cast<const float*>(ring + (m + g) * RING_ROW + j * 4);
-            }
             const float inv = 2.f * half_inv;
             const float ef = (float)(g - 4 - j);  // input frame (rb - 8 + 4 s + g) minus output frame (rb - 4 + j) = ef + 4 s
             const int F = ta + rb - 4 + j;       // this lane's output frame
@@ -589,18 +596,80 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             }
             stores_pending = 2 * (1 + dord);
         };
+        // ================= the same step when its 24-frame window holds a non-finite cepstrum (rare, wave-uniform) =================
+        // GMM_UBM.py:53-69 term by term: delta[t] = sum_n n c[clamp(t + n)] / denom including the n = 0 term (0 . inf = NaN, as numpy.dot
+        // has it), delta-delta = delta(delta(c)) with the clamp at both levels: exactly the frames within +-2 / +-4 of a non-finite
+        // cepstrum come out non-finite, every other one from finite terms only.  Lane layout and stores of the transposed form.
+        auto time_step_nf = [&](int b) {
+            const int rb = 16 * b;
+            int ol = lane;
+            asm volatile("" : "+v"(ol));
+            const int g = ol >> 4, j = ol & 15;
+            const float inv = 2.f * half_inv;
+            const int F = ta + rb - 4 + j;       // this lane's output frame; it holds cepstra 4 g .. 4 g + 3
+            const bool emit = F >= t0 && F < t0 + n;
+            const int row16 = (emit && g < 3) ? (F * Dd + 4 * g) * 4 : 0x7ffffff0;
+            const int row4 = (emit && g == 3) ? (F * Dd + 12) * 4 : 0x7ffffff0;
+            auto store = [&](v4f v, int blk) {
+                typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), ro, row16 + blk * (nc * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.x), ro, row4 + blk * (nc * 4), 0, 0);
+            };
+            // cepstra of utterance frame clamp(t): every frame an emitted row needs is in the ring (relative frames rb - 8 .. rb + 15)
+            auto cread = [&](int t) -> v4f {
+                t = min(max(t, 0), T - 1);
+                const unsigned slot = (unsigned)(t - ta + 2 * RING_FRAMES) % (unsigned)RING_FRAMES;
+                return *reinterpret_cast<const v4f*>(ring + slot * RING_ROW + g * 16);
+            };
+            auto dl = [&](int u) -> v4f {
+                u = min(max(u, 0), T - 1);
+                v4f s = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int m = -2; m <= 2; ++m) {
+                    const float fm = (float)m;
+                    s = __builtin_elementwise_fma(v4f{fm, fm, fm, fm}, cread(u + m), s);
+                }
+                return s * inv;
+            };
+            store(cread(F), 0);
+            if (dord >= 1) store(dl(F), 1);
+            if (dord >= 2) {
+                v4f q = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int k = -2; k <= 2; ++k) {
+                    const float fk = (float)k;
+                    q = __builtin_elementwise_fma(v4f{fk, fk, fk, fk}, dl(F + k), q);
+                }
+                store(q * inv, 2);
+            }
+            stores_pending = 2 * (1 + dord);
+            cm_nf = 1;
+        };
         // a step whose window (frames rb - 8 .. rb + 15) lies strictly inside the utterance takes the transposed form; utterance ends
         // (edge-replicated weights) and the scaling instances (their column sums live in the row-major layout) the chained one
         auto emit_step = [&](int b) {
+            cbarr_t cb;
+            ring_window(b, cb);
 #ifdef SSP_S_NOTSTEP
-            time_step(b);
+            time_step(b, cb);
 #else
+#ifndef SSP_S_NONF
+            {
+                // the window's 24 frames x 16 columns sit one value per lane and k-step: any non-finite term makes the sum non-finite
+                // (cepstra are O(10): finite terms do not overflow); one compare per step, wave-uniform branch
+                const float t = ((cb[0] + cb[1]) + (cb[2] + cb[3])) + (cb[4] + cb[5]);
+                if (__builtin_amdgcn_ballot_w64(__builtin_amdgcn_classf(t, 0x207 /* NaN, +-inf */)) != 0) {
+                    time_step_nf(b);
+                    return;
+                }
+            }
+#endif
             const bool interior = ta + 16 * b - 8 >= 1 && ta + 16 * b + 16 <= T - 2;  // wave-uniform
             // (not the scaling instances — their column sums live in the row-major layout — nor the widest filterbank instance, which has no
             //  register left for the second form)
             constexpr bool TSTEP = !CM && !(MELV >= 4 && NS >= 4);
-            if (TSTEP && interior) time_step_T(b);
-            else time_step(b);
+            if (TSTEP && interior) time_step_T(b, cb);
+            else time_step(b, cb);
 #endif
         };
 
@@ -692,7 +761,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                     ring_put(q, v4f{0.f, 0.f, 0.f, 0.f}, false);
                 }
 #ifndef SSP_S_NOSTEP
-                if ((q & 3) == 3) time_step(q >> 2);
+                if ((q & 3) == 3) emit_step(q >> 2);
 #endif
             }
 #else
@@ -741,6 +810,35 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             asm volatile("" : "+v"(ol));
             const int g = ol >> 4, j = ol & 15;
             float* ct = reinterpret_cast<float*>(ring);  // [0, 48): means, [48, 96): 1 / std  (the ring is idle until the next chunk zeroes it)
+            if (cm_nf) {
+                // the utterance holds non-finite cepstra (rare): sklearn.preprocessing.scale takes the statistics over the entries that
+                // are not NaN (nanmean / nanstd, sk:preprocessing/_data.py scale) and leaves the NaN entries as they are.  Lane = column;
+                // the rows come back through L2 (this wave wrote them; its stores have completed)
+                double n1 = 0.0, a1 = 0.0, a2 = 0.0;
+                const int col = ol < Dd ? ol : 0;
+                for (int F0 = 0; F0 < T; F0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, F0 + k < T ? ((F0 + k) * Dd + col) * 4 : 0x7ffffff0, 0, 1));
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool ok = F0 + k < T && v[k] == v[k];
+                        const double d = ok ? (double)v[k] : 0.0;
+                        n1 += ok ? 1.0 : 0.0;
+                        a1 += d;
+                        a2 += d * d;
+                    }
+                }
+                const double mean = a1 / n1;  // (no entry at all: NaN, as nanmean has it)
+                const double var = a2 / n1 - mean * mean;
+                double sd = __builtin_sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
+                if (sd < 10.0 * 1.1920929e-07) sd = 1.0;
+                if (ol < Dd) {
+                    ct[ol] = (float)mean;
+                    ct[48 + ol] = (float)(1.0 / sd);
+                }
+            } else
 #pragma unroll
             for (int blk = 0; blk < 3; ++blk) {
                 if (blk > dord) break;

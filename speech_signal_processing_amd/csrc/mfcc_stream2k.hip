@@ -466,7 +466,7 @@ int build_s2k_tables(ssp_mfcc_plan* p) {
             if (start < 0 || start + 4 * gsteps[g] < lo[j] + len[j]) return SSP_OK;  // (a filter wider than the sweep: the generic kernel keeps the plan)
             int n_opt = 1;  // starts start, start - 4, ... that still cover the filter
             while (start - 4 * n_opt >= 0 && start - 4 * n_opt + 4 * gsteps[g] >= lo[j] + len[j] && n_opt < 16) ++n_opt;
-            cand.push_back({j, start, len[j] == 0 ? 16 : n_opt});
+            cand.push_back({j, start, len[j] == 0 ? std::min(16, start / 4 + 1) : n_opt});  // (a filter with no tap may sit anywhere at or below its start — not in front of the P row)
         }
         std::stable_sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) { return x.n_opt < y.n_opt; });
         bool used[4][16] = {}, lane_taken[64] = {};

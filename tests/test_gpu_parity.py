@@ -373,26 +373,80 @@ def test_auto_mode_falls_back_where_the_stream_kernel_has_no_instance(ssp, shift
             assert_feat_close(got[u], O.mfcc_pipeline(s, cfg, w, fb, dct), what=f"auto {shift} cmvn {cmvn} utt {u}")
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_partially_silent_utterance_nonfinite_pattern(ssp, variant):
-    """Digital silence inside an utterance: ln 0 = -inf in the silent frames (sidekit has no floor).  The reference's delta touches
-    frames within +-2 (delta) / +-4 (delta-delta) of a non-finite cepstrum; every frame outside that reach must stay finite and
-    equal to the oracle, and every frame the oracle marks non-finite must be non-finite here."""
+def _silent_cases():
+    """utterances with digitally silent stretches: ln 0 = -inf in the silent frames (sidekit has no floor).  A frame t is silent when
+    all of samples [160 t, 160 t + 400) are zero."""
+    def zero_frames(x, t_first, t_last):
+        x = x.copy()
+        x[160 * t_first:160 * t_last + 400] = 0.0
+        return x
+    a = synth_audio(9, 16000, 16000)    # 98 frames
+    b = synth_audio(11, 48000, 16000)   # 298 frames
+    return [zero_frames(a, 37, 46),                                   # ten frames mid-utterance
+            zero_frames(a, 0, 2),                                     # the utterance's first frames (edge-replicated deltas)
+            zero_frames(a, 95, 97),                                   # ... its last ones
+            zero_frames(b, 100, 100),                                 # a single frame
+            zero_frames(zero_frames(b, 10, 12), 15, 15),              # two stretches three frames apart (their reaches overlap)
+            zero_frames(zero_frames(b, 60, 61), 200, 230),            # stretches in different 16-row steps, one longer than a step window
+            zero_frames(b, 293, 297),                                 # the last frames of a long utterance
+            synth_audio(10, 8000, 16000), b]                          # untouched neighbours
+
+
+def _assert_nonfinite_pattern(got, ref, what):
+    bad_ref, bad_got = ~np.isfinite(ref), ~np.isfinite(got)
+    assert (bad_got | ~bad_ref).all(), what + ": a frame the reference makes non-finite came out finite"
+    assert (bad_got == bad_ref).all(), "%s: non-finite pattern differs from the reference: %d vs %d entries" % (what, bad_got.sum(), bad_ref.sum())
+    assert (np.isnan(got) == np.isnan(ref)).all(), what + ": NaN / inf classes differ"
+    ok = ~bad_ref
+    if ok.any():
+        assert np.abs(got[ok] - ref[ok]).max() <= 1e-4 * max(1.0, np.abs(ref[ok]).max()), what
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("order,cmvn", [(0, 0), (1, 0), (2, 0), (1, 1), (2, 1)])
+def test_partially_silent_utterance_nonfinite_pattern(ssp, variant, order, cmvn):
+    """Digital silence inside an utterance.  The reference's delta (GMM_UBM.py:53-69) touches frames within +-2 (delta) / +-4
+    (delta-delta) of a non-finite cepstrum; every frame outside that reach must stay finite and equal to the oracle, and every frame
+    the oracle marks non-finite must be non-finite here — on EVERY kernel, the default one included (variants 0 / 3: the matrix-core
+    time products would spread 0 * NaN over a whole 16-row step; such steps take a term-by-term path).  With scaling
+    (preprocessing.scale, GMM_UBM.py:93) the statistics run over the entries that are not NaN, as the library's do."""
     pkg, api = ssp
     from oracle import ref_cpu as O
-    x = synth_audio(9, 16000, 16000).copy()
-    x[6000:6000 + 160 * 10 + 400] = 0.0  # >= 10 wholly silent frames
-    tables = pkg.preset_sidekit(delta_order=2)
-    got, _ = _run_plan(api, tables, [x, synth_audio(10, 8000, 16000)], variant=variant)
-    cfg, w, fb, dct = O.sidekit_tables(delta_order=2)
-    with np.errstate(all="ignore"):
-        ref = O.mfcc_pipeline(x, cfg, w, fb, dct)
-    bad_ref = ~np.isfinite(ref)
-    bad_got = ~np.isfinite(got[0])
-    assert bad_ref.any() and (bad_got | ~bad_ref).all(), "a frame the reference makes non-finite came out finite"
-    assert (bad_got == bad_ref).all(), "non-finite pattern differs from the reference: %d vs %d entries" % (bad_got.sum(), bad_ref.sum())
-    ok = ~bad_ref
-    assert np.abs(got[0][ok] - ref[ok]).max() <= 1e-4 * max(1.0, np.abs(ref[ok]).max())
+    sigs = _silent_cases()
+    tables = pkg.preset_sidekit(delta_order=order, cmvn=cmvn)
+    got, _ = _run_plan(api, tables, sigs, variant=variant)
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=order, cmvn=cmvn)
+    n_bad = 0
+    for u, x in enumerate(sigs):
+        with np.errstate(all="ignore"):
+            ref = O.mfcc_pipeline(x, cfg, w, fb, dct)
+        n_bad += int((~np.isfinite(ref)).any())
+        _assert_nonfinite_pattern(got[u], ref, "variant %d order %d cmvn %d utt %d" % (variant, order, cmvn, u))
+    assert n_bad == len(sigs) - 2
+
+
+@pytest.mark.parametrize("order,cmvn", [(2, 0), (1, 1)])
+def test_partially_silent_utterances_in_a_machine_filling_batch(ssp, order, cmvn):
+    """the same in a batch large enough for whole-utterance chunks, the tail split and (cmvn) the in-kernel scaling of the wave-stream
+    kernel: the silent utterances are spread through the batch, the last-claimed ones included"""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    cases = [c for c in _silent_cases() if len(c) == 16000]
+    n = 3400
+    sigs = [synth_audio(100 + (u % 7), 16000, 16000) for u in range(n)]
+    where = {5: 0, 1700: 1, n - 3: 2, n - 1: 0, 2000: 2}
+    for u, k in where.items():
+        sigs[u] = cases[k]
+    tables = pkg.preset_sidekit(delta_order=order, cmvn=cmvn)
+    got, _ = _run_plan(api, tables, sigs, variant=0)
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=order, cmvn=cmvn)
+    for u in sorted(set(where) | {0, 4, 6, 1699, 1701, n - 2}):
+        with np.errstate(all="ignore"):
+            ref = O.mfcc_pipeline(sigs[u], cfg, w, fb, dct)
+        assert (~np.isfinite(ref)).any() == (u in where)
+        _assert_nonfinite_pattern(got[u], ref, "batch order %d cmvn %d utt %d" % (order, cmvn, u))
+    for u in range(7, n, 7 * 41):  # copies of one utterance agree to rounding wherever they sit
+        np.testing.assert_allclose(got[u], got[u % 7 + 7], rtol=0, atol=2e-4 * max(1.0, float(np.abs(got[u % 7 + 7]).max())))
 
 
 def test_sidekit_shape_fact(ssp):
@@ -1664,6 +1718,51 @@ def test_bit_reproducible_runs(ssp):
     w = rng.dirichlet(5 * np.ones(64)); mu = rng.standard_normal((64, 39)); cov = rng.uniform(0.5, 2.0, (64, 39))
     s1, s2 = api.gmm_em_stats(ctx, w, mu, cov, X), api.gmm_em_stats(ctx, w, mu, cov, X)
     assert s1["loglik_sum"] == s2["loglik_sum"] and np.array_equal(s1["sx"], s2["sx"]) and np.array_equal(s1["nk"], s2["nk"])
+
+
+@pytest.mark.parametrize("dialect", ["sidekit39", "sidekit26_scaled", "inrepo", "librosa"])
+def test_reproducible_plan_pins_the_bits(ssp, dialect):
+    """SSP_MFCC_REPRODUCIBLE (include/ssp.h): an utterance gets the same float32 bits alone (cut into short latency chunks), in a small
+    batch and in a machine-filling batch (whole-utterance chunks, 512-frame cuts, the tail split; by default the in-kernel scaling /
+    the fused clamp + DCT) — array_equal, not allclose."""
+    pkg, api = ssp
+    tables = {"sidekit39": lambda: pkg.preset_sidekit(delta_order=2), "sidekit26_scaled": lambda: pkg.preset_sidekit(delta_order=1, cmvn=1),
+              "inrepo": lambda: pkg.preset_inrepo(16000, 512, 256, delta_order=2), "librosa": lambda: pkg.preset_librosa(16000, 13)}[dialect]()
+    probes = [synth_audio(31, 48000, 16000), synth_audio(32, 16000 * 7 + 123, 16000), synth_audio(33, 20011, 16000)]  # 3 s, 7 s (cut at 512 frames), ragged
+    ctx = api.default_context()
+    plan = api.MfccPlan(ctx, tables).set_reproducible(True)
+
+    def run(sigs):
+        seg = api.Segments.from_lengths(ctx, [len(x) for x in sigs])
+        fseg = plan.frame_segments(seg)
+        flat = np.empty(sum(len(x) for x in sigs), np.float32)
+        o = 0
+        for x in sigs:
+            flat[o:o + len(x)] = x
+            o += len(x)
+        out = np.asarray(plan.run(flat, seg, fseg, variant=0))
+        return [out[fseg.offsets[i]:fseg.offsets[i + 1]] for i in range(len(sigs))]
+
+    alone = [run([x])[0] for x in probes]
+    small = run(probes)
+    # machine-filling: at least 12 chunks per CU (chunks: whole utterances up to 512 frames, 128 for the 2048-point kernel)
+    base = [synth_audio(40 + k, 48000, 16000) for k in range(5)]
+    ch = 128 if dialect == "librosa" else 512
+    n = int(1.04 * 12 * 256 * ch / plan.num_frames(48000)) + 8
+    filler = [base[u % 5] for u in range(n)]
+    where = [3, n // 2, n - 2]                   # the last ones are claimed in the tail
+    for u, x in zip(where, probes):
+        filler[u] = x
+    big = run(filler)
+    for k, u in enumerate(where):
+        assert np.isfinite(alone[k]).all()
+        assert np.array_equal(alone[k], small[k]), (dialect, k, "alone vs small batch")
+        assert np.array_equal(alone[k], big[u]), (dialect, k, "alone vs machine-filling batch", float(np.abs(alone[k] - big[u]).max()))
+    assert np.array_equal(big[0], big[5])        # copies of one utterance inside the batch
+    plan.set_reproducible(False)                 # (the default layout is within rounding of it)
+    dflt = run(probes)
+    for k in range(3):
+        np.testing.assert_allclose(dflt[k], alone[k], rtol=0, atol=2e-4 * max(1.0, float(np.abs(alone[k]).max())))
 
 
 def test_baseline_configs0_plumbing_case(ssp):

@@ -74,6 +74,21 @@ def test_scale_matches_sklearn(golden):
     np.testing.assert_allclose(O.scale(g["scale_one_in"]), g["scale_one_out"], rtol=0, atol=1e-12)
 
 
+def test_scale_nan_rows_match_sklearn(golden):
+    """NaN rows (digital silence through a dialect without a log floor, GMM_UBM.py:89-93): statistics over the other entries, NaN kept;
+    +-inf raises like the library (tests/golden/make_golden_nan.py)."""
+    g = golden("scale_nan")
+    for k in ("nanrows", "nancols"):
+        got, ref = O.scale(g[k + "_in"]), g[k + "_out"]
+        assert (np.isnan(got) == np.isnan(ref)).all()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12, equal_nan=True)
+    assert int(g["inf_raises"]) == 1
+    bad = g["nanrows_in"].copy()
+    bad[3, 2] = -np.inf
+    with pytest.raises(ValueError):
+        O.scale(bad)
+
+
 @pytest.mark.parametrize("K,D", [(1, 13), (16, 26), (64, 39), (5, 7), (40, 39)])
 def test_gmm_score_samples_matches_sklearn(golden, K, D):
     g = golden("gmm")

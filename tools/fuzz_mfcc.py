@@ -52,6 +52,14 @@ for case in range(n_cases):
     if cmvn:
         lens = [max(l, 2000) for l in lens]   # a 1-frame utterance has std 0 in every column: covered by the unit tests
     sigs = [(0.3 * rng.standard_normal(l)).astype(np.float32) for l in lens]
+    # digitally silent stretches (sidekit has no log floor: ln 0 = -inf, NaN cepstra, the deltas spread them +-2 / +-4 frames; the
+    # scaling leaves them out of its statistics): every kernel must reproduce the oracle's non-finite pattern exactly
+    if dialect == "sidekit" and rng.random() < 0.5:
+        for x in sigs:
+            for _ in range(int(rng.integers(0, 3))):
+                if len(x) > 800:
+                    a0 = int(rng.integers(0, len(x) - 400))
+                    x[a0:a0 + int(rng.integers(400, 4000))] = 0.0
     if '-v' in sys.argv:
         print(case, dialect, order, cmvn, lens, flush=True)
     plan = api.MfccPlan(ctx, tables)
@@ -62,7 +70,8 @@ for case in range(n_cases):
     fast = np.asarray(plan.run(flat, seg, fseg, variant=2)) if has_fast else gen
     auto = np.asarray(plan.run(flat, seg, fseg, variant=0))
     for u, s in enumerate(sigs):
-        ref = O.mfcc_pipeline(s, cfg, w, fb, dct)
+        with np.errstate(all='ignore'):
+            ref = O.mfcc_pipeline(s, cfg, w, fb, dct)
         a, b, c = (v[fseg.offsets[u]:fseg.offsets[u + 1]] for v in (fast, gen, auto))
         assert a.shape == ref.shape, (case, u, a.shape, ref.shape)
         if ref.size == 0:
