@@ -6,11 +6,11 @@ rows = []
 r = d["roofline"]
 rows.append(("fused 39-d MFCC, 100k × 3 s utterances resident in HBM (configs[1]; wave-stream kernel, software-pipelined quad loop, DCT / Δ / ΔΔ on the matrix cores)",
              "%.3g frames/s (%.2f ms/pass)" % (d["value"], r["kernel_ms"]),
-             "%.2f of 8 TB/s HBM; HBM traffic %s × algorithmic (`profiles/mfcc_hbm_traffic.json`); VALU issue %s of every SIMD issuing every cycle at 2.4 GHz, %s at the %s GHz the pass holds on the 1400 W package cap (`profiles/mfcc_valu_lds_pmc.json`, `profiles/r03_clock_power.md`)" % (
+             "%.2f of 8 TB/s HBM; HBM traffic %s × algorithmic (`profiles/mfcc_hbm_traffic.json`); %s of the 157.3 TFLOP/s packed-FMA vector peak on %s counted flop per frame (`tools/flop_count.py`), %s of the add / multiply-mix-weighted peak; the pass holds 1.96 GHz on the 1400 W package cap (`profiles/r03_clock_power.md`)" % (
                  r["frac"], ("%.3f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])) if r.get("traffic") else "n/a",
-                 ("%.2f" % d["roofline_valu"]["frac"]) if d.get("roofline_valu") else "n/a",
-                 ("%.2f" % d["roofline_valu"]["frac_at_sustained_clock"]) if (d.get("roofline_valu") or {}).get("frac_at_sustained_clock") else "n/a",
-                 ("%.2f" % d["roofline_valu"]["sustained_clock_ghz"]) if (d.get("roofline_valu") or {}).get("sustained_clock_ghz") else "n/a")))
+                 ("%.2f" % d["roofline_flop"]["frac"]) if (d.get("roofline_flop") or {}).get("frac") else "n/a",
+                 (d.get("roofline_flop") or {}).get("flop_per_frame", "n/a"),
+                 ("%.2f" % d["roofline_flop"]["frac_mix_weighted"]) if (d.get("roofline_flop") or {}).get("frac_mix_weighted") else "n/a")))
 v = d["mfcc_ref26_cmvn"]
 rows.append(("the reference's `extract_feature` output: 13 cepstra + Δ, scaled per utterance (26-d), scaling inside the same kernel at three waves per SIMD",
              "%.3g frames/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of HBM" % v["roofline"]["frac"]))
