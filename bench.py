@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 VALU_FP32_PEAK_TF = 157.3     # packed fp32 FMA on the vector ALU: 256 CUs x 4 SIMDs x 16 lanes x 2 (packed) x 2 flop x 2.4 GHz (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
 MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md, Matrix cores)
 
 
@@ -648,6 +649,23 @@ def main():
                          "frac": flop / (c_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "cosine_reg_kernel<32, false> (d <= 256: embeddings register-resident, centroid tiles by LDS-DMA)",
                          "kernel_ms": c_ms, "algorithmic_flop_per_launch": flop},
         }
+        # split precision (ssp_cosine_identify2 precision = 1): bf16 x 3 MFMA sweep keeping the two best cosines + fp32 re-scoring of the
+        # rows inside the proven error band (device-side list, no host round trip); the fp32 path's arg-min on every row
+        am0 = rc["argmin"].clone()
+        r16 = api.cosine_identify(ctx, X, Cn, precision=1)
+        ms16 = []
+        for _ in range(c_steps):
+            r16 = api.cosine_identify(ctx, X, Cn, timing=True, precision=1)
+            ms16.append(r16["kernel_ms"])
+        c16 = float(np.mean(ms16))
+        result["cosine_bf16x3"] = {
+            "metric": "cosine pair-scores/s, split precision (bf16 x 3 MFMA + fp32 re-scoring of close calls), arg-min only", "value": N * S / (c16 * 1e-3),
+            "unit": "pair-scores/s", "dtype": "bf16x3 (fp32 accumulate)", "argmin_equals_fp32_path": bool((r16["argmin"] == am0).all().item()),
+            "rows_rescored_fp32": int(r16["rescored"]), "speedup_vs_fp32": c_ms / c16,
+            "roofline": {"bound": "mfma", "achieved": flop / (c16 * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flop / (c16 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, "frac_executed": 3.0 * flop / (c16 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+                         "traffic": None, "kernel": "cosine_bf16x3_kernel<16> + cosine_reg_kernel<32> on the listed rows", "kernel_ms": c16,
+                         "algorithmic_flop_per_launch": flop, "executed_flop_per_launch": 3.0 * flop}}
 
     # ------------------------------------------------------------------ widened stages; reported, not part of `value`
     if "em" in stages:

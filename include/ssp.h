@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SSP_ABI_VERSION 2 /* 2: ssp_comm_* / ssp_allgather / ssp_allreduce_sum; ssp_gmm_score precision = 1 re-scores close calls in fp32 (host sync) */
+#define SSP_ABI_VERSION 3 /* 3: ssp_cosine_identify2 (precision), ssp_mfcc_plan_set_flags; 2: ssp_comm_* / ssp_allgather / ssp_allreduce_sum; ssp_gmm_score precision = 1 re-scores close calls in fp32 (host sync) */
 
 typedef enum {
     SSP_OK = 0,
@@ -261,6 +261,16 @@ int ssp_centroids(ssp_ctx* ctx, const float* X, const int32_t* labels, int64_t N
 
 int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S,
                         float* dist_out, int32_t* argmin_out, float* min_out, int where, float* kernel_ms);
+/* the same with a choice of arithmetic.  precision 0: fp32-input MFMA (the parity path; ssp_cosine_identify).  precision 1: the sweep on
+ * bf16 MFMA with every operand split hi + lo (three products per k-step, fp32 accumulation) keeping each embedding's two largest
+ * cosines; rows whose two best are closer than twice a PROVEN bound on |cos(bf16x3) - cos(fp32 path)| for unit vectors
+ * (3.01 * 2^-18 + 4 d 2^-23: cosine.hip cos_band), and every row that meets a NaN or a zero norm, are scored again by the fp32 kernel from
+ * a device-side list (no host round trip in between).  argmin_out is therefore the fp32 path's on EVERY row; min_out is within the bound
+ * of it (exact on the re-scored rows).  Arg-min / minimum only: dist_out must be NULL; d <= 256. */
+int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,
+                         int32_t* argmin_out, float* min_out, int where, int precision, float* kernel_ms);
+/* diagnostics: rows the last precision = 1 call scored again in fp32 */
+int ssp_cosine_last_rescored(const ssp_ctx* ctx, int32_t* n_out);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("SSP_LIB_PATH") or os.path.join(HERE, "libsspgpu.so") 
 
 SSP_OK, SSP_ERR_INVALID, SSP_ERR_UNSUPPORTED, SSP_ERR_HIP, SSP_ERR_NOMEM, SSP_ERR_NODEVICE = 0, -1, -2, -3, -4, -5
 HOST, DEVICE = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
 
 
@@ -82,6 +82,8 @@ SIGNATURES = {
     "ssp_dtw_path": (C.c_int, [_P, _F32P, C.c_int64, _F32P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "ssp_centroids": (C.c_int, [_P, _F32P, _P, C.c_int64, C.c_int32, C.c_int32, _F32P, C.c_int, _MSP]),
     "ssp_cosine_identify": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, C.c_int32, _F32P, _P, _F32P, C.c_int, _MSP]),
+    "ssp_cosine_identify2": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, C.c_int32, _F32P, _P, _F32P, C.c_int, C.c_int, _MSP]),
+    "ssp_cosine_last_rescored": (C.c_int, [_P, C.POINTER(C.c_int32)]),
 }
 
 _lib = None

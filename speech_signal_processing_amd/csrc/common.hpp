@@ -119,6 +119,7 @@ struct ssp_ctx {
     void* comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     hipEvent_t order_ev[2] = {nullptr, nullptr};  // ssp_ctx_wait_stream / ssp_ctx_signal_stream
+    int32_t cos_last_rescored = 0;  // rows the last ssp_cosine_identify2(precision = 1) call scored again in fp32
 };
 
 struct ssp_segments {

@@ -252,6 +252,10 @@ struct CosRegArgs {
     float* minval;
     int64_t N;
     int32_t d, S, n_tiles;
+    // re-scoring pass of the split-precision path: the embeddings are X[rows[i]], i < *n_dev (a device-side count: no host round trip),
+    // results go to argmin[rows[i]] / minval[rows[i]]; the launch covers the worst case and workgroups past the count leave at once
+    const int32_t* rows = nullptr;
+    const int32_t* n_dev = nullptr;
 };
 
 // DENSE: the same streaming GEMM as a fully connected layer (rows = units of an un-normalised packed weight image, epilogue = bias +
@@ -266,6 +270,8 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
     const int fl = lane & 31, h = lane >> 5;
     const int d = a.d;
     const int64_t col0 = (int64_t)blockIdx.x * 128 + wave * 32;  // this wave's 32 embeddings
+    const int64_t Nn = a.n_dev ? (int64_t)*a.n_dev : a.N;
+    if ((int64_t)blockIdx.x * 128 >= Nn) return;  // (whole workgroup: before any barrier)
 
     // ---- B operand: b[q][e] = x[col][8q + 2e + h]; staged through LDS in 64-wide k chunks so HBM reads stay coalesced
     float b[NQ][4];
@@ -282,8 +288,8 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
                 const int idx = lane + 64 * u, r = idx >> 4, k = kc * 64 + 4 * (idx & 15);
                 const int64_t gc = col0 + r;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gc < a.N) {
-                    const float* __restrict__ p = a.X + gc * d + k;
+                if (gc < Nn) {
+                    const float* __restrict__ p = a.X + (a.rows ? (int64_t)a.rows[gc] : gc) * d + k;
                     if (k + 3 < d) {
                         const f4u t4 = *reinterpret_cast<const f4u*>(p);
                         v[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
@@ -343,6 +349,7 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
     float best = INFINITY;
     int besti = 0x7fffffff;
     const int64_t gc = col0 + fl;
+    const int64_t go = (a.rows && gc < Nn) ? (int64_t)a.rows[gc] : gc;  // where this lane's results go
     int slot = 0;  // slot of half-step 2 t
     for (int t = 0; t < a.n_tiles; ++t) {
         const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
             }
         }
         if (DENSE) {
-            if (gc < a.N) {
+            if (gc < Nn) {
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
                     const int row = t * 32 + 8 * i4 + 4 * h;
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
                     float dv = 1.0f - acc[i] * ix;
                     const bool fin = dv == dv;  // a NaN stays a NaN and orders first (see cosine_kernel)
                     dv = fin ? fminf(fmaxf(dv, 0.0f), 2.0f) : dv;
-                    if (a.dist && gc < a.N) a.dist[gc * a.S + row] = dv;
+                    if (a.dist && gc < Nn) a.dist[go * a.S + row] = dv;
                     const float key = fin ? dv : -INFINITY;
                     if (key < best || (key == best && row < besti)) {
                         best = key;
@@ -424,9 +431,9 @@ __global__ __launch_bounds__(256, 3) void cosine_reg_kernel(CosRegArgs a) {
         best = ob;
         besti = oi;
     }
-    if (h == 0 && gc < a.N) {
-        if (a.argmin) a.argmin[gc] = besti == 0x7fffffff ? 0 : besti;
-        if (a.minval) a.minval[gc] = best == -INFINITY ? __builtin_nanf("") : best;  // (distances are >= 0: -inf is the NaN key)
+    if (h == 0 && gc < Nn) {
+        if (a.argmin) a.argmin[go] = besti == 0x7fffffff ? 0 : besti;
+        if (a.minval) a.minval[go] = best == -INFINITY ? __builtin_nanf("") : best;  // (distances are >= 0: -inf is the NaN key)
     }
 }
 
@@ -442,6 +449,242 @@ static int launch_cos_reg(const CosRegArgs& a, hipStream_t s) {
     SSP_HIP(hipGetLastError());
     return SSP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-precision arg-min (precision = 1): the same sweep on v_mfma_f32_32x32x16_bf16 — 16 x the per-clock rate of the fp32-input
+// MFMA.  Unit-norm centroids and unit-norm embeddings are split into hi = bf16(v), lo = bf16(v - hi); a cosine is accumulated in fp32
+// as  ch.xh + ch.xl + cl.xh  (3 MFMAs per 16 k instead of 8 fp32 ones).  What is dropped or rounded differently from the fp32 path is
+// BOUNDED for unit vectors (cos_band below), so the kernel keeps every embedding's two largest cosines: when they are further apart
+// than twice the bound the arg-min is the fp32 path's; otherwise (or when anything is NaN) the row goes on a device-side list and the
+// fp32 kernel above scores it again (cosine_reg_kernel with rows / n_dev: no host round trip) — the arg-min is the fp32 path's on
+// EVERY row, the minimum distance within the band of it.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// centroid image: [tile][half 2][ks 8 (NK/2)][part hi | lo][lane 64][8 bf16]: lane (h = l >> 5, row = l & 31) holds
+// c_hat[tile * 32 + row][16 (half * NK/2 + ks) + 8 h + j]; flag[0] |= 1 when a centroid's norm is not a finite positive number
+__global__ __launch_bounds__(256) void cos_pack16_kernel(const float* __restrict__ C, int S, int d, int nk, __bf16* __restrict__ img,
+                                                         int32_t* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_rows = ((S + 31) / 32) * 32;
+    if (row >= n_rows) return;
+    float ss = 0.f;
+    if (row < S)
+        for (int k = lane; k < d; k += 64) ss = fmaf(C[(size_t)row * d + k], C[(size_t)row * d + k], ss);
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float inv = 1.0f / sqrtf(ss);
+    if (row < S && lane == 0 && !(inv > 0.f && inv < INFINITY)) atomicOr(flag, 1);
+    __bf16* tile = img + (size_t)(row >> 5) * nk * 1024;  // nk k-steps x (hi + lo) x 64 lanes x 8
+    for (int k = lane; k < nk * 16; k += 64) {
+        const float v = (row < S && k < d) ? C[(size_t)row * d + k] * inv : 0.f;
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        const int ks = k >> 4, hh = (k >> 3) & 1, j = k & 7;
+        const size_t at = (((size_t)ks * 2) * 64 + hh * 32 + (row & 31)) * 8 + j;
+        tile[at] = hi;
+        tile[at + 512] = lo;
+    }
+}
+
+struct Cos16Args {
+    const float* X;
+    const __bf16* img;
+    int32_t* argmin;
+    float* minval;
+    int32_t* list;         // rows to score again in fp32
+    int32_t* count;        // [0] how many; [1] centroid flag (cos_pack16_kernel)
+    int64_t N;
+    int32_t d, S, n_tiles;
+    float band2;           // twice the bound on |cos(bf16 x 3) - cos(fp32 path)|
+};
+
+template <int NK>  // k-steps of 16: d <= 16 NK
+__global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HALF_BYTES = (NK / 2) * 2048;  // a k-half of a 32-row tile: NK/2 k-steps x (hi + lo) x 1 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 31, h = lane >> 5;
+    const int d = a.d;
+    const int64_t col0 = (int64_t)blockIdx.x * 128 + wave * 32;
+
+    // ---- B operand: lane (embedding fl, half h) holds x_hat[col][16 ks + 8 h + j] as hi / lo fragments.  The rows come through LDS in
+    //      64-wide k chunks (coalesced HBM reads), first as fp32 (the norm needs all of a row), then split in place.
+    float bx[NK][8];
+    float ss = 0.f;
+    {
+        float* xs = reinterpret_cast<float*>(smem) + wave * (32 * 65);  // [32 rows][64 + 1 pad]
+#pragma unroll
+        for (int kc = 0; kc < NK / 4; ++kc) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = lane + 64 * u, r = idx >> 4, k = kc * 64 + 4 * (idx & 15);
+                const int64_t gc = col0 + r;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gc < a.N) {
+                    const float* __restrict__ p = a.X + gc * d + k;
+                    if (k + 3 < d) {
+                        const f4u t4 = *reinterpret_cast<const f4u*>(p);
+                        v[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
+                    } else {
+                        if (k < d) v[u].x = p[0];
+                        if (k + 1 < d) v[u].y = p[1];
+                        if (k + 2 < d) v[u].z = p[2];
+                        if (k + 3 < d) v[u].w = p[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = lane + 64 * u, r = idx >> 4, c = 4 * (idx & 15);
+                float* dst = xs + r * 65 + c;
+                dst[0] = v[u].x;
+                dst[1] = v[u].y;
+                dst[2] = v[u].z;
+                dst[3] = v[u].w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v1 = xs[fl * 65 + 16 * k4 + 8 * h + j];
+                    bx[kc * 4 + k4][j] = v1;
+                    ss = fmaf(v1, v1, ss);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    ss += __shfl_xor(ss, 32);
+    const float ix = 1.0f / sqrtf(ss);
+    bf16x8 bh[NK], bl[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = bx[ks][j] * ix;
+            const __bf16 hi = (__bf16)v;
+            bh[ks][j] = hi;
+            bl[ks][j] = (__bf16)(v - (float)hi);
+        }
+    __syncthreads();  // the staging area is about to be overwritten by tile 0
+
+    // centroid tiles stream through a ring of THREE half-tile slots, as in cosine_reg_kernel
+    const int n_steps = 2 * a.n_tiles;
+    auto stage = [&](int step, int slot) {
+        const char* src = reinterpret_cast<const char*>(a.img) + (size_t)step * HALF_BYTES;
+        char* dst = smem + slot * HALF_BYTES;
+#pragma unroll
+        for (int p = 0; p < (NK + 3) / 4; ++p) {
+            const int piece = wave + 4 * p;  // NK 1-KiB pieces per half
+            if (piece < NK) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + piece * 1024 + lane * 16), (lds_ptr_t)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    stage(1, 1);
+    __syncthreads();
+
+    float b1 = -INFINITY, b2 = -INFINITY;  // the two largest cosines of this lane's rows (b1: the first row that reaches it)
+    int i1 = 0x7fffffff;
+    bool bad = false;                      // a NaN went by
+    int slot = 0;
+    for (int t = 0; t < a.n_tiles; ++t) {
+        const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (2 * t + 2 < n_steps) stage(2 * t + 2, s2);
+        {
+            const char* wcur = smem + slot * HALF_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < NK / 2; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wcur + (ks * 2 + 0) * 1024 + lane * 16);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wcur + (ks * 2 + 1) * 1024 + lane * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (2 * t + 3 < n_steps) stage(2 * t + 3, slot);
+        {
+            const char* wcur = smem + s1 * HALF_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < NK / 2; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wcur + (ks * 2 + 0) * 1024 + lane * 16);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wcur + (ks * 2 + 1) * 1024 + lane * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[NK / 2 + ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[NK / 2 + ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[NK / 2 + ks], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // ascending in i: a strict > keeps the first row of equal cosines
+            if (row < a.S) {
+                const float v = acc[i];
+                bad = bad || v != v;
+                const bool gt = v > b1;
+                b2 = gt ? b1 : fmaxf(b2, v);
+                i1 = gt ? row : i1;
+                b1 = gt ? v : b1;
+            }
+        }
+        __syncthreads();
+        slot = s2;
+    }
+    // the two lane halves hold different rows of the same embedding
+    {
+        const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+        const int oi = __shfl_xor(i1, 32);
+        const bool ob = __shfl_xor((int)bad, 32) != 0;
+        const bool take = o1 > b1 || (o1 == b1 && oi < i1);
+        const float lose = take ? b1 : o1;
+        b2 = fmaxf(fmaxf(b2, o2), lose);
+        b1 = take ? o1 : b1;
+        i1 = take ? oi : i1;
+        bad = bad || ob;
+    }
+    const int64_t gc = col0 + fl;
+    const bool mine = h == 0 && gc < a.N;
+    // close calls (and anything that is not a number: a zero-norm embedding, a NaN centroid) are scored again in fp32; with a single
+    // centroid there is nothing to confuse
+    const bool again = mine && (bad || a.count[1] != 0 || !(ix > 0.f && ix < INFINITY) || (a.S > 1 && !(b1 - b2 >= a.band2)));
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(again);
+    if (m != 0) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.count, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (again) a.list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)gc;
+    }
+    if (mine && !again) {
+        if (a.argmin) a.argmin[gc] = i1;
+        if (a.minval) a.minval[gc] = fminf(fmaxf(1.0f - b1, 0.0f), 2.0f);
+    }
+}
+
+template <int NK>
+static int launch_cos16(const Cos16Args& a, hipStream_t s) {
+    const size_t ring = (size_t)3 * (NK / 2) * 2048, xst = (size_t)4 * 32 * 65 * 4;
+    const size_t lds = ring > xst ? ring : xst;
+    const int64_t grid = ceil_div<int64_t>(a.N, 128);
+    if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
+    if (lds > 64 * 1024)
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_bf16x3_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((cosine_bf16x3_kernel<NK>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
+}
+
+// bound on |cos(bf16 x 3) - cos(fp32 path)| for unit vectors of dimension d.  x = hi + lo + r with |x - hi| <= 2^-9 |x| and
+// |r| <= 2^-18 |x| (two round-to-nearest bf16 steps), likewise c: the products the split path leaves out (lo.lo, every r term) sum to at
+// most 3.01 2^-18 sum |x_k| |c_k| <= 3.01 2^-18 (Cauchy-Schwarz, unit vectors).  Products of bf16 numbers are exact in fp32; the
+// accumulation of 3 d terms whose absolute sum is <= 1 + 2^-7 rounds (or truncates: the matrix core's internal order is not documented, so
+// the bound assumes the worst, 2^-23 per term) at most 3 d 2^-23 in total; the fp32 path's own sweep over d terms at most d 2^-23.
+static float cos_band(int d) { return 3.01f * 0x1p-18f + 4.0f * (float)d * 0x1p-23f * 1.01f; }
 
 // d_vector.py:310-313 — one workgroup per speaker, rows summed IN ROW ORDER into a float64 accumulator (fixed summation order, like
 // numpy's mean on the reference's float64 `avg`).  The label array is scanned 2048 rows at a time with independent coalesced loads;
@@ -578,13 +821,28 @@ int ssp_centroids(ssp_ctx* ctx, const float* X, const int32_t* labels, int64_t N
 
 int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,
                         int32_t* argmin_out, float* min_out, int where, float* kernel_ms) {
+    return ssp_cosine_identify2(ctx, X, N, d, C, S, dist_out, argmin_out, min_out, where, 0, kernel_ms);
+}
+
+int ssp_cosine_last_rescored(const ssp_ctx* ctx, int32_t* n_out) {
+    if (!ctx || !n_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_last_rescored: null");
+    *n_out = ctx->cos_last_rescored;
+    return SSP_OK;
+}
+
+int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,
+                         int32_t* argmin_out, float* min_out, int where, int precision, float* kernel_ms) {
     ssp::TraceRange trace_("ssp_cosine_identify");
     SSP_TRY(use_ctx(ctx));
     if (N < 0 || d < 1 || S < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: bad shape N=%lld d=%d S=%d", (long long)N, d, S);
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: where");
+    if (precision < 0 || precision > 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: precision must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA + fp32 re-scoring of close calls)");
+    if (precision == 1 && (dist_out || d > 256))
+        SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_cosine_identify: precision 1 gives the arg-min / minimum only (dist_out must be NULL) for d <= 256");
     if (kernel_ms) *kernel_ms = 0.f;
     if (N == 0) return SSP_OK;
     if (!X || !C) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: null input");
+    if (N > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_cosine_identify: more than 2^31 - 1 embeddings in one call");
     hipStream_t s = ctx->stream;
     Staged sx, sc, sd, sa, sm;
     int rc;
@@ -600,6 +858,47 @@ int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, cons
     SSP_TRY(rc);
     DevBuf inc, img;
     Timer tm;
+    ctx->cos_last_rescored = 0;
+    if (precision == 1) {
+        // bf16 x 3 sweep with the two best cosines per embedding, then the fp32 kernel on the rows whose call is closer than the error
+        // bound (a device-side list and count: nothing comes back to the host in between)
+        const int nk = d <= 64 ? 4 : (d <= 128 ? 8 : (d <= 192 ? 12 : 16)), nq = 2 * nk;
+        const int n_tiles = (S + 31) / 32;
+        DevBuf img16, list, count;
+        SSP_TRY(img16.alloc((size_t)n_tiles * nk * 2048));
+        SSP_TRY(img.alloc((size_t)n_tiles * nq * 256 * sizeof(float)));
+        SSP_TRY(list.alloc((size_t)N * sizeof(int32_t)));
+        SSP_TRY(count.alloc(2 * sizeof(int32_t)));
+        int32_t* dA2 = dA;
+        float* dM2 = dM;
+        Cos16Args ca{dX, img16.as<__bf16>(), dA2, dM2, list.as<int32_t>(), count.as<int32_t>(), N, d, S, n_tiles, 2.0f * cos_band(d)};
+        CosRegArgs ra{dX, img.as<float>(), nullptr, 0, nullptr, dA2, dM2, N, d, S, n_tiles};
+        ra.rows = list.as<int32_t>();
+        ra.n_dev = count.as<int32_t>();
+        SSP_TRY(tm.start(kernel_ms != nullptr, s));
+        SSP_HIP(hipMemsetAsync(count.p, 0, 2 * sizeof(int32_t), s));
+        hipLaunchKernelGGL(cos_pack16_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nk, img16.as<__bf16>(), count.as<int32_t>() + 1);
+        hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>(), 1);
+        SSP_HIP(hipGetLastError());
+        switch (nk) {
+            case 4: SSP_TRY(launch_cos16<4>(ca, s)); break;
+            case 8: SSP_TRY(launch_cos16<8>(ca, s)); break;
+            case 12: SSP_TRY(launch_cos16<12>(ca, s)); break;
+            default: SSP_TRY(launch_cos16<16>(ca, s)); break;
+        }
+        switch (nq) {
+            case 8: SSP_TRY(launch_cos_reg<8>(ra, s)); break;
+            case 16: SSP_TRY(launch_cos_reg<16>(ra, s)); break;
+            case 24: SSP_TRY(launch_cos_reg<24>(ra, s)); break;
+            default: SSP_TRY(launch_cos_reg<32>(ra, s)); break;
+        }
+        SSP_TRY(tm.stop(s, kernel_ms));
+        SSP_TRY(sa.back(ctx, argmin_out, (size_t)N * sizeof(int32_t), where));
+        SSP_TRY(sm.back(ctx, min_out, (size_t)N * sizeof(float), where));
+        SSP_HIP(hipMemcpyAsync(&ctx->cos_last_rescored, count.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SSP_HIP(hipStreamSynchronize(s));  // the images / list are freed at return
+        return SSP_OK;
+    }
     if (d <= 256) {  // register-resident embeddings, LDS-DMA streamed centroid tiles
         const int nq = d <= 64 ? 8 : (d <= 128 ? 16 : (d <= 192 ? 24 : 32));
         const int n_tiles = (S + 31) / 32;

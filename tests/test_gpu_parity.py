@@ -1104,6 +1104,66 @@ def test_cosine_odd_shapes_vs_oracle(ssp):
         np.testing.assert_allclose(r["min"], ref.min(1), rtol=0, atol=3e-6)
 
 
+@pytest.mark.parametrize("d", [128, 256, "tie"])
+def test_cosine_split_precision_argmin_equals_fp32_path_on_golden(golden, ssp, d):
+    """ssp_cosine_identify2(precision = 1): bf16x3 MFMA sweep + fp32 re-scoring of close calls — the fp32 path's arg-min on EVERY row,
+    the constructed exact tie (first index, d_vector.py:319) and the 1.4e-9 near tie included; the minimum within the error bound."""
+    pkg, api = ssp
+    g = golden("cosine")
+    X, Cn = g[f"X_{d}"].astype(np.float32), g[f"C_{d}"].astype(np.float32)
+    ctx = api.default_context()
+    r0 = api.cosine_identify(ctx, X, Cn)
+    r1 = api.cosine_identify(ctx, X, Cn, precision=1)
+    assert np.array_equal(np.asarray(r1["argmin"]), np.asarray(r0["argmin"]))
+    np.testing.assert_allclose(r1["min"], r0["min"], rtol=0, atol=2e-4)
+    ref = g[f"dist_{d}"]
+    top2 = np.sort(ref, axis=1)[:, :2]
+    clear = (top2[:, 1] - top2[:, 0] > 1e-6) | (top2[:, 1] == top2[:, 0])
+    assert (np.asarray(r1["argmin"])[clear] == g[f"argmin_{d}"][clear]).all()
+    if d == "tie":
+        assert r1["rescored"] >= 1   # the exact tie cannot be called by the approximate sweep
+
+
+def test_cosine_split_precision_close_calls_nan_rules_and_shapes(ssp):
+    """adversarial inputs for the error band: pairs of centroids closer than the bf16x3 error (every row is a close call and must be
+    scored again), centroids of wildly different norms, zero-norm / NaN embeddings, a NaN centroid (numpy's argmin takes the first NaN),
+    one centroid, odd shapes — arg-min equal to the fp32 path's everywhere, NaN minima where it has them"""
+    pkg, api = ssp
+    ctx = api.default_context()
+    rng = np.random.default_rng(29)
+
+    def both(X, Cn):
+        r0 = api.cosine_identify(ctx, X, Cn)
+        r1 = api.cosine_identify(ctx, X, Cn, precision=1)
+        assert np.array_equal(np.asarray(r1["argmin"]), np.asarray(r0["argmin"]))
+        m0, m1 = np.asarray(r0["min"]), np.asarray(r1["min"])
+        assert (np.isnan(m0) == np.isnan(m1)).all()
+        ok = ~np.isnan(m0)
+        assert np.abs(m0[ok] - m1[ok]).max(initial=0.0) <= 2e-4
+        return r1["rescored"]
+
+    for (N, S, d) in [(1, 1, 3), (130, 129, 70), (257, 1251, 256), (5, 300, 33), (1000, 40, 192), (333, 64, 16)]:
+        Cn = rng.standard_normal((S, d)).astype(np.float32)
+        X = (Cn[rng.integers(0, S, N)] + 0.7 * rng.standard_normal((N, d))).astype(np.float32)
+        both(X, Cn)
+    # near-duplicate centroids: c_{2i+1} = c_{2i} (1 + 1e-6 noise): the two best cosines differ by ~1e-6 < the band
+    S, d, N = 64, 256, 4000
+    Cn = rng.standard_normal((S, d)).astype(np.float32)
+    Cn[1::2] = Cn[0::2] * (1.0 + 1e-6 * rng.standard_normal((S // 2, d)).astype(np.float32))
+    X = (Cn[rng.integers(0, S, N)] + 0.5 * rng.standard_normal((N, d))).astype(np.float32)
+    assert both(X, Cn) == N
+    # norms over 12 orders of magnitude (the kernel normalises before it splits), a zero-norm row, a NaN row, an inf entry
+    Cn = (rng.standard_normal((50, 128)) * (10.0 ** rng.uniform(-6, 6, (50, 1)))).astype(np.float32)
+    X = (rng.standard_normal((500, 128)) * (10.0 ** rng.uniform(-6, 6, (500, 1)))).astype(np.float32)
+    X[7] = 0.0
+    X[11, 3] = np.nan
+    X[13, 5] = np.inf
+    both(X, Cn)
+    Cn2 = Cn.copy()
+    Cn2[17] = np.nan   # an empty speaker's centroid (d_vector.py:310-313: the mean of no rows)
+    assert both(X, Cn2) == len(X)
+
+
 def test_nn_model_test_enroll_eval(ssp):
     from speech_signal_processing_amd import d_vector
     rng = np.random.default_rng(11)
@@ -1563,6 +1623,11 @@ def test_full_size_cfg4_cosine_replication(ssp):
     refd = O.cosine_matrix(base, Cn)
     assert (am[:R].cpu().numpy() == refd.argmin(1)).all()
     assert np.abs(mn[:R].cpu().numpy() - refd.min(1)).max() < 5e-6
+    # split precision at full size: the fp32 path's arg-min on all 1e6 rows
+    r1 = api.cosine_identify(ctx, X, torch.from_numpy(Cn).cuda(), precision=1)
+    torch.cuda.synchronize()
+    assert bool((r1["argmin"] == am).all())
+    assert float((r1["min"] - mn).abs().max()) <= 2e-4
 
 
 def _random_generic_case(rng, n_fft):
