@@ -587,6 +587,25 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
     stage(1, 1);
     __syncthreads();
 
+    // one k-half of a tile: the A fragments of k-step ks + 1 are in flight while the three products of k-step ks issue (the LDS latency
+    // would otherwise sit between every triple: the reads are what the matrix pipe waits for)
+    auto half_sweep = [&](const char* wcur, int k0, f32x16& acc) {
+        const char* wl = wcur + lane * 16;
+        bf16x8 ah = *reinterpret_cast<const bf16x8*>(wl), al = *reinterpret_cast<const bf16x8*>(wl + 1024);
+#pragma unroll
+        for (int ks = 0; ks < NK / 2; ++ks) {
+            bf16x8 nh = ah, nl = al;
+            if (ks + 1 < NK / 2) {
+                nh = *reinterpret_cast<const bf16x8*>(wl + (ks + 1) * 2048);
+                nl = *reinterpret_cast<const bf16x8*>(wl + (ks + 1) * 2048 + 1024);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[k0 + ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[k0 + ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[k0 + ks], acc, 0, 0, 0);
+            ah = nh;
+            al = nl;
+        }
+    };
     float b1 = -INFINITY, b2 = -INFINITY;  // the two largest cosines of this lane's rows (b1: the first row that reaches it)
     int i1 = 0x7fffffff;
     bool bad = false;                      // a NaN went by
@@ -597,30 +616,10 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         if (2 * t + 2 < n_steps) stage(2 * t + 2, s2);
-        {
-            const char* wcur = smem + slot * HALF_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < NK / 2; ++ks) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wcur + (ks * 2 + 0) * 1024 + lane * 16);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wcur + (ks * 2 + 1) * 1024 + lane * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc, 0, 0, 0);
-            }
-        }
+        half_sweep(smem + slot * HALF_BYTES, 0, acc);
         __syncthreads();
         if (2 * t + 3 < n_steps) stage(2 * t + 3, slot);
-        {
-            const char* wcur = smem + s1 * HALF_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < NK / 2; ++ks) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wcur + (ks * 2 + 0) * 1024 + lane * 16);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wcur + (ks * 2 + 1) * 1024 + lane * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[NK / 2 + ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[NK / 2 + ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[NK / 2 + ks], acc, 0, 0, 0);
-            }
-        }
+        half_sweep(smem + s1 * HALF_BYTES, NK / 2, acc);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // ascending in i: a strict > keeps the first row of equal cosines
