@@ -21,14 +21,15 @@ constexpr int ITERS = 2000;
 #define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 enum Op { FMA, PKFMA, PKADD, PKMUL, ADD, MUL, DPPMOV, DPPADD, FMAC, LOGF, PKFMA_SEL, MIX_PK_PLAIN, DSR64, DSR128, DSW64, DSW32, DSR32,
-          MFMA16, MFMA16_V4, MFMA16_V8, MFMA16_V12, MFMA4, MFMA4_V2, PKFMA_DEP, FMA_DEP, BPERM, MFMA16_PK2, MFMA16_PK4, MFMA16_PK6, SNOP, VMOV, NOPS };
+          MFMA16, MFMA16_V4, MFMA16_V8, MFMA16_V12, MFMA4, MFMA4_V2, PKFMA_DEP, FMA_DEP, BPERM, MFMA16_PK2, MFMA16_PK4, MFMA16_PK6, SNOP, VMOV, MFMA32BF, MFMA32BF_PK4, CVTBF, PERM32, SPLIT2, NOPS };
 static const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_add_f32", "v_mul_f32", "v_mov_b32_dpp row_mirror",
                               "v_add_f32_dpp row_mirror", "v_fmac_f32", "v_log_f32", "v_pk_fma_f32 op_sel", "pk_fma + fma alternating (per pair)",
                               "ds_read_b64", "ds_read_b128", "ds_write_b64", "ds_write_b32", "ds_read_b32",
                               "mfma_16x16x4_f32 alone", "mfma_16x16x4 + 4 v_fma (per group)", "mfma_16x16x4 + 8 v_fma (per group)", "mfma_16x16x4 + 12 v_fma (per group)",
                               "mfma_4x4x1_16b_f32 alone", "mfma_4x4x1 + 2 v_fma (per group)", "v_pk_fma_f32 dependent chain", "v_fma_f32 dependent chain",
                               "ds_bpermute_b32", "mfma_16x16x4 + 2 v_pk_fma (per group)", "mfma_16x16x4 + 4 v_pk_fma (per group)", "mfma_16x16x4 + 6 v_pk_fma (per group)",
-                              "s_nop 0", "v_mov_b32"};
+                              "s_nop 0", "v_mov_b32", "mfma_32x32x16_bf16 alone", "mfma_32x32x16_bf16 + 4 v_pk_fma (per group)", "v_cvt_pk_bf16_f32",
+                              "v_permlane32_swap_b32", "bf16 hi/lo split of a float pair (cvt, 2 unpack, pk_add, cvt: per group of 5)"};
 // instructions per body (for reporting): groups count as 1
 static int body_count(int op) { return 32; }
 
@@ -48,6 +49,15 @@ __global__ __launch_bounds__(256) void bench(unsigned long long* spans, float* s
     v4f acc4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc4[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    v16f acc16[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc16[i][k] = 0.f;
+    v4f opa = v4f{1.5f, 2.5f, 3.5f, 4.5f}, opb = v4f{0.5f, 0.25f, 0.125f, 1.f};
+    unsigned hb[8], lb2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hb[i] = lb2[i] = i;
     const unsigned ldsaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + (lane * 16) % 8192;
     const unsigned ldsaddr8 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + lane * 8;
     const unsigned ldsaddr4 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds + lane * 4;
@@ -166,6 +176,36 @@ __global__ __launch_bounds__(256) void bench(unsigned long long* spans, float* s
     if constexpr (OP == MFMA16_PK6) { VP(4) VP(5) }
                 R8(X)
 #undef X
+            } else if constexpr (OP == MFMA32BF || OP == MFMA32BF_PK4) {
+                // the bf16 matrix-core product a hi/lo-split radix-16 pass would run on (two independent 32 x 32 accumulators)
+#define VP(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define X(i)                                                                                                   \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc16[i & 1]) : "v"(opa), "v"(opb));           \
+    if constexpr (OP == MFMA32BF_PK4) { VP(0) VP(1) VP(2) VP(3) }
+                R8(X)
+#undef X
+#undef VP
+            } else if constexpr (OP == CVTBF) {
+#define X(i) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hb[i]) : "v"(a[i].x), "v"(a[i].y));
+                R8(X)
+#undef X
+            } else if constexpr (OP == PERM32) {
+#define X(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(s[i]), "+v"(s[(i + 1) & 7]));
+                R8(X)
+#undef X
+            } else if constexpr (OP == SPLIT2) {
+                // hi = bf16(x) for a pair, back to fp32 (shift / mask), lo = bf16(x - hi): what every operand of a split product costs
+#define X(i)                                                                                                   \
+    {                                                                                                          \
+        v2f hf;                                                                                                \
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hb[i]) : "v"(a[i].x), "v"(a[i].y));                   \
+        asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(hf.x) : "v"(hb[i]));                                      \
+        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(hf.y) : "v"(hb[i]));                                  \
+        asm volatile("v_pk_add_f32 %0, %1, %0 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(hf) : "v"(a[i]));                \
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lb2[i]) : "v"(hf.x), "v"(hf.y));                      \
+    }
+                R8(X)
+#undef X
             } else if constexpr (OP == MFMA4 || OP == MFMA4_V2) {
 #define X(i)                                                                                                   \
     asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc4[i & 3]) : "v"(b.x), "v"(c.y));           \
@@ -183,6 +223,9 @@ __global__ __launch_bounds__(256) void bench(unsigned long long* spans, float* s
     for (int i = 0; i < 8; ++i) keep += a[i].x + a[i].y + s[i] + q[i].x + q[i].w;
 #pragma unroll
     for (int i = 0; i < 4; ++i) keep += acc4[i].x + acc4[i].y;
+    keep += acc16[0][0] + acc16[1][5];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) keep += (float)(hb[i] + lb2[i]);
     if (keep == 123.456f) sink[threadIdx.x] = keep + lds[lane];
     if (lane == 0) spans[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -259,7 +302,7 @@ int main(int argc, char** argv) {
         const double sec = atof(argv[4]);
         switch (op) {
 #define P(O) case O: return power<O>(ncu, d_spans, d_sink, wps, sec);
-            P(SNOP) P(VMOV) P(FMA) P(PKFMA) P(PKADD) P(PKMUL) P(ADD) P(DPPMOV) P(LOGF) P(DSR32) P(DSR64) P(DSR128) P(DSW32) P(DSW64) P(BPERM) P(MFMA16) P(MFMA16_PK4)
+            P(SNOP) P(VMOV) P(FMA) P(PKFMA) P(PKADD) P(PKMUL) P(ADD) P(DPPMOV) P(LOGF) P(DSR32) P(DSR64) P(DSR128) P(DSW32) P(DSW64) P(BPERM) P(MFMA16) P(MFMA16_PK4) P(MFMA32BF) P(MFMA32BF_PK4) P(CVTBF) P(PERM32) P(SPLIT2)
 #undef P
             default: printf("op %d not in the power list\n", op); return 1;
         }
@@ -298,5 +341,10 @@ int main(int argc, char** argv) {
     run<MFMA16_PK6>(ncu, d_spans, d_sink);
     run<MFMA4>(ncu, d_spans, d_sink);
     run<MFMA4_V2>(ncu, d_spans, d_sink);
+    run<MFMA32BF>(ncu, d_spans, d_sink);
+    run<MFMA32BF_PK4>(ncu, d_spans, d_sink);
+    run<CVTBF>(ncu, d_spans, d_sink);
+    run<PERM32>(ncu, d_spans, d_sink);
+    run<SPLIT2>(ncu, d_spans, d_sink);
     return 0;
 }
