@@ -195,9 +195,12 @@ int ssp_gmm_destroy(ssp_gmm* gmm);
  * over speaker models (index 0 = first speaker model); precision: 0 fp32 MFMA (parity path) |
  * 1 bf16x3 split MFMA (fast path, same tolerance class) with every utterance whose top-2 margin lies inside the split-precision
  * error band scored again on the fp32 path, so the arg-max equals precision 0's | 2 bf16x3 split MFMA alone.
- * (precision 1: the band is 8e-5 * (|UBM score| + 1), eight times the split-precision error measured at K = 64 and K = 512, D = 39 — a
- *  calibrated heuristic, not a bound for arbitrary shapes; the call reads the flag count on the host, so it synchronises the stream even
- *  with device pointers and cannot be captured in a graph.  precision 0 is the parity path.)
+ * (precision 1: the band is a BOUND, not a calibration: with every operand split hi + lo the exponent of a mixture is off by at most
+ *  eps * S(x), S(x) = sum_d |x_d| max|mu P|_d + x_d^2 max(P/2)_d (maxima over every mixture of every model, taken at ssp_gmm_pack),
+ *  eps = 3.01 * 2^-18 + 8 D 2^-23 (the products a two-term split leaves out + worst-case fp32 accumulation on both paths); the
+ *  log-sum-exp is 1-Lipschitz and the mean a mean, so a margin between two models is resolved when it exceeds
+ *  2 (eps mean_t S(x_t) + 2^-20 (|score| + 1)): gmm.hip gmm_band_kernel.  The call reads the flag count on the host, so it synchronises the
+ *  stream even with device pointers and cannot be captured in a graph.  precision 0 is the parity path.)
  * Without loglik_out the per-utterance means are formed inside the scoring kernel (the [n_models x frames] matrix never exists). */
 int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_seg, float* loglik_out,
                   float* scores_out, int32_t* argmax_out, int where, int precision, float* kernel_ms);

@@ -546,8 +546,48 @@ __global__ __launch_bounds__(256) void gmm_piece_reduce_kernel(const double* __r
 
 // ---- bf16x3 close calls: utterances whose top-2 margin is within the split-precision error band are listed IN ORDER (one workgroup,
 // ballot prefix: deterministic) for re-scoring on the exact fp32 path
-__global__ __launch_bounds__(256) void gmm_flag_kernel(const float* __restrict__ margin, const float* __restrict__ scores, int n_models,
-                                                       int n_utt, float rel_thr, int32_t* __restrict__ list, int32_t* __restrict__ count) {
+// The band: what the split-precision scores of TWO models can differ by, relative to each other, from the fp32 path's.  A mixture's
+// exponent is c_k + sum_j W_kj aug_j over aug = [x, x^2] (2 D terms; c_k is the accumulator's exact initial value on both paths).  With
+// W and aug split hi + lo (two round-to-nearest bf16 steps: |v - hi - lo| <= 2^-18 |v|) the products left out sum to at most
+// 3.01 2^-18 sum |W_kj| |aug_j|; bf16 products are exact in fp32, and the accumulation of the 6 D terms rounds (or truncates: the matrix
+// core's internal order is undocumented, so 2^-23 per term) at most 6 D 2^-23 sum |W| |aug| (1 + 2^-7); the fp32 path's own 2 D terms
+// another 2 D 2^-23.  sum_j |W_kj| |aug_j| <= S(x) = sum_d |x_d| A_d + x_d^2 B_d with A_d = max |mu P|, B_d = max P / 2 over every mixture
+// of every model (packed once).  The log-sum-exp moves by at most the largest exponent error (it is 1-Lipschitz in the max norm) plus
+// its own evaluation noise (a few ulp of its magnitude on either path: 2^-20 (|score| + 1) covers both), the utterance mean by the mean:
+//   |score_bf16x3 - score_fp32| <= eps mean_t S(x_t) + 2^-20 (|score| + 1),  eps = 3.01 2^-18 + 8 D 2^-23 1.01
+// and a margin between two models by twice that.  One workgroup per utterance.
+__global__ __launch_bounds__(256) void gmm_band_kernel(const float* __restrict__ feats, const int64_t* __restrict__ frame_off, int D,
+                                                       const float* __restrict__ tab, float eps, const float* __restrict__ scores,
+                                                       int n_models, float* __restrict__ band) {
+    __shared__ float red[4];
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const int64_t a0 = frame_off[u], T = frame_off[u + 1] - a0;
+    const float* __restrict__ x = feats + a0 * D;
+    const int64_t n = T * D;
+    float s = 0.f;
+    int d = tid % D;
+    const int step = 256 % D;
+    for (int64_t i = tid; i < n; i += 256) {
+        const float v = x[i];
+        s = fmaf(fabsf(v), tab[d], s);
+        s = fmaf(v * v, tab[D + d], s);
+        d += step;
+        d = d >= D ? d - D : d;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float S = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(T > 0 ? T : 1);
+        const float mag = fabsf(scores[(size_t)u * n_models]) + 1.0f;
+        band[u] = 2.0f * (eps * S * 1.001f + 0x1p-20f * mag);
+    }
+}
+
+// ---- bf16x3 close calls: utterances whose top-2 margin is within the split-precision error band are listed IN ORDER (one workgroup,
+// ballot prefix: deterministic) for re-scoring on the exact fp32 path
+__global__ __launch_bounds__(256) void gmm_flag_kernel(const float* __restrict__ margin, const float* __restrict__ band, int n_utt,
+                                                       int32_t* __restrict__ list, int32_t* __restrict__ count) {
     __shared__ int s_base, s_wave[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_base = 0;
@@ -555,11 +595,7 @@ __global__ __launch_bounds__(256) void gmm_flag_kernel(const float* __restrict__
     for (int u0 = 0; u0 < n_utt; u0 += 256) {
         const int u = u0 + tid;
         bool f = false;
-        if (u < n_utt) {
-            const float mg = margin[u];
-            const float mag = fabsf(scores[(size_t)u * n_models]) + 1.0f;
-            f = !(mg >= rel_thr * mag);  // close call, or not comparable (NaN)
-        }
+        if (u < n_utt) f = !(margin[u] >= band[u]);  // close call, or not comparable (NaN)
         const unsigned long long b = __ballot(f);
         if (lane == 0) s_wave[wave] = __popcll(b);
         __syncthreads();
@@ -645,6 +681,7 @@ struct ssp_gmm {
     uint64_t pb_serial = 0;
     int32_t pb_gran = 0, pb_pieces = 0;
     std::vector<int32_t> pb_host;
+    ssp::DevBuf bound_tab, band;  // precision = 1: [2 D] largest |mu P| and P / 2 per dimension over every mixture; [n_utt] error band of the margins
     ssp::DevBuf pb_dev, partial, margin, flag_list, flag_count, sub_feats, sub_off, sub_scores, sub_argmax, sub_pb, sub_partial;
     std::vector<int32_t> sub_list_host, sub_pb_host;
     std::vector<int64_t> sub_off_host;
@@ -756,6 +793,14 @@ int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const dou
                 reinterpret_cast<float*>(tile + (size_t)2 * nk16 * 1024)[hh * 16 + i] = (float)cst;
             }
     }
+    // precision = 1's error bound (gmm_band_kernel): per dimension the largest |mu P| and P / 2 over every mixture of every model
+    std::vector<float> btab((size_t)2 * D, 0.f);
+    for (size_t mk = 0; mk < (size_t)n_models * K; ++mk)
+        for (int d = 0; d < D; ++d) {
+            const double P = 1.0 / covars[mk * D + d];
+            btab[d] = std::max(btab[d], (float)(std::fabs(means[mk * D + d]) * P * (1.0 + 1e-6)));
+            btab[D + d] = std::max(btab[D + d], (float)(0.5 * P * (1.0 + 1e-6)));
+        }
     ssp_gmm* g = new (std::nothrow) ssp_gmm;
     if (!g) SSP_FAIL(SSP_ERR_NOMEM, "gmm: host alloc");
     g->ctx = ctx;
@@ -767,6 +812,11 @@ int ssp_gmm_pack(ssp_ctx* ctx, int32_t n_models, int32_t K, int32_t D, const dou
     g->tiles_per_model = tpm;
     g->nk16 = nk16;
     int rc = g->wimg.alloc(img.size() * sizeof(float));
+    if (rc == SSP_OK) rc = g->bound_tab.alloc(btab.size() * sizeof(float));
+    if (rc == SSP_OK && hipMemcpyAsync(g->bound_tab.p, btab.data(), btab.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        set_error("gmm: bound table upload failed");
+        rc = SSP_ERR_HIP;
+    }
     if (rc == SSP_OK && nk16 > 0) {
         rc = g->wimg16.alloc(img16.size());
         if (rc == SSP_OK && hipMemcpyAsync(g->wimg16.p, img16.data(), img16.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
@@ -990,13 +1040,15 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
         SSP_TRY(score_fused(gmm, d_feats, frame_seg->host.data(), frame_seg->dev.as<int64_t>(), n_utt, frame_seg->serial, bf16, false,
                             d_sc_work, d_am, d_margin, s));
         if (rescore) {
-            // utterances whose top-2 margin lies within the split-precision error band are scored again on the exact fp32 path, so the
-            // arg-max is the fp32 path's for every utterance.  Band: |score error| of the bf16x3 kernel is <= 1e-5 (|score| + 1)
-            // (measured 7e-6 |score| at configs[2]); the margin threshold leaves a factor 8
-            const float rel_thr = 8.0e-5f;
+            // utterances whose top-2 margin lies within the split-precision error BOUND (gmm_band_kernel) are scored again on the exact
+            // fp32 path, so the arg-max is the fp32 path's for every utterance
+            const float eps = 3.01f * 0x1p-18f + 8.0f * (float)gmm->D * 0x1p-23f * 1.01f;
+            SSP_TRY(gmm->band.reserve((size_t)n_utt * sizeof(float)));
             SSP_TRY(gmm->flag_list.reserve((size_t)n_utt * sizeof(int32_t)));
             SSP_TRY(gmm->flag_count.reserve(sizeof(int32_t)));
-            hipLaunchKernelGGL(gmm_flag_kernel, dim3(1), dim3(256), 0, s, d_margin, d_sc_work, M, (int)n_utt, rel_thr,
+            hipLaunchKernelGGL(gmm_band_kernel, dim3((unsigned)n_utt), dim3(256), 0, s, d_feats, frame_seg->dev.as<int64_t>(), gmm->D,
+                               gmm->bound_tab.as<float>(), eps, d_sc_work, M, gmm->band.as<float>());
+            hipLaunchKernelGGL(gmm_flag_kernel, dim3(1), dim3(256), 0, s, d_margin, gmm->band.as<float>(), (int)n_utt,
                                gmm->flag_list.as<int32_t>(), gmm->flag_count.as<int32_t>());
             SSP_HIP(hipGetLastError());
             int32_t n_flag = 0;

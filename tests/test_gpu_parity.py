@@ -883,6 +883,40 @@ def test_gmm_bf16x3_close_calls_are_rescored_in_fp32(ssp):
     assert np.array_equal(np.asarray(only_am["argmax"]), np.asarray(r0["argmax"]))
 
 
+@pytest.mark.parametrize("K,scale", [(1, 1.0), (512, 1.0), (64, 30.0), (16, 1e-2)])
+def test_gmm_bf16x3_band_is_a_bound_at_adversarial_shapes(ssp, K, scale):
+    """precision = 1's band is derived, not calibrated (include/ssp.h): K = 1 and K = 512, means far from the data relative to the
+    variances (|mu| / sigma = 30: the exponents are O(1e4) and the split error with them) and tiny variances — with speakers a hair
+    apart (1e-5 relative) so that calls ARE close — the arg-max must be the fp32 path's on every utterance."""
+    pkg, api = ssp
+    rng = np.random.default_rng(1000 + K)
+    D, S, U = 39, 8, 300
+    w = rng.dirichlet(5 * np.ones(K))
+    cov = rng.uniform(0.5, 2.0, (K, D)) * (scale ** 2 if scale < 1 else 1.0)
+    mu = rng.standard_normal((K, D)) * (scale if scale >= 1 else 1.0)
+    mus = [mu] + [mu * (1.0 + 1e-5 * rng.standard_normal((K, D))) for _ in range(S)]
+    mus[3] = mus[2].copy()
+    lens = rng.integers(10, 120, U)
+    feats = np.vstack([(mus[1 + u % S][rng.choice(K, size=n, p=w)] + np.sqrt(cov[rng.choice(K, size=n)]) * rng.standard_normal((n, D))).astype(np.float32)
+                       for u, n in enumerate(lens)])
+    ctx = api.default_context()
+    sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), np.stack(mus), np.stack([cov] * (S + 1)), has_ubm=True)
+    seg = api.Segments.from_lengths(ctx, lens)
+    r0 = sc.score(feats, seg, precision=0)
+    r1 = sc.score(feats, seg, precision=1)
+    assert np.array_equal(np.asarray(r0["argmax"]), np.asarray(r1["argmax"]))
+    s0, s2 = np.asarray(r0["scores"]), np.asarray(sc.score(feats, seg, precision=2)["scores"])
+    # the raw split-precision scores sit inside the bound the band is made of (margins may use twice this per pair)
+    A = np.max(np.abs(np.stack(mus)) / cov, axis=(0, 1))
+    B = np.max(0.5 / cov, axis=0)
+    eps = 3.01 * 2.0 ** -18 + 8 * D * 2.0 ** -23 * 1.01
+    off = np.concatenate([[0], np.cumsum(lens)])
+    Sx = np.abs(feats.astype(np.float64)) @ A + (feats.astype(np.float64) ** 2) @ B
+    bound = np.array([eps * Sx[off[u]:off[u + 1]].mean() for u in range(U)])[:, None] + 2.0 ** -20 * (np.abs(s0) + 1)
+    assert (np.abs(s2 - s0) <= bound).all(), float((np.abs(s2 - s0) / bound).max())
+    print("K %d scale %g: %d of %d re-scored; raw error / bound max %.3f" % (K, scale, sc.last_rescored, U, float((np.abs(s2 - s0) / bound).max())))
+
+
 def test_gmm_bounded_scratch_batches(ssp, monkeypatch):
     """the piece-sum scratch is capped: scoring in many small utterance batches gives bit-identical results (the sums are float64, so
     where an utterance's frames are cut into pieces has no visible effect on its fp32 mean)"""
