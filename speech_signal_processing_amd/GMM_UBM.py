@@ -91,6 +91,16 @@ def score_matrix(models, ubm, feats):
     return sc[:, 1:] - sc[:, :1], np.asarray(r["argmax"]).astype(np.int64)
 
 
+def identify_with_confidence(models, ubm, feature):
+    """The GUI's read-out of one utterance (UI/GMM_UBM_GUI.py:102-113): prob[0, i] = models[i].score(feature) - ubm.score(feature),
+    res = argmax, then the softmax of the score differences, exp(prob) / sum exp(prob).  Returns (index, softmax probability of that
+    index, the (1, S) softmax row)."""
+    pred, am = score_matrix(models, ubm, [feature])
+    e = np.exp(pred)
+    prob = e / e.sum(axis=1)
+    return int(am[0]), float(prob[0, am[0]]), prob
+
+
 def save_models(gmms, ubm, model_dir="Model"):
     """The two pickles the reference writes after training (GMM_UBM.py:173-179): Model/GMM_MFCC_model.pkl (list of the
     per-speaker models) and Model/UBM_MFCC_model.pkl."""

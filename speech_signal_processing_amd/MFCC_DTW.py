@@ -80,3 +80,12 @@ def generate_template(x):
         keep[1:] = p1[1:] != p1[:-1]
         template = template[keep]
     return template
+
+
+def vote(label):
+    """MFCC_DTW.py:220-229 — the most frequent label; among equally frequent ones the one met first (a stable sort by count over a dict
+    in insertion order, as the reference's)."""
+    counts = {}
+    for l in np.array(label):
+        counts[l] = counts.get(l, 0) + 1
+    return sorted(counts.items(), key=lambda kv: kv[1], reverse=True)[0][0]

@@ -917,6 +917,23 @@ def test_gmm_bf16x3_band_is_a_bound_at_adversarial_shapes(ssp, K, scale):
     print("K %d scale %g: %d of %d re-scored; raw error / bound max %.3f" % (K, scale, sc.last_rescored, U, float((np.abs(s2 - s0) / bound).max())))
 
 
+def test_gui_readout_softmax_of_score_differences(ssp):
+    """UI/GMM_UBM_GUI.py:102-113: arg-max of score differences and their softmax, against sklearn's own score()."""
+    from sklearn.mixture import GaussianMixture
+    from speech_signal_processing_amd import GMM_UBM
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((600, 13))
+    ubm = GaussianMixture(4, covariance_type="diag", random_state=0).fit(X)
+    models = [GaussianMixture(4, covariance_type="diag", random_state=s).fit(X[s::3] + 0.3 * s) for s in range(3)]
+    feat = (X[:80] + 0.6).astype(np.float32)
+    idx, p, row = GMM_UBM.identify_with_confidence(models, ubm, feat)
+    prob = np.array([[m.score(feat) - ubm.score(feat) for m in models]])
+    ref = np.exp(prob) / np.exp(prob).sum(axis=1)
+    assert idx == int(prob.argmax(axis=1)[0])
+    np.testing.assert_allclose(row, ref, rtol=1e-4, atol=1e-6)
+    assert abs(p - ref[0, idx]) <= 1e-4
+
+
 def test_gmm_bounded_scratch_batches(ssp, monkeypatch):
     """the piece-sum scratch is capped: scoring in many small utterance batches gives bit-identical results (the sums are float64, so
     where an utterance's frames are cut into pieces has no visible effect on its fp32 mean)"""

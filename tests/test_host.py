@@ -235,3 +235,12 @@ def test_build_stamp_and_kernel_hash(tmp_path, monkeypatch):
     for name in ("mfcc_hbm_traffic.json", "mfcc_valu_lds_pmc.json"):
         j = json.load(open(os.path.join(ROOT, "profiles", name)))
         assert len(j["kernel_source_sha256"]) == 64              # (whether it matches the tree is for bench.py to report, not a test)
+
+
+def test_vote_matches_the_reference_rule():
+    """MFCC_DTW.py:220-229: most frequent label; ties go to the label met first (stable sort over insertion order)."""
+    from speech_signal_processing_amd.MFCC_DTW import vote
+    assert vote([3, 1, 3, 2, 1, 3]) == 3
+    assert vote(["b", "a", "a", "b"]) == "b"      # two each: the first met
+    assert vote([7]) == 7
+    assert vote(np.array([2, 2, 5, 5, 5])) == 5
