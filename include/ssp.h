@@ -194,7 +194,9 @@ int ssp_gmm_destroy(ssp_gmm* gmm);
  * (= GaussianMixture.score); argmax_out (nullable): int32[n_utt] = argmax_i(score_i - score_ubm)
  * over speaker models (index 0 = first speaker model); precision: 0 fp32 MFMA (parity path) |
  * 1 bf16x3 split MFMA (fast path, same tolerance class) with every utterance whose top-2 margin lies inside the split-precision
- * error band scored again on the fp32 path, so the arg-max equals precision 0's | 2 bf16x3 split MFMA alone.
+ * error band scored again on the fp32 path, so the arg-max equals precision 0's | 2 bf16x3 split MFMA alone | 3 as 1 with the
+ * calibrated band 8e-5 (|UBM score| + 1) (eight times the error measured at K = 64 / 512, D = 39): a HEURISTIC, about 100 times narrower
+ * than 1's bound (rounding errors do not conspire and they average over an utterance's frames), so far fewer utterances are scored twice.
  * (precision 1: the band is a BOUND, not a calibration: with every operand split hi + lo the exponent of a mixture is off by at most
  *  eps * S(x), S(x) = sum_d |x_d| max|mu P|_d + x_d^2 max(P/2)_d (maxima over every mixture of every model, taken at ssp_gmm_pack),
  *  eps = 3.01 * 2^-18 + 8 D 2^-23 (the products a two-term split leaves out + worst-case fp32 accumulation on both paths); the

@@ -561,18 +561,30 @@ __global__ __launch_bounds__(256) void gmm_band_kernel(const float* __restrict__
                                                        int n_models, float* __restrict__ band) {
     __shared__ float red[4];
     const int u = blockIdx.x, tid = threadIdx.x;
+    if (eps < 0.f) {  // the calibrated (heuristic) band
+        if (tid == 0) band[u] = 8.0e-5f * (fabsf(scores[(size_t)u * n_models]) + 1.0f);
+        return;
+    }
     const int64_t a0 = frame_off[u], T = frame_off[u + 1] - a0;
     const float* __restrict__ x = feats + a0 * D;
-    const int64_t n = T * D;
+    // thread = (row phase, column): its two table entries stay in registers and a sweep of the workgroup reads whole consecutive rows
+    const int R = 256 / D;  // rows per sweep (D <= 127)
+    const int col = tid % D, ph = tid / D;
     float s = 0.f;
-    int d = tid % D;
-    const int step = 256 % D;
-    for (int64_t i = tid; i < n; i += 256) {
-        const float v = x[i];
-        s = fmaf(fabsf(v), tab[d], s);
-        s = fmaf(v * v, tab[D + d], s);
-        d += step;
-        d = d >= D ? d - D : d;
+    if (ph < R) {
+        const float ta = tab[col], tb = tab[D + col];
+        int64_t r = ph;
+        for (; r + 3 * R < T; r += 4 * R) {  // four loads in flight
+            const float v0 = x[r * D + col], v1 = x[(r + R) * D + col], v2 = x[(r + 2 * R) * D + col], v3 = x[(r + 3 * R) * D + col];
+            s = fmaf(fabsf(v0), ta, fmaf(v0 * v0, tb, s));
+            s = fmaf(fabsf(v1), ta, fmaf(v1 * v1, tb, s));
+            s = fmaf(fabsf(v2), ta, fmaf(v2 * v2, tb, s));
+            s = fmaf(fabsf(v3), ta, fmaf(v3 * v3, tb, s));
+        }
+        for (; r < T; r += R) {
+            const float v = x[r * D + col];
+            s = fmaf(fabsf(v), ta, fmaf(v * v, tb, s));
+        }
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -980,8 +992,9 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     ssp_ctx* ctx = gmm->ctx;
     SSP_TRY(use_ctx(ctx));
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: where");
-    if (precision < 0 || precision > 2)
-        SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: precision must be 0 (fp32 MFMA), 1 (bf16x3 MFMA + fp32 re-scoring of close calls) or 2 (bf16x3 MFMA alone)");
+    if (precision < 0 || precision > 3)
+        SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: precision must be 0 (fp32 MFMA), 1 (bf16x3 MFMA + fp32 re-scoring inside the proven error bound), "
+                                  "2 (bf16x3 MFMA alone) or 3 (bf16x3 MFMA + fp32 re-scoring inside the calibrated, heuristic band)");
     if (precision != 0 && gmm->nk16 == 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_score: bf16x3 path covers D <= 64");
     if (kernel_ms) *kernel_ms = 0.f;
     const int64_t F = frame_seg->host.back();
@@ -1025,7 +1038,7 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
         }
     } else if (scores_out || argmax_out) {
         // fused path: per-utterance sums leave the scoring kernel as piece partials, [M x F] never reaches HBM
-        const bool rescore = precision == 1 && gmm->has_ubm + 1 < M;  // (one speaker model: nothing to confuse)
+        const bool rescore = (precision == 1 || precision == 3) && gmm->has_ubm + 1 < M;  // (one speaker model: nothing to confuse)
         float* d_margin = nullptr;
         float* d_sc_work = d_sc;
         if (rescore) {
@@ -1046,8 +1059,10 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
             SSP_TRY(gmm->band.reserve((size_t)n_utt * sizeof(float)));
             SSP_TRY(gmm->flag_list.reserve((size_t)n_utt * sizeof(int32_t)));
             SSP_TRY(gmm->flag_count.reserve(sizeof(int32_t)));
+            // (precision 3: the calibrated band of rounds 2 - 3 instead — 8e-5 (|UBM score| + 1), eight times the error measured at K = 64 and
+            //  K = 512, D = 39: a heuristic, 100 x narrower than the bound because rounding errors do not conspire and average over the frames)
             hipLaunchKernelGGL(gmm_band_kernel, dim3((unsigned)n_utt), dim3(256), 0, s, d_feats, frame_seg->dev.as<int64_t>(), gmm->D,
-                               gmm->bound_tab.as<float>(), eps, d_sc_work, M, gmm->band.as<float>());
+                               gmm->bound_tab.as<float>(), precision == 3 ? -1.0f : eps, d_sc_work, M, gmm->band.as<float>());
             hipLaunchKernelGGL(gmm_flag_kernel, dim3(1), dim3(256), 0, s, d_margin, gmm->band.as<float>(), (int)n_utt,
                                gmm->flag_list.as<int32_t>(), gmm->flag_count.as<int32_t>());
             SSP_HIP(hipGetLastError());

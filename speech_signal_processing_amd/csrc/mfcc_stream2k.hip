@@ -89,6 +89,9 @@ struct S2kArgs {
 // sample was fetched 2048 / hop times through L2 — become register moves.
 template <int POWER, int SH>
 __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(MfccArgs a, S2kArgs s) {
+#ifdef SSP_2K_REGTAB
+    static_assert(S2K_WAVES <= 8, "register-resident tables need the 256-VGPR budget of two waves per SIMD");
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,6 +137,15 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
     const int hop = a.hop;
     const int M = 1024;
     const bool centre = a.frame_mode == 2;
+#ifdef SSP_2K_REGTAB  // (experiment: window, first-pass and split twiddles resident in registers at two waves per SIMD)
+    v2f wreg[16], tAreg[15], tSreg[8];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wreg[r] = winl[64 * r];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) tAreg[k1 - 1] = twAl[64 * k1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tSreg[i] = twS[i * 64 + lane];
+#endif
 
     for (;;) {
         int cidx = 0;
@@ -197,7 +209,11 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
         for (int t = t0; t < t0 + n; ++t) {
             v2f z[16];
 #pragma unroll
+#ifdef SSP_2K_REGTAB
+            for (int r = 0; r < 16; ++r) z[r] = nx[r] * wreg[r];
+#else
             for (int r = 0; r < 16; ++r) z[r] = nx[r] * lds_read_v2f(&winl[64 * r]);
+#endif
 #ifndef SSP_2K_NOPREFETCH  // (ablation, wrong results: every frame transforms the chunk's first one)
             if (t + 1 < t0 + n) {
                 if constexpr (SH > 0) {
@@ -210,7 +226,11 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
             // ---- pass 1: DFT16 over r (points 64 r + l), twiddle W_1024^(l k1)
             fft16(z);
 #pragma unroll
+#ifdef SSP_2K_REGTAB
+            for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], tAreg[k1 - 1]);
+#else
             for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], lds_read_v2f(&twAl[64 * k1]));
+#endif
             // ---- transpose 1: lane (k1, lb) <- points l = 4 la + lb of row k1
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) buf[k1 * ROW1 + lane] = z[k1];
@@ -261,7 +281,11 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
                 const v2f hz = zk * 0.5f;
                 const v2f e = __builtin_elementwise_fma(zm, v2f{0.5f, -0.5f}, hz);
                 const v2f d = __builtin_elementwise_fma(zm, v2f{-0.5f, 0.5f}, hz);
+#ifdef SSP_2K_REGTAB
+                const v2f o = cmul_negi(d, tSreg[i]);
+#else
                 const v2f o = cmul_negi(d, lds_read_v2f(&twS[i * 64 + lane]));
+#endif
                 const v2f xa = e + o, xb = e - o;
                 float p0 = xa.x * xa.x + xa.y * xa.y, p1 = xb.x * xb.x + xb.y * xb.y;
                 if (POWER == 1) {  // v_sqrt_f32 (1 ulp): the magnitude feeds a filter sum and a logarithm

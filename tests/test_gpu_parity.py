@@ -881,6 +881,9 @@ def test_gmm_bf16x3_close_calls_are_rescored_in_fp32(ssp):
     print("bf16x3: %d of %d utterances re-scored; raw bf16x3 arg-max differs on %d" % (n_res, U, (np.asarray(r2["argmax"]) != np.asarray(r0["argmax"])).sum()))
     only_am = sc.score(feats, seg, scores=False, precision=1)   # arg-max alone: the work copy of the scores is internal
     assert np.array_equal(np.asarray(only_am["argmax"]), np.asarray(r0["argmax"]))
+    r3 = sc.score(feats, seg, precision=3)                      # the calibrated (heuristic) band: fewer utterances scored twice
+    assert 0 < sc.last_rescored <= n_res
+    assert np.array_equal(np.asarray(r3["argmax"]), np.asarray(r0["argmax"]))
 
 
 @pytest.mark.parametrize("K,scale", [(1, 1.0), (512, 1.0), (64, 30.0), (16, 1e-2)])
