@@ -49,6 +49,10 @@ struct GmmArgs {
                                 // the utterance sits in the batch) then has no visible effect on the fp32 mean
     int64_t frame_base;         // absolute index of the batch's first frame
     int32_t n_utt;
+    // candidate re-scoring (fp32 kernel only): workgroup b scores only the models block_models[b * bl_stride + 1 ..] (count in entry 0;
+    // -1 or a null table: every model) — their tiles in list order, partial sums under their real model index
+    const int32_t* block_models;
+    int32_t bl_stride;
 };
 
 // sum over lanes 0..31 of a value that is zero on lanes 32..63, in float64 and in a fixed order: inclusive DPP row scans, then the two
@@ -255,7 +259,18 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
     PieceMap<CT> pm;
     if (FUSED) pm.init(a, f0 + (int64_t)wave * CT * 32, fl, h);
     __syncthreads();  // every wave has its frames in registers: the staging bytes become the tile ring
-    stage_tile<NQ>(a.wimg, wbuf, wave, lane);  // row tile 0
+    // which row tiles this workgroup walks: all of them, or (candidate re-scoring) the tiles of its listed models only
+    const int32_t* bl = a.block_models ? a.block_models + (size_t)blockIdx.x * a.bl_stride : nullptr;
+    const int n_list = bl ? __builtin_amdgcn_readfirstlane(bl[0]) : -1;
+    const int tpm = a.tiles_per_model;
+    const int n_it = n_list >= 0 ? n_list * tpm : a.n_tiles;
+    auto tile_at = [&](int r) -> int {
+        if (n_list < 0) return r;
+        const int k = r / tpm;
+        return __builtin_amdgcn_readfirstlane(bl[1 + k]) * tpm + (r - k * tpm);
+    };
+    if (n_it == 0) return;  // (wave-uniform over the whole workgroup: no barrier is left waiting)
+    stage_tile<NQ>(a.wimg + (size_t)tile_at(0) * TILE_FLOATS, wbuf, wave, lane);  // the first row tile
     __syncthreads();
 
     float run_m[CT], run_s[CT];
@@ -266,12 +281,12 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
     }
 
     int rt = 0, model = 0;
-    for (int r = 0; r < a.n_tiles; ++r) {
+    for (int r = 0; r < n_it; ++r) {
         const float* wcur = wbuf + (r & 1) * TILE_FLOATS;
         // tile r+1 streams into the other buffer while this one feeds the MFMAs (the barrier at the end of the
         // iteration drains the LDS-DMA: __syncthreads() waits vmcnt(0))
-        if (r + 1 < a.n_tiles)
-            stage_tile<NQ>(a.wimg + (size_t)(r + 1) * TILE_FLOATS, wbuf + ((r + 1) & 1) * TILE_FLOATS, wave, lane);
+        if (r + 1 < n_it)
+            stage_tile<NQ>(a.wimg + (size_t)tile_at(r + 1) * TILE_FLOATS, wbuf + ((r + 1) & 1) * TILE_FLOATS, wave, lane);
         f32x16 acc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -290,16 +305,17 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) lse2_update(acc[ct], run_m[ct], run_s[ct]);
         if (++rt == a.tiles_per_model) {
+            const int mid = n_list >= 0 ? __builtin_amdgcn_readfirstlane(bl[1 + model]) : model;  // the model these tiles belong to
             float llv[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 llv[ct] = lse2_finish(run_m[ct], run_s[ct]);
                 const int fidx = (wave * CT + ct) * 32 + fl;
-                if (!FUSED && h == 0 && fidx < n_valid) a.llT[(size_t)model * a.F + f0 + fidx] = llv[ct];
+                if (!FUSED && h == 0 && fidx < n_valid) a.llT[(size_t)mid * a.F + f0 + fidx] = llv[ct];
                 run_m[ct] = -INFINITY;
                 run_s[ct] = 0.f;
             }
-            if (FUSED) pm.emit(a, model, llv, lane);
+            if (FUSED) pm.emit(a, mid, llv, lane);
             rt = 0;
             ++model;
         }
@@ -621,6 +637,88 @@ __global__ __launch_bounds__(256) void gmm_flag_kernel(const float* __restrict__
     if (tid == 0) *count = s_base;
 }
 
+// ---- which models of a listed (close-call) utterance can still win on the fp32 path: every speaker model whose split-precision score
+// difference is within the band of the best one (the band is twice the bound on a score's error: a model further behind cannot catch
+// up), plus the UBM (the differences are formed against its fp32 score).  cand[i] = (count, models ...); count -1: every model (more
+// than CM - 1 candidates, or scores that are not numbers).  One workgroup per listed utterance.
+constexpr int GMM_CAND = 16;
+__global__ __launch_bounds__(256) void gmm_candidates_kernel(const int32_t* __restrict__ list, const float* __restrict__ scores,
+                                                             const float* __restrict__ band, int n_models, int has_ubm,
+                                                             int32_t* __restrict__ cand) {
+    __shared__ float redf[4];
+    __shared__ int redi[4], s_cnt;
+    const int i = blockIdx.x, u = list[i], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ row = scores + (size_t)u * n_models;
+    const float base = has_ubm ? row[0] : 0.f;
+    float best = -INFINITY;
+    int bad = 0;
+    for (int m = has_ubm + tid; m < n_models; m += 256) {
+        const float v = row[m] - base;
+        bad |= !(v == v);
+        best = fmaxf(best, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        best = fmaxf(best, __shfl_xor(best, o));
+        bad |= __shfl_xor(bad, o);
+    }
+    if (lane == 0) {
+        redf[wave] = best;
+        redi[wave] = bad;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    best = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    bad = redi[0] | redi[1] | redi[2] | redi[3];
+    const float thr = best - band[u];
+    int32_t* out = cand + (size_t)i * GMM_CAND;
+    if (!bad)
+        for (int m = has_ubm + tid; m < n_models; m += 256)
+            if (row[m] - base >= thr) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < GMM_CAND - 1 - has_ubm) out[1 + has_ubm + pos] = m;
+            }
+    __syncthreads();
+    if (tid == 0) {
+        const int c = s_cnt;
+        if (has_ubm) out[1] = 0;
+        out[0] = (bad || !(thr == thr) || c > GMM_CAND - 1 - has_ubm) ? -1 : c + has_ubm;
+    }
+}
+
+// results of the candidate re-scoring back into the batch's outputs: the fp32 scores of the listed utterance's candidates (sub_scores
+// holds garbage for models its workgroups skipped), and the arg-max by gmm_piece_reduce_kernel's rule — fp32 difference against the
+// UBM, larger wins, lower index on ties — over the candidates; count -1: every model was scored, the reduce kernel's own arg-max stands
+__global__ __launch_bounds__(64) void gmm_scatter_cand_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cand, int n_models,
+                                                              int has_ubm, const float* __restrict__ sub_scores,
+                                                              const int32_t* __restrict__ sub_argmax, float* __restrict__ scores,
+                                                              int32_t* __restrict__ argmax_out) {
+    const int i = blockIdx.x, u = list[i], lane = threadIdx.x;
+    const int32_t* c = cand + (size_t)i * GMM_CAND;
+    const float* __restrict__ src = sub_scores + (size_t)i * n_models;
+    const int n = c[0];
+    if (n < 0) {
+        if (scores)
+            for (int m = lane; m < n_models; m += 64) scores[(size_t)u * n_models + m] = src[m];
+        if (argmax_out && lane == 0) argmax_out[u] = sub_argmax[i];
+        return;
+    }
+    if (scores && lane < n) scores[(size_t)u * n_models + c[1 + lane]] = src[c[1 + lane]];
+    if (argmax_out && lane == 0) {
+        const float base = has_ubm ? src[0] : 0.f;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int k = has_ubm; k < n; ++k) {
+            const int m = c[1 + k];
+            const float v = src[m] - base;
+            if (bi == 0x7fffffff || v > best || (v == best && m - has_ubm < bi)) {
+                best = v;
+                bi = m - has_ubm;
+            }
+        }
+        argmax_out[u] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
 // rows of the listed utterances into a compact matrix (sub_off: their frame offsets in the compact matrix)
 __global__ __launch_bounds__(256) void gmm_gather_frames_kernel(const float* __restrict__ feats, const int64_t* __restrict__ frame_off,
                                                                 const int32_t* __restrict__ list, const int64_t* __restrict__ sub_off,
@@ -693,6 +791,8 @@ struct ssp_gmm {
     uint64_t pb_serial = 0;
     int32_t pb_gran = 0, pb_pieces = 0;
     std::vector<int32_t> pb_host;
+    ssp::DevBuf cand, blk;        // candidate re-scoring: [n_flag][GMM_CAND] per listed utterance, [n_blocks][1 + BL] per workgroup of the re-scoring launch
+    std::vector<int32_t> cand_host, blk_host;
     ssp::DevBuf bound_tab, band;  // precision = 1: [2 D] largest |mu P| and P / 2 per dimension over every mixture; [n_utt] error band of the margins
     ssp::DevBuf pb_dev, partial, margin, flag_list, flag_count, sub_feats, sub_off, sub_scores, sub_argmax, sub_pb, sub_partial;
     std::vector<int32_t> sub_list_host, sub_pb_host;
@@ -905,7 +1005,8 @@ static void piece_table(const int64_t* h_off, int64_t u0, int64_t u1, int gran, 
 // are the same n_utt + 1 offsets on the host / device.  bf16: the split-precision kernel.  d_margin (nullable): top-2 margins.
 // `sub`: use the second buffer set (the re-scoring pass runs while the first set still holds the batch's tables).
 static int score_fused(ssp_gmm* gmm, const float* d_feats, const int64_t* h_off, const int64_t* d_off, int64_t n_utt, uint64_t seg_serial,
-                       bool bf16, bool sub, float* d_sc, int32_t* d_am, float* d_margin, hipStream_t s) {
+                       bool bf16, bool sub, float* d_sc, int32_t* d_am, float* d_margin, hipStream_t s,
+                       const int32_t* block_models = nullptr, int bl_stride = 0) {
     const int M = gmm->n_models;
     const int gran = piece_granule(gmm, bf16);
     const size_t cap = [] {
@@ -972,6 +1073,9 @@ static int score_fused(ssp_gmm* gmm, const float* d_feats, const int64_t* h_off,
         a.partial = partial.as<double>();
         a.frame_base = h_off[u0];
         a.n_utt = (int32_t)(u1 - u0);
+        // (workgroup-indexed model lists belong to a batch that runs as ONE launch; a call that had to be cut scores every model)
+        a.block_models = (whole && !bf16) ? block_models : nullptr;
+        a.bl_stride = bl_stride;
         SSP_TRY(launch_kernel_any(gmm, a, bf16, true, s));
         hipLaunchKernelGGL(gmm_piece_reduce_kernel, dim3((unsigned)(u1 - u0)), dim3(256), (size_t)M * sizeof(float), s, partial.as<double>(),
                            d_off + u0, pb_b, M, gmm->has_ubm, d_sc ? d_sc + (size_t)u0 * M : nullptr,
@@ -1071,8 +1175,16 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
             SSP_HIP(hipStreamSynchronize(s));
             gmm->last_rescored = n_flag;
             if (n_flag > 0) {
+                // only the models that can still win are scored again: per listed utterance the speaker models within the band of its best
+                // split-precision difference (+ the UBM); the fp32 kernel's workgroups walk the union of their frames' lists
+                SSP_TRY(gmm->cand.reserve((size_t)n_flag * GMM_CAND * sizeof(int32_t)));
+                hipLaunchKernelGGL(gmm_candidates_kernel, dim3((unsigned)n_flag), dim3(256), 0, s, gmm->flag_list.as<int32_t>(), d_sc_work,
+                                   gmm->band.as<float>(), M, gmm->has_ubm, gmm->cand.as<int32_t>());
+                SSP_HIP(hipGetLastError());
                 gmm->sub_list_host.resize((size_t)n_flag);
+                gmm->cand_host.resize((size_t)n_flag * GMM_CAND);
                 SSP_HIP(hipMemcpyAsync(gmm->sub_list_host.data(), gmm->flag_list.p, (size_t)n_flag * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                SSP_HIP(hipMemcpyAsync(gmm->cand_host.data(), gmm->cand.p, (size_t)n_flag * GMM_CAND * sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 SSP_HIP(hipStreamSynchronize(s));
                 gmm->sub_off_host.resize((size_t)n_flag + 1);
                 gmm->sub_off_host[0] = 0;
@@ -1081,6 +1193,39 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
                     gmm->sub_off_host[(size_t)i + 1] = gmm->sub_off_host[(size_t)i] + (frame_seg->host[(size_t)u + 1] - frame_seg->host[(size_t)u]);
                 }
                 const int64_t Fs = gmm->sub_off_host.back();
+                // model list of every workgroup of the re-scoring launch (4 waves x the piece granule frames each): the sorted union of the
+                // lists of the utterances its frames belong to; -1 (every model) when one of them asks for that or the union outgrows the row
+                constexpr int BL = 48;
+                const int64_t fw = 4 * (int64_t)piece_granule(gmm, false);
+                const int64_t n_blk = (Fs + fw - 1) / fw;
+                gmm->blk_host.assign((size_t)std::max<int64_t>(n_blk, 1) * (1 + BL), 0);
+                {
+                    int32_t i0 = 0;
+                    std::vector<int32_t> un;
+                    for (int64_t b = 0; b < n_blk; ++b) {
+                        const int64_t fa = b * fw, fb = std::min(Fs, fa + fw);
+                        while (i0 < n_flag && gmm->sub_off_host[(size_t)i0 + 1] <= fa) ++i0;
+                        un.clear();
+                        bool all = false;
+                        for (int32_t i = i0; i < n_flag && gmm->sub_off_host[(size_t)i] < fb; ++i) {
+                            if (gmm->sub_off_host[(size_t)i + 1] == gmm->sub_off_host[(size_t)i]) continue;  // (an empty utterance)
+                            const int32_t* c = gmm->cand_host.data() + (size_t)i * GMM_CAND;
+                            if (c[0] < 0) all = true;
+                            else un.insert(un.end(), c + 1, c + 1 + c[0]);
+                        }
+                        std::sort(un.begin(), un.end());
+                        un.erase(std::unique(un.begin(), un.end()), un.end());
+                        int32_t* row = gmm->blk_host.data() + (size_t)b * (1 + BL);
+                        if (all || (int)un.size() > BL) {
+                            row[0] = -1;
+                        } else {
+                            row[0] = (int32_t)un.size();
+                            std::copy(un.begin(), un.end(), row + 1);
+                        }
+                    }
+                }
+                SSP_TRY(gmm->blk.reserve(gmm->blk_host.size() * sizeof(int32_t)));
+                SSP_HIP(hipMemcpyAsync(gmm->blk.p, gmm->blk_host.data(), gmm->blk_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
                 SSP_TRY(gmm->sub_off.reserve(((size_t)n_flag + 1) * sizeof(int64_t)));
                 SSP_HIP(hipMemcpyAsync(gmm->sub_off.p, gmm->sub_off_host.data(), ((size_t)n_flag + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
                 SSP_TRY(gmm->sub_feats.reserve((size_t)std::max<int64_t>(Fs, 1) * gmm->D * sizeof(float)));
@@ -1094,9 +1239,9 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
                 float* sub_sc = gmm->sub_scores.as<float>() + work_rows * M;
                 SSP_TRY(gmm->sub_argmax.reserve((size_t)n_flag * sizeof(int32_t)));
                 SSP_TRY(score_fused(gmm, gmm->sub_feats.as<float>(), gmm->sub_off_host.data(), gmm->sub_off.as<int64_t>(), n_flag, 0, false, true,
-                                    sub_sc, gmm->sub_argmax.as<int32_t>(), nullptr, s));
-                hipLaunchKernelGGL(gmm_scatter_kernel, dim3((unsigned)n_flag), dim3(256), 0, s, gmm->flag_list.as<int32_t>(), M, sub_sc,
-                                   gmm->sub_argmax.as<int32_t>(), d_sc, d_am);
+                                    sub_sc, gmm->sub_argmax.as<int32_t>(), nullptr, s, gmm->blk.as<int32_t>(), 1 + BL));
+                hipLaunchKernelGGL(gmm_scatter_cand_kernel, dim3((unsigned)n_flag), dim3(64), 0, s, gmm->flag_list.as<int32_t>(),
+                                   gmm->cand.as<int32_t>(), M, gmm->has_ubm, sub_sc, gmm->sub_argmax.as<int32_t>(), d_sc, d_am);
                 SSP_HIP(hipGetLastError());
             }
         }
