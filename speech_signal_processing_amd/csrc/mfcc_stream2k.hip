@@ -278,9 +278,11 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
                 const int k = lane + 64 * i;
                 const v2f zk = lds_read_v2f(&buf[xpad(k)]);
                 const v2f zm = lds_read_v2f(&buf[xpad((M - k) & (M - 1))]);
-                const v2f hz = zk * 0.5f;
-                const v2f e = __builtin_elementwise_fma(zm, v2f{0.5f, -0.5f}, hz);
-                const v2f d = __builtin_elementwise_fma(zm, v2f{-0.5f, 0.5f}, hz);
+                // (E' = Z[k] + conj Z[M - k] = 2 E, D' = Z[k] - conj Z[M - k] = 2 D: the halvings and the spectrum's scale are folded into
+                //  the filterbank weights — two packed additions instead of a multiplication and two FMAs per bin pair)
+                const v2f zc = v2f{zm.x, -zm.y};
+                const v2f e = zk + zc;
+                const v2f d = zk - zc;
 #ifdef SSP_2K_REGTAB
                 const v2f o = cmul_negi(d, tSreg[i]);
 #else
@@ -292,15 +294,15 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
                     p0 = __builtin_amdgcn_sqrtf(p0);
                     p1 = __builtin_amdgcn_sqrtf(p1);
                 }
-                pa[i] = p0 * a.spec_scale;
-                pb[i] = p1 * a.spec_scale;
+                pa[i] = p0;
+                pb[i] = p1;
             }
             const int2 mi0 = minfol[0], mi1 = minfol[64];
             const int mstart0 = mi0.x, mfid0 = mi0.y, mstart1 = mi1.x, mfid1 = mi1.y;
             const v2f z512 = lds_read_v2f(&buf[xpad(M / 2)]);  // (one address for the wave: a broadcast)
-            float p512 = z512.x * z512.x + z512.y * z512.y;
+            // (X[512] = conj Z[512]: against the other bins' 2 X[k] this one carries a factor 4 (power) / 2 (magnitude))
+            float p512 = 4.f * (z512.x * z512.x + z512.y * z512.y);
             if (POWER == 1) p512 = __builtin_amdgcn_sqrtf(p512);
-            p512 *= a.spec_scale;
             wave_sync2k();
             float* P = reinterpret_cast<float*>(buf);
 #pragma unroll
@@ -477,6 +479,9 @@ int build_s2k_tables(ssp_mfcc_plan* p) {
                                     {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                     {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
                                     {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    // the kernel's split step leaves 2 X[k] (its two halvings are not executed) and does not apply the spectrum's scale: both ride in the
+    // weights — (scale / 4) w on a power spectrum, (scale / 2) w on a magnitude spectrum (a filter sum is linear in its weights)
+    const float fold = (c.spec_power == 2 ? 0.25f : 0.5f) * c.spec_scale;
     int slot_clashes = 0;
     for (int g = 0; g < 2; ++g) {
         const int i0 = g * 64, i1 = std::min(c.n_filt, i0 + 64);
@@ -519,7 +524,7 @@ int build_s2k_tables(ssp_mfcc_plan* p) {
             minfo[(g * 64 + l) * 2 + 1] = cd.j;
             for (int k = 0; k < len[cd.j]; ++k) {
                 const int tap = lo[cd.j] + k - start;
-                wt[((size_t)(tap / 4) * 64 + l) * 4 + (tap & 3)] = fb[(size_t)cd.j * nb + lo[cd.j] + k];
+                wt[((size_t)(tap / 4) * 64 + l) * 4 + (tap & 3)] = fold * fb[(size_t)cd.j * nb + lo[cd.j] + k];
             }
         }
         // lanes without a filter read where another lane of their set reads (same address: a broadcast, no bank of its own)
