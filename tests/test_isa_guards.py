@@ -12,19 +12,25 @@ CSRC = os.path.join(ROOT, "speech_signal_processing_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def _isa(src, tmp_path):
+def _isa(src, tmp_path, extra=(), with_depth=False):
+    """kernel name -> instruction lines (with_depth: (loop depth from the compiler's block comments, line) pairs)"""
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
     out = str(tmp_path / (src + ".s"))
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-munsafe-fp-atomics", "-Wno-pass-failed",
-                        "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-munsafe-fp-atomics", "-Wno-pass-failed", *extra,
+                        "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    kernels, cur = {}, None
+    kernels, cur, depth = {}, None, 0
     for line in open(out):
         m = re.match(r"^(_Z\S+):", line)
         if m:
             cur = m.group(1)
             kernels[cur] = []
+            depth = 0
+            continue
+        if line.startswith(".LBB"):
+            d = re.search(r"Depth=(\d+)", line)
+            depth = int(d.group(1)) if d else 0
             continue
         t = line.strip()
         if cur is None or not t or t.startswith((";", ".")):
@@ -33,7 +39,7 @@ def _isa(src, tmp_path):
         if op == "s_endpgm":
             cur = None
             continue
-        kernels[cur].append(t)
+        kernels[cur].append((depth, t) if with_depth else t)
     return kernels
 
 
@@ -81,3 +87,30 @@ def test_dtw_cell_is_three_instructions(tmp_path):
     v = k[name[0]]
     assert _count(v, r"v_cndmask") <= 45, _count(v, r"v_cndmask")
     assert _count(v, r"v_min3_f32") >= 20
+
+
+def test_stream512_quad_loops_are_free_of_scratch(tmp_path):
+    """mfcc_stream512_kernel (benchmark instances): a spill reload inside the quad loop waits on vmcnt behind the sample DMA — its whole
+    latency, every quad (12.4 instead of 10.1 ms with 16 spilled registers once).  The headline instance <13,2,1,3,6,2,3,0> carries no
+    scratch at all; the scaling instances may reload once per CHUNK (loop depth 1), never per quad (depth >= 2).  The non-finite check of
+    a time step is ONE compare per step: at most two v_cmp against infinity per quad-loop body (main loop + drain loop)."""
+    k = _isa("mfcc_stream.hip", tmp_path, extra=("-DSSP_FAST_MINIMAL",), with_depth=True)
+    inst = {n: v for n, v in k.items() if "mfcc_stream512_kernel" in n}
+    head = [n for n in inst if "ILi13ELi2ELi1ELi3ELi6ELi2ELi3ELi0E" in n]
+    assert len(head) == 1, list(inst)
+    assert not any(t.startswith("scratch_") for _, t in inst[head[0]])
+    for n, v in inst.items():
+        deep = [t for d, t in v if d >= 2 and t.startswith("scratch_")]
+        assert not deep, (n, deep[:3])
+    assert sum(1 for d, t in inst[head[0]] if d >= 2 and re.match(r"v_cmp_(nlg|class)_f32", t)) <= 2
+
+
+def test_cosine_split_precision_tile_loop_is_free_of_scratch(tmp_path):
+    """cosine_bf16x3_kernel<16> sits exactly on the 168-register line of three waves per SIMD: what it spills must stay in the prologue /
+    epilogue (loop depth 0), the tile loop holds 48 matrix instructions per tile (16 k-steps x 3 products) and no scratch access."""
+    k = _isa("cosine.hip", tmp_path, with_depth=True)
+    name = [n for n in k if "cosine_bf16x3_kernelILi16E" in n]
+    assert len(name) == 1, list(k)
+    v = k[name[0]]
+    assert not [t for d, t in v if d >= 1 and t.startswith("scratch_")]
+    assert sum(1 for d, t in v if d >= 1 and t.startswith("v_mfma_f32_32x32x16_bf16")) == 48
