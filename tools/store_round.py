@@ -31,7 +31,7 @@ if have("kernel_stats.csv"):
 
 # ---- per-stage listings
 DOM = {"mfcc": ("mfcc_stream512_kernel", "roofline"), "ref26": ("mfcc_stream512_kernel", "mfcc_ref26_cmvn"), "inrepo": ("mfcc_stream512_kernel", "mfcc_inrepo"),
-       "librosa": ("mfcc_stream2048_kernel", "mfcc_librosa"), "gmm": ("gmm_loglik", "gmm"), "cosine": ("cosine_reg_kernel", "cosine"), "plp": ("mfcc_stream512_kernel", "plp")}
+       "librosa": ("mfcc_stream2048_kernel", "mfcc_librosa"), "gmm": ("gmm_loglik", "gmm"), "cosine": ("cosine_", "cosine"), "plp": ("mfcc_stream512_kernel", "plp")}
 for st, (kern, key) in DOM.items():
     tr = "stage_%s_kernel_trace.csv" % st
     if not have(tr):
@@ -72,6 +72,15 @@ for st, (kern, key) in DOM.items():
         v = line["gmm_bf16x3"]["roofline"]
         out.append("bench line `gmm_bf16x3.roofline`: kernel_ms %.3f -> achieved %.4g %s of peak %.4g = frac %.4f (incl. fp32 re-scoring of %d close calls)" % (
             v["kernel_ms"], v["achieved"], v["unit"], v["peak"], v["frac"], line["gmm_bf16x3"]["utterances_rescored_in_fp32"]))
+    if st == "gmm" and "gmm_bf16x3_proven_band" in line:
+        v = line["gmm_bf16x3_proven_band"]
+        out.append("bench line `gmm_bf16x3_proven_band`: kernel_ms %.3f (precision 1: the derived bound; %d utterances listed, candidates re-scored in fp32; arg-max mismatches vs fp32: %d)" % (
+            v["kernel_ms"], v["utterances_rescored_in_fp32"], v["argmax_mismatches_vs_fp32_path"]))
+    if st == "cosine" and "cosine_bf16x3" in line:
+        v = line["cosine_bf16x3"]
+        out.append("bench line `cosine_bf16x3.roofline`: kernel_ms %.3f -> achieved %.4g TFLOP/s algorithmic of peak %.4g = frac %.4f (executed: %.3f); arg-min equal to the fp32 path: %s; rows re-scored in fp32: %d" % (
+            v["roofline"]["kernel_ms"], v["roofline"]["achieved"], v["roofline"]["peak"], v["roofline"]["frac"], v["roofline"]["frac_executed"],
+            v["argmin_equals_fp32_path"], v["rows_rescored_fp32"]))
     open(os.path.join(P, "%s_stage_%s.md" % (R, st)), "w").write("\n".join(out) + "\n")
     print("stage", st, {k: round(sum(v[-5:]) / min(5, len(v)), 3) for k, v in by.items()})
 
