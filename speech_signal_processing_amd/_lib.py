@@ -84,6 +84,7 @@ SIGNATURES = {
     "ssp_cosine_identify": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, C.c_int32, _F32P, _P, _F32P, C.c_int, _MSP]),
     "ssp_cosine_identify2": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, C.c_int32, _F32P, _P, _F32P, C.c_int, C.c_int, _MSP]),
     "ssp_cosine_last_rescored": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "ssp_cosine_last_split_rows": (C.c_int, [_P, C.POINTER(C.c_int32)]),
 }
 
 _lib = None

@@ -631,7 +631,8 @@ def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True
     """dist[i,j] = clip(1 - cos(X[i], C[j]), 0, 2); argmin over j (first index on ties) — d_vector.py:315-319.
     precision 0: fp32 MFMA (parity path).  precision 1: bf16x3 MFMA sweep + fp32 re-scoring of the rows whose two best cosines are
     closer than a proven error bound — the arg-min of the fp32 path on every row, about 3x faster; no distance matrix (dist=False);
-    the result then carries "rescored" (rows that went through fp32 again)."""
+    the result then carries "rescored" (rows that went through fp32 again).  precision 2: a bf16 sweep in front (bound 4e-3), its close
+    calls to the bf16x3 sweep: same arg-min guarantee, the minimum only within 4e-3 on rows the first sweep decided."""
     xk, xp, where = _as_f32(X, "X")
     ck, cp, cwhere = _as_f32(Cn, "C")
     if cwhere != where:
@@ -653,10 +654,12 @@ def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True
         _lib.check(ctx._lib.ssp_cosine_identify2(ctx._h, xp, N, d, cp, S, p(dm), p(am), p(mv), where, int(precision),
                                                  C.byref(ms) if timing else None))
     res = {}
-    if precision == 1:
+    if precision >= 1:
         n = C.c_int32(0)
         _lib.check(ctx._lib.ssp_cosine_last_rescored(ctx._h, C.byref(n)))
         res["rescored"] = n.value
+        _lib.check(ctx._lib.ssp_cosine_last_split_rows(ctx._h, C.byref(n)))
+        res["split_rows"] = n.value   # precision 2: rows the bf16 sweep handed to the bf16x3 sweep
     if dist:
         res["dist"] = dm
     if argmin:

@@ -119,7 +119,8 @@ struct ssp_ctx {
     void* comm = nullptr;
     int comm_rank = 0, comm_size = 1;
     hipEvent_t order_ev[2] = {nullptr, nullptr};  // ssp_ctx_wait_stream / ssp_ctx_signal_stream
-    int32_t cos_last_rescored = 0;  // rows the last ssp_cosine_identify2(precision = 1) call scored again in fp32
+    int32_t cos_last_rescored = 0;  // rows the last ssp_cosine_identify2(precision >= 1) call scored again in fp32
+    int32_t cos_last_split = 0;     // ... rows its precision-2 cascade handed from the bf16 sweep to the bf16x3 sweep
 };
 
 struct ssp_segments {

@@ -491,22 +491,32 @@ struct Cos16Args {
     const __bf16* img;
     int32_t* argmin;
     float* minval;
-    int32_t* list;         // rows to score again in fp32
-    int32_t* count;        // [0] how many; [1] centroid flag (cos_pack16_kernel)
+    int32_t* list;         // rows the NEXT stage scores again
+    int32_t* count;        // [0] how many
+    const int32_t* cflag;  // [0] != 0: a centroid's norm is not a finite positive number (cos_pack16_kernel): every row goes on the list
     int64_t N;
     int32_t d, S, n_tiles;
-    float band2;           // twice the bound on |cos(bf16 x 3) - cos(fp32 path)|
+    float band2;           // twice the bound on |cos(this sweep) - cos(fp32 path)|
+    // later stages of a cascade: the embeddings are X[rows[i]], i < *n_dev (device-side count of the previous stage's list)
+    const int32_t* rows;
+    const int32_t* n_dev;
 };
 
-template <int NK>  // k-steps of 16: d <= 16 NK
+// SPLIT = 3: hi + lo operands, three products per k-step (error 1.3e-4 at d = 256); SPLIT = 1: the hi parts alone, one product per k-step
+// (error 4e-3): the first sweep of the cascade (ssp_cosine_identify2 precision 2), whose close calls the SPLIT = 3 sweep takes over
+template <int NK, int SPLIT>  // k-steps of 16: d <= 16 NK
 __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int HALF_BYTES = (NK / 2) * 2048;  // a k-half of a 32-row tile: NK/2 k-steps x (hi + lo) x 1 KiB
+    constexpr int PARTS = SPLIT == 1 ? 1 : 2;
+    constexpr int HALF_BYTES = (NK / 2) * PARTS * 1024;  // a k-half of a 32-row tile in LDS: NK/2 k-steps x (hi [+ lo]) x 1 KiB
+    constexpr int HALF_SRC = (NK / 2) * 2048;            // ... in the image (always hi + lo)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 31, h = lane >> 5;
     const int d = a.d;
     const int64_t col0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t Nn = a.n_dev ? (int64_t)*a.n_dev : a.N;
+    if ((int64_t)blockIdx.x * 128 >= Nn) return;  // (whole workgroup: before any barrier)
 
     // ---- B operand: lane (embedding fl, half h) holds x_hat[col][16 ks + 8 h + j] as hi / lo fragments.  The rows come through LDS in
     //      64-wide k chunks (coalesced HBM reads), first as fp32 (the norm needs all of a row), then split in place.
@@ -522,8 +532,8 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
                 const int idx = lane + 64 * u, r = idx >> 4, k = kc * 64 + 4 * (idx & 15);
                 const int64_t gc = col0 + r;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gc < a.N) {
-                    const float* __restrict__ p = a.X + gc * d + k;
+                if (gc < Nn) {
+                    const float* __restrict__ p = a.X + (a.rows ? (int64_t)a.rows[gc] : gc) * d + k;
                     if (k + 3 < d) {
                         const f4u t4 = *reinterpret_cast<const f4u*>(p);
                         v[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
@@ -560,7 +570,7 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
     }
     ss += __shfl_xor(ss, 32);
     const float ix = 1.0f / sqrtf(ss);
-    bf16x8 bh[NK], bl[NK];
+    bf16x8 bh[NK], bl[SPLIT == 1 ? 1 : NK];
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks)
 #pragma unroll
@@ -568,19 +578,21 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
             const float v = bx[ks][j] * ix;
             const __bf16 hi = (__bf16)v;
             bh[ks][j] = hi;
-            bl[ks][j] = (__bf16)(v - (float)hi);
+            if (SPLIT != 1) bl[SPLIT == 1 ? 0 : ks][j] = (__bf16)(v - (float)hi);
         }
     __syncthreads();  // the staging area is about to be overwritten by tile 0
 
     // centroid tiles stream through a ring of THREE half-tile slots, as in cosine_reg_kernel
     const int n_steps = 2 * a.n_tiles;
     auto stage = [&](int step, int slot) {
-        const char* src = reinterpret_cast<const char*>(a.img) + (size_t)step * HALF_BYTES;
+        const char* src = reinterpret_cast<const char*>(a.img) + (size_t)step * HALF_SRC;
         char* dst = smem + slot * HALF_BYTES;
+        constexpr int NP = (NK / 2) * PARTS;  // 1-KiB pieces per half (SPLIT = 1: the hi pieces only — every other piece of the image)
 #pragma unroll
-        for (int p = 0; p < (NK + 3) / 4; ++p) {
-            const int piece = wave + 4 * p;  // NK 1-KiB pieces per half
-            if (piece < NK) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + piece * 1024 + lane * 16), (lds_ptr_t)(dst + piece * 1024), 16, 0, 0);
+        for (int p = 0; p < (NP + 3) / 4; ++p) {
+            const int piece = wave + 4 * p;
+            if (piece < NP)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + piece * (SPLIT == 1 ? 2048 : 1024) + lane * 16), (lds_ptr_t)(dst + piece * 1024), 16, 0, 0);
         }
     };
     stage(0, 0);
@@ -591,19 +603,27 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
     // would otherwise sit between every triple: the reads are what the matrix pipe waits for)
     auto half_sweep = [&](const char* wcur, int k0, f32x16& acc) {
         const char* wl = wcur + lane * 16;
-        bf16x8 ah = *reinterpret_cast<const bf16x8*>(wl), al = *reinterpret_cast<const bf16x8*>(wl + 1024);
+        if constexpr (SPLIT == 1) {
 #pragma unroll
-        for (int ks = 0; ks < NK / 2; ++ks) {
-            bf16x8 nh = ah, nl = al;
-            if (ks + 1 < NK / 2) {
-                nh = *reinterpret_cast<const bf16x8*>(wl + (ks + 1) * 2048);
-                nl = *reinterpret_cast<const bf16x8*>(wl + (ks + 1) * 2048 + 1024);
+            for (int ks = 0; ks < NK / 2; ++ks) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(wl + ks * 1024);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[k0 + ks], acc, 0, 0, 0);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[k0 + ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[k0 + ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[k0 + ks], acc, 0, 0, 0);
-            ah = nh;
-            al = nl;
+        } else {
+            bf16x8 ah = *reinterpret_cast<const bf16x8*>(wl), al = *reinterpret_cast<const bf16x8*>(wl + 1024);
+#pragma unroll
+            for (int ks = 0; ks < NK / 2; ++ks) {
+                bf16x8 nh = ah, nl = al;
+                if (ks + 1 < NK / 2) {
+                    nh = *reinterpret_cast<const bf16x8*>(wl + (ks + 1) * 2048);
+                    nl = *reinterpret_cast<const bf16x8*>(wl + (ks + 1) * 2048 + 1024);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[k0 + ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[SPLIT == 1 ? 0 : k0 + ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[k0 + ks], acc, 0, 0, 0);
+                ah = nh;
+                al = nl;
+            }
         }
     };
     float b1 = -INFINITY, b2 = -INFINITY;  // the two largest cosines of this lane's rows (b1: the first row that reaches it)
@@ -648,34 +668,45 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
         bad = bad || ob;
     }
     const int64_t gc = col0 + fl;
-    const bool mine = h == 0 && gc < a.N;
-    // close calls (and anything that is not a number: a zero-norm embedding, a NaN centroid) are scored again in fp32; with a single
-    // centroid there is nothing to confuse
-    const bool again = mine && (bad || a.count[1] != 0 || !(ix > 0.f && ix < INFINITY) || (a.S > 1 && !(b1 - b2 >= a.band2)));
+    const bool mine = h == 0 && gc < Nn;
+    const int64_t go = (a.rows && gc < Nn) ? (int64_t)a.rows[gc] : gc;  // the row this lane's embedding is
+    // close calls (and anything that is not a number: a zero-norm embedding, a NaN centroid) are scored again by the next stage; with a
+    // single centroid there is nothing to confuse
+    const bool again = mine && (bad || a.cflag[0] != 0 || !(ix > 0.f && ix < INFINITY) || (a.S > 1 && !(b1 - b2 >= a.band2)));
     const unsigned long long m = __builtin_amdgcn_ballot_w64(again);
     if (m != 0) {
         int base = 0;
         if (lane == 0) base = atomicAdd(a.count, __popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (again) a.list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)gc;
+        if (again) a.list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)go;
     }
     if (mine && !again) {
-        if (a.argmin) a.argmin[gc] = i1;
-        if (a.minval) a.minval[gc] = fminf(fmaxf(1.0f - b1, 0.0f), 2.0f);
+        if (a.argmin) a.argmin[go] = i1;
+        if (a.minval) a.minval[go] = fminf(fmaxf(1.0f - b1, 0.0f), 2.0f);
     }
 }
 
-template <int NK>
+template <int NK, int SPLIT>
 static int launch_cos16(const Cos16Args& a, hipStream_t s) {
-    const size_t ring = (size_t)3 * (NK / 2) * 2048, xst = (size_t)4 * 32 * 65 * 4;
+    const size_t ring = (size_t)3 * (NK / 2) * (SPLIT == 1 ? 1024 : 2048), xst = (size_t)4 * 32 * 65 * 4;
     const size_t lds = ring > xst ? ring : xst;
     const int64_t grid = ceil_div<int64_t>(a.N, 128);
     if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
     if (lds > 64 * 1024)
-        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_bf16x3_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((cosine_bf16x3_kernel<NK>), dim3((unsigned)grid), dim3(256), lds, s, a);
+        SSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_bf16x3_kernel<NK, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((cosine_bf16x3_kernel<NK, SPLIT>), dim3((unsigned)grid), dim3(256), lds, s, a);
     SSP_HIP(hipGetLastError());
     return SSP_OK;
+}
+
+template <int SPLIT>
+static int launch_cos16_nk(int nk, const Cos16Args& a, hipStream_t s) {
+    switch (nk) {
+        case 4: return launch_cos16<4, SPLIT>(a, s);
+        case 8: return launch_cos16<8, SPLIT>(a, s);
+        case 12: return launch_cos16<12, SPLIT>(a, s);
+        default: return launch_cos16<16, SPLIT>(a, s);
+    }
 }
 
 // bound on |cos(bf16 x 3) - cos(fp32 path)| for unit vectors of dimension d.  x = hi + lo + r with |x - hi| <= 2^-9 |x| and
@@ -684,6 +715,9 @@ static int launch_cos16(const Cos16Args& a, hipStream_t s) {
 // accumulation of 3 d terms whose absolute sum is <= 1 + 2^-7 rounds (or truncates: the matrix core's internal order is not documented, so
 // the bound assumes the worst, 2^-23 per term) at most 3 d 2^-23 in total; the fp32 path's own sweep over d terms at most d 2^-23.
 static float cos_band(int d) { return 3.01f * 0x1p-18f + 4.0f * (float)d * 0x1p-23f * 1.01f; }
+// ... of the hi parts alone: x = hi + r, |r| <= 2^-9 |x|, |hi| <= (1 + 2^-9) |x|: what hi.hi' leaves out is at most
+// (2 2^-9 (1 + 2^-9) + 2^-18) sum |x_k| |c_k| <= 2.01 2^-9; d exact products accumulated (2^-23 each, worst case) + the fp32 path's d
+static float cos_band1(int d) { return 2.01f * 0x1p-9f + 2.0f * (float)d * 0x1p-23f * 1.01f; }
 
 // d_vector.py:310-313 — one workgroup per speaker, rows summed IN ROW ORDER into a float64 accumulator (fixed summation order, like
 // numpy's mean on the reference's float64 `avg`).  The label array is scanned 2048 rows at a time with independent coalesced loads;
@@ -829,15 +863,23 @@ int ssp_cosine_last_rescored(const ssp_ctx* ctx, int32_t* n_out) {
     return SSP_OK;
 }
 
+int ssp_cosine_last_split_rows(const ssp_ctx* ctx, int32_t* n_out) {
+    if (!ctx || !n_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_last_split_rows: null");
+    *n_out = ctx->cos_last_split;
+    return SSP_OK;
+}
+
 int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,
                          int32_t* argmin_out, float* min_out, int where, int precision, float* kernel_ms) {
     ssp::TraceRange trace_("ssp_cosine_identify");
     SSP_TRY(use_ctx(ctx));
     if (N < 0 || d < 1 || S < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: bad shape N=%lld d=%d S=%d", (long long)N, d, S);
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: where");
-    if (precision < 0 || precision > 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: precision must be 0 (fp32 MFMA) or 1 (bf16x3 MFMA + fp32 re-scoring of close calls)");
-    if (precision == 1 && (dist_out || d > 256))
-        SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_cosine_identify: precision 1 gives the arg-min / minimum only (dist_out must be NULL) for d <= 256");
+    if (precision < 0 || precision > 2)
+        SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: precision must be 0 (fp32 MFMA), 1 (bf16x3 MFMA + fp32 re-scoring of close calls) or 2 (bf16 sweep, "
+                                  "then bf16x3, then fp32 on the respective close calls)");
+    if (precision >= 1 && (dist_out || d > 256))
+        SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_cosine_identify: precision 1 / 2 give the arg-min / minimum only (dist_out must be NULL) for d <= 256");
     if (kernel_ms) *kernel_ms = 0.f;
     if (N == 0) return SSP_OK;
     if (!X || !C) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: null input");
@@ -857,34 +899,39 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
     SSP_TRY(rc);
     DevBuf inc, img;
     Timer tm;
-    ctx->cos_last_rescored = 0;
-    if (precision == 1) {
-        // bf16 x 3 sweep with the two best cosines per embedding, then the fp32 kernel on the rows whose call is closer than the error
-        // bound (a device-side list and count: nothing comes back to the host in between)
+    ctx->cos_last_rescored = ctx->cos_last_split = 0;
+    if (precision >= 1) {
+        // split-precision sweep(s) keeping the two best cosines per embedding, then the fp32 kernel on the rows whose call is closer than
+        // the error bound — device-side lists and counts: nothing comes back to the host in between.  precision 2 puts a hi-parts-only
+        // sweep (one MFMA per k-step, bound 4e-3) in front: its close calls go to the bf16 x 3 sweep, that one's to fp32
         const int nk = d <= 64 ? 4 : (d <= 128 ? 8 : (d <= 192 ? 12 : 16)), nq = 2 * nk;
         const int n_tiles = (S + 31) / 32;
-        DevBuf img16, list, count;
+        DevBuf img16, list1, list2, count;
         SSP_TRY(img16.alloc((size_t)n_tiles * nk * 2048));
         SSP_TRY(img.alloc((size_t)n_tiles * nq * 256 * sizeof(float)));
-        SSP_TRY(list.alloc((size_t)N * sizeof(int32_t)));
-        SSP_TRY(count.alloc(2 * sizeof(int32_t)));
-        int32_t* dA2 = dA;
-        float* dM2 = dM;
-        Cos16Args ca{dX, img16.as<__bf16>(), dA2, dM2, list.as<int32_t>(), count.as<int32_t>(), N, d, S, n_tiles, 2.0f * cos_band(d)};
-        CosRegArgs ra{dX, img.as<float>(), nullptr, 0, nullptr, dA2, dM2, N, d, S, n_tiles};
-        ra.rows = list.as<int32_t>();
-        ra.n_dev = count.as<int32_t>();
+        SSP_TRY(list2.alloc((size_t)N * sizeof(int32_t)));
+        if (precision == 2) SSP_TRY(list1.alloc((size_t)N * sizeof(int32_t)));
+        SSP_TRY(count.alloc(4 * sizeof(int32_t)));  // [0] rows for the bf16 x 3 sweep (precision 2), [1] rows for fp32, [2] centroid flag
+        int32_t* cnt = count.as<int32_t>();
+        Cos16Args c3{dX, img16.as<__bf16>(), dA, dM, list2.as<int32_t>(), cnt + 1, cnt + 2, N, d, S, n_tiles, 2.0f * cos_band(d), nullptr, nullptr};
+        CosRegArgs ra{dX, img.as<float>(), nullptr, 0, nullptr, dA, dM, N, d, S, n_tiles};
+        ra.rows = list2.as<int32_t>();
+        ra.n_dev = cnt + 1;
         SSP_TRY(tm.start(kernel_ms != nullptr, s));
-        SSP_HIP(hipMemsetAsync(count.p, 0, 2 * sizeof(int32_t), s));
-        hipLaunchKernelGGL(cos_pack16_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nk, img16.as<__bf16>(), count.as<int32_t>() + 1);
+        SSP_HIP(hipMemsetAsync(count.p, 0, 4 * sizeof(int32_t), s));
+        hipLaunchKernelGGL(cos_pack16_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nk, img16.as<__bf16>(), cnt + 2);
         hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>(), 1);
         SSP_HIP(hipGetLastError());
-        switch (nk) {
-            case 4: SSP_TRY(launch_cos16<4>(ca, s)); break;
-            case 8: SSP_TRY(launch_cos16<8>(ca, s)); break;
-            case 12: SSP_TRY(launch_cos16<12>(ca, s)); break;
-            default: SSP_TRY(launch_cos16<16>(ca, s)); break;
+        if (precision == 2) {
+            Cos16Args c1 = c3;
+            c1.list = list1.as<int32_t>();
+            c1.count = cnt;
+            c1.band2 = 2.0f * cos_band1(d);
+            SSP_TRY(launch_cos16_nk<1>(nk, c1, s));
+            c3.rows = list1.as<int32_t>();
+            c3.n_dev = cnt;
         }
+        SSP_TRY(launch_cos16_nk<3>(nk, c3, s));
         switch (nq) {
             case 8: SSP_TRY(launch_cos_reg<8>(ra, s)); break;
             case 16: SSP_TRY(launch_cos_reg<16>(ra, s)); break;
@@ -894,8 +941,11 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
         SSP_TRY(tm.stop(s, kernel_ms));
         SSP_TRY(sa.back(ctx, argmin_out, (size_t)N * sizeof(int32_t), where));
         SSP_TRY(sm.back(ctx, min_out, (size_t)N * sizeof(float), where));
-        SSP_HIP(hipMemcpyAsync(&ctx->cos_last_rescored, count.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        SSP_HIP(hipStreamSynchronize(s));  // the images / list are freed at return
+        int32_t hc[2] = {0, 0};
+        SSP_HIP(hipMemcpyAsync(hc, count.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SSP_HIP(hipStreamSynchronize(s));  // the images / lists are freed at return
+        ctx->cos_last_split = hc[0];
+        ctx->cos_last_rescored = hc[1];
         return SSP_OK;
     }
     if (d <= 256) {  // register-resident embeddings, LDS-DMA streamed centroid tiles

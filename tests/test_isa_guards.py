@@ -106,10 +106,10 @@ def test_stream512_quad_loops_are_free_of_scratch(tmp_path):
 
 
 def test_cosine_split_precision_tile_loop_is_free_of_scratch(tmp_path):
-    """cosine_bf16x3_kernel<16> sits exactly on the 168-register line of three waves per SIMD: what it spills must stay in the prologue /
+    """cosine_bf16x3_kernel<16, 3> sits exactly on the 168-register line of three waves per SIMD: what it spills must stay in the prologue /
     epilogue (loop depth 0), the tile loop holds 48 matrix instructions per tile (16 k-steps x 3 products) and no scratch access."""
     k = _isa("cosine.hip", tmp_path, with_depth=True)
-    name = [n for n in k if "cosine_bf16x3_kernelILi16E" in n]
+    name = [n for n in k if "cosine_bf16x3_kernelILi16ELi3E" in n]
     assert len(name) == 1, list(k)
     v = k[name[0]]
     assert not [t for d, t in v if d >= 1 and t.startswith("scratch_")]
