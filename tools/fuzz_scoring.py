@@ -36,6 +36,17 @@ for case in range(n_cases):
                 continue
             refs = np.array([O.gmm_score(w[m], mu[m], cov[m], X[off[u]:off[u + 1]]) for m in range(M)])
             assert np.allclose(np.asarray(r["scores"])[u], refs, rtol=2e-4, atol=2e-4), (case, "score", u, prec)
+    # ---- the split-precision modes keep the fp32 path's arg-max (proven band: precision 1; calibrated band: 3), speakers a hair apart
+    if D <= 64 and M - int(has_ubm) >= 2 and sum(lens) > 0:
+        mu2 = mu.copy()
+        for m in range(int(has_ubm) + 1, M):
+            mu2[m] = mu2[int(has_ubm)] * (1.0 + 10.0 ** rng.uniform(-7, -2) * rng.standard_normal((K, D)))
+        sc2 = api.GmmScorer(ctx, np.repeat(w[:1], M, 0), mu2, np.repeat(cov[:1], M, 0), has_ubm=has_ubm)
+        a0 = np.asarray(sc2.score(X, seg, precision=0)["argmax"])
+        for prec in (1, 3):
+            a1 = np.asarray(sc2.score(X, seg, precision=prec)["argmax"])
+            nz = np.array(lens) > 0
+            assert np.array_equal(a0[nz], a1[nz]), (case, "gmm split-precision arg-max", prec, K, D, M)
     # ---- cosine
     N, S, d = int(rng.choice([1, 31, 32, 33, 500])), int(rng.choice([1, 2, 31, 32, 33, 129, 300])), int(rng.choice([1, 3, 64, 128, 255, 256, 257, 512]))
     if verbose:
@@ -50,6 +61,13 @@ for case in range(n_cases):
     srt = np.sort(refd, axis=1)
     clear = (srt[:, 1] - srt[:, 0] > 1e-5) if S > 1 else np.ones(N, bool)
     assert (am[clear] == refd.argmin(1)[clear]).all(), (case, "argmin")
+    if d <= 256:  # split precision (bf16x3; the cascade with a bf16 sweep in front): the fp32 path's arg-min on every row, close calls included
+        Cc = Cn.copy()
+        if S >= 2:
+            Cc[1::2] = Cc[0::2][: len(Cc[1::2])] * (1.0 + 10.0 ** rng.uniform(-8, -2) * rng.standard_normal(Cc[1::2].shape).astype(np.float32))
+        a0 = np.asarray(api.cosine_identify(ctx, Xc, Cc)["argmin"])
+        for prec in (1, 2):
+            assert np.array_equal(a0, np.asarray(api.cosine_identify(ctx, Xc, Cc, precision=prec)["argmin"])), (case, "cosine split-precision arg-min", prec, N, S, d)
     # ---- dense
     Nn, di, un = int(rng.choice([1, 5, 127, 128, 129, 300])), int(rng.choice([1, 2, 31, 32, 33, 100, 1274])), int(rng.choice([1, 3, 127, 128, 129, 256]))
     if verbose:
