@@ -28,8 +28,12 @@ v = d["gmm"]
 rows.append(("GMM-UBM scoring, 51 models × 64 mixtures × 39-d, fp32 MFMA (parity path), one launch, per-utterance means fused; 12-byte decision records gathered",
              "%.3g frame-scores/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
 v = d["gmm_bf16x3"]
-rows.append(("same, bf16×3 split-precision MFMA + fp32 re-scoring of close calls (%d of %d; arg-max mismatches against fp32: %d)" % (v["utterances_rescored_in_fp32"], v["utterances"], v["argmax_mismatches_vs_fp32_path"]),
+rows.append(("same, bf16×3 split-precision MFMA + fp32 re-scoring of the close calls' candidate models, calibrated (heuristic) band (%d of %d listed; arg-max mismatches against fp32: %d)" % (v["utterances_rescored_in_fp32"], v["utterances"], v["argmax_mismatches_vs_fp32_path"]),
              "%.2g frame-scores/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of the dense bf16 peak on algorithmic FLOPs" % v["roofline"]["frac"]))
+if "gmm_bf16x3_proven_band" in d:
+    v = d["gmm_bf16x3_proven_band"]
+    rows.append(("same with the PROVEN error bound as the band (`ssp_gmm_score` precision 1: %d of %d listed; arg-max mismatches against fp32: %d)" % (v["utterances_rescored_in_fp32"], v["utterances"], v["argmax_mismatches_vs_fp32_path"]),
+                 "%.2g frame-scores/s (%.1f ms)" % (v["value"], v["kernel_ms"]), "%.2f of the dense bf16 peak on algorithmic FLOPs" % v["roofline"]["frac"]))
 c3 = d["gmm_cfg3_shape"]
 fs = c3.get("bf16x3_full_share")
 rows.append(("configs[3] model shape (K = 512, 1251 speakers + UBM): 12 000 utterances per GPU fp32 / bf16×3" + ("; the FULL per-GPU share (150 000 utterances) on bf16×3, measured" if fs else ""),
@@ -39,7 +43,13 @@ rows.append(("configs[3] model shape (K = 512, 1251 speakers + UBM): 12 000 utte
 v = d["gmm_em"]
 rows.append(("GMM EM training (E step + M sums per iteration), 3e6 frames × 64 mix × 39-d", "%.2f ms per iteration" % v["kernel_ms"], "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
 v = d["cosine"]
-rows.append(("cosine scoring, 1e6 × 1251 × 256", "%.2g pair-scores/s" % v["value"], "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
+rows.append(("cosine scoring, 1e6 × 1251 × 256, fp32 MFMA (parity path)", "%.2g pair-scores/s (%.2f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
+if "cosine_bf16x3" in d:
+    v, c = d["cosine_bf16x3"], d.get("cosine_bf16_cascade")
+    rows.append(("same, arg-min only: bf16×3 sweep keeping the two best cosines + fp32 re-scoring inside a proven band from a device-side list (arg-min equal to fp32 on all rows: %s)" % v["argmin_equals_fp32_path"]
+                 + ("; the cascade with a bf16 sweep in front (equal: %s; rows to later stages: %d / %d — well-separated synthetic embeddings)" % (c["argmin_equals_fp32_path"], c["rows_to_bf16x3"], c["rows_rescored_fp32"]) if c else ""),
+                 "%.2g pair-scores/s (%.2f ms)" % (v["value"], v["roofline"]["kernel_ms"]) + ("; %.2g (%.2f ms)" % (c["value"], c["roofline"]["kernel_ms"]) if c else ""),
+                 "%.2f of the dense bf16 peak executed (%.2f algorithmic)" % (v["roofline"]["frac_executed"], v["roofline"]["frac"]) + ("; cascade %.2f algorithmic" % c["roofline"]["frac"] if c else "")))
 v = d["dvector_dnn"]
 rows.append(("d-vector network forward 1274→256×4 (one packed object, hidden layers chained in registers), 5e5 embeddings", "%.2g embeddings/s (%.1f ms)" % (v["value"], v["kernel_ms"]), "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
 v = d["dvector_pipeline"]
