@@ -762,22 +762,28 @@ def main():
         Ce = torch.randn((1251, 256), generator=gen, device=device)
         f13 = torch.empty((fseg13.total, 13), dtype=torch.float32, device=device)
 
-        def run_e2e():
+        def run_e2e(cos_precision=0):
             plan13.run(chunks.reshape(-1), seg13, fseg13, out=f13)
             h = net_e.forward(f13.view(n_ch, 98 * 13))
-            return api.cosine_identify(ctx, h, Ce, minval=False)["argmin"]
-        run_e2e()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ids = run_e2e()
-        torch.cuda.synchronize()
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t0, device)
+            return api.cosine_identify(ctx, h, Ce, minval=False, precision=cos_precision)["argmin"]
+
+        def timed(cos_precision):
+            run_e2e(cos_precision)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = run_e2e(cos_precision)
+            torch.cuda.synchronize()
+            barrier()
+            return out, max_over_ranks(time.perf_counter() - t0, device)
+        ids, dt = timed(0)
+        ids2, dt2 = timed(2)   # the same with the cosine stage as the split-precision cascade (same indices, proven)
         result["dvector_pipeline"] = {"metric": "d-vector recogniser end to end: 1 s chunks -> MFCC 98x13 -> Dense 1274-256x4 -> cosine vs 1251 -> arg-min",
                                       "value": n_ch * world / dt, "unit": "chunks/s", "chunks_per_gpu": n_ch, "ms": dt * 1e3,
-                                      "audio_seconds_per_second": n_ch * world / dt, "dtype": "f32", "ids_checksum": int(ids.long().sum().item())}
-        del chunks, f13, ids
+                                      "audio_seconds_per_second": n_ch * world / dt, "dtype": "f32", "ids_checksum": int(ids.long().sum().item()),
+                                      "with_cosine_cascade": {"value": n_ch * world / dt2, "unit": "chunks/s", "ms": dt2 * 1e3,
+                                                              "ids_equal": bool((ids == ids2).all().item())}}
+        del chunks, f13, ids, ids2
     if "dtw" in stages:
         rng = np.random.default_rng(13)
         nq, nt, L = 128, 64, 1222
