@@ -302,7 +302,7 @@ int main(int argc, char** argv) {
         const double sec = atof(argv[4]);
         switch (op) {
 #define P(O) case O: return power<O>(ncu, d_spans, d_sink, wps, sec);
-            P(SNOP) P(VMOV) P(FMA) P(PKFMA) P(PKADD) P(PKMUL) P(ADD) P(DPPMOV) P(LOGF) P(DSR32) P(DSR64) P(DSR128) P(DSW32) P(DSW64) P(BPERM) P(MFMA16) P(MFMA16_PK4) P(MFMA32BF) P(MFMA32BF_PK4) P(CVTBF) P(PERM32) P(SPLIT2)
+            P(SNOP) P(VMOV) P(FMA) P(PKFMA) P(PKADD) P(PKMUL) P(ADD) P(DPPMOV) P(LOGF) P(DSR32) P(DSR64) P(DSR128) P(DSW32) P(DSW64) P(BPERM) P(MFMA16) P(MFMA16_PK4) P(MFMA4) P(MFMA4_V2) P(MFMA32BF) P(MFMA32BF_PK4) P(CVTBF) P(PERM32) P(SPLIT2)
 #undef P
             default: printf("op %d not in the power list\n", op); return 1;
         }
