@@ -13,6 +13,17 @@
 
 namespace ssp {
 
+// numpy.maximum / ndarray.max(): a NaN on either side is the result (fmaxf returns the other operand).  The librosa dialect's floor
+// max(amin, S) and its top_db clamp max(S_db, S_db.max() - top_db) (MFCC_DTW.py:28-31 through librosa.power_to_db) are such maxima: one
+// NaN sample makes the whole utterance's features NaN there, and the kernels must not hand back finite numbers instead.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float nanmax(float a, float b) {
+    const float r = fmaxf(a, b);
+    return (a != a || b != b) ? __builtin_nanf("") : r;
+}
+#endif
+
+
 void set_error(const char* fmt, ...);
 
 #define SSP_FAIL(code, ...)            \

@@ -124,4 +124,14 @@ __device__ __forceinline__ void fft_small(v2f (&z)[R]) {
     }
 }
 
+// sample pair x window pair where a ZERO weight silences whatever the sample holds (v_mul_legacy_f32: 0 . x = 0 for NaN and inf too).
+// The 512-point kernels read whole 32-sample rows: the window's last row runs past its last tap into the samples behind the frame,
+// and a NaN there (a corrupt recording) must not reach a frame it does not belong to — in the reference's arithmetic it does not.
+__device__ __forceinline__ v2f wmul_edge(v2f y, v2f w) {
+    float r0, r1;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r0) : "v"(y.x), "v"(w.x));
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r1) : "v"(y.y), "v"(w.y));
+    return v2f{r0, r1};
+}
+
 }  // namespace ssp

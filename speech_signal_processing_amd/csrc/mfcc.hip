@@ -96,7 +96,7 @@ __device__ __forceinline__ float frame_sample(const MfccArgs& a, const float* __
 
 __device__ __forceinline__ float apply_log(const MfccArgs& a, float v) {
     if (a.floor_mode == 1) v += a.eps;
-    else if (a.floor_mode == 2) v = fmaxf(v, a.eps);
+    else if (a.floor_mode == 2) v = nanmax(v, a.eps);  // (numpy.maximum: a NaN stays a NaN)
     if (a.log_mode == 0) return logf(v);
     if (a.log_mode == 1) return log10f(v);
     return 10.0f * log10f(v);
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
                     lm[j] = v;
                     if (a.lm_out && t >= t0 && t < t0 + n) {
                         a.lm_out[(size_t)(f0 + t) * a.n_filt + j] = v;
-                        wave_max = fmaxf(wave_max, v);
+                        wave_max = nanmax(wave_max, v);
                     }
                 }
             }
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
                 lm[fi] = v;
                 if (a.lm_out && t >= t0 && t < t0 + n) {
                     a.lm_out[(size_t)(f0 + t) * a.n_filt + fi] = v;
-                    wave_max = fmaxf(wave_max, v);
+                    wave_max = nanmax(wave_max, v);
                 }
             }
         };
@@ -408,9 +408,12 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
     __syncthreads();
     GSTAMP(6)
     if (a.lm_out) {  // utterance maximum for the second pass: one atomic per wave (float order through the integer trick)
-        for (int o = 32; o > 0; o >>= 1) wave_max = fmaxf(wave_max, __shfl_xor(wave_max, o));
-        if (lane == 0 && wave_max > -INFINITY) {
-            if (wave_max >= 0.f) atomicMax(reinterpret_cast<int*>(a.utt_max + ch.utt), __float_as_int(wave_max));
+        for (int o = 32; o > 0; o >>= 1) wave_max = nanmax(wave_max, __shfl_xor(wave_max, o));
+        if (lane == 0 && (wave_max > -INFINITY || wave_max != wave_max)) {
+            // (a NaN maximum sticks: its canonical bits 0x7fc00000 are below every negative float's as unsigned and above every positive
+            //  float's as int, so whichever atomic a later chunk uses leaves it in place)
+            if (wave_max != wave_max) atomicExch(reinterpret_cast<unsigned*>(a.utt_max + ch.utt), 0x7fc00000u);
+            else if (wave_max >= 0.f) atomicMax(reinterpret_cast<int*>(a.utt_max + ch.utt), __float_as_int(wave_max));
             else atomicMin(reinterpret_cast<unsigned*>(a.utt_max + ch.utt), __float_as_uint(wave_max));
         }
         return;
@@ -421,14 +424,14 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
         const int rows = tb - ta;
         for (int i = tid; i < rows * a.n_filt; i += nt) {
             const int r = i / a.n_filt;
-            mx = fmaxf(mx, lmrows[(size_t)r * a.lm_stride + (i - r * a.n_filt)]);
+            mx = nanmax(mx, lmrows[(size_t)r * a.lm_stride + (i - r * a.n_filt)]);
         }
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        for (int o = 32; o > 0; o >>= 1) mx = nanmax(mx, __shfl_xor(mx, o));
         float* red = stats + 2 * a.d_out;
         if (lane == 0) red[wave] = mx;
         __syncthreads();
         float thr = red[0];
-        for (int w = 1; w < nw; ++w) thr = fmaxf(thr, red[w]);
+        for (int w = 1; w < nw; ++w) thr = nanmax(thr, red[w]);
         thr -= a.top_db;
         // consecutive lanes take consecutive rows (stride 4 x odd floats: conflict-free 16-byte reads) of two coefficients, whose
         // DCT rows are broadcast reads
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
                 v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 for (int j = 0; j < n_filt4; j += 4) {
                     v4f l = *reinterpret_cast<const v4f*>(lm + j);
-                    l = v4f{fmaxf(l.x, thr), fmaxf(l.y, thr), fmaxf(l.z, thr), fmaxf(l.w, thr)};
+                    l = v4f{nanmax(l.x, thr), nanmax(l.y, thr), nanmax(l.z, thr), nanmax(l.w, thr)};
                     acc0 = __builtin_elementwise_fma(l, *reinterpret_cast<const v4f*>(d0 + j), acc0);
                     acc1 = __builtin_elementwise_fma(l, *reinterpret_cast<const v4f*>(d1 + j), acc1);
                 }
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(512) void mfcc_generic_kernel(MfccArgs a) {
                 const int q = i / rows, r = i - q * rows;
                 const float* lm = lmrows + (size_t)r * a.lm_stride;
                 float acc = 0.f;
-                for (int j = 0; j < a.n_filt; ++j) acc = fmaf(fmaxf(lm[j], thr), tbl[j * nc + q], acc);
+                for (int j = 0; j < a.n_filt; ++j) acc = fmaf(nanmax(lm[j], thr), tbl[j * nc + q], acc);
                 ceps[(size_t)r * nc + q] = acc;
             }
         };
@@ -564,18 +567,18 @@ __global__ __launch_bounds__(256) void topdb_dct_kernel(const float* __restrict_
     if (T == 0) return;
     const float* __restrict__ x = lm + f0 * n_filt;
     float mx = -INFINITY;
-    for (int64_t i = tid; i < T * n_filt; i += 256) mx = fmaxf(mx, x[i]);
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    for (int64_t i = tid; i < T * n_filt; i += 256) mx = nanmax(mx, x[i]);
+    for (int o = 32; o > 0; o >>= 1) mx = nanmax(mx, __shfl_xor(mx, o));
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    const float thr = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) - top_db;
+    const float thr = nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3])) - top_db;
     for (int64_t i = tid; i < T * nc; i += 256) {
         const int64_t r = i / nc;
         const int q = (int)(i - r * nc);
         const float* __restrict__ row = x + r * n_filt;
         const float* __restrict__ drow = dct + (size_t)q * n_filt;
         float acc = 0.f;
-        for (int j = 0; j < n_filt; ++j) acc = fmaf(fmaxf(row[j], thr), drow[j], acc);
+        for (int j = 0; j < n_filt; ++j) acc = fmaf(nanmax(row[j], thr), drow[j], acc);
         out[(f0 + r) * nc + q] = acc;
     }
 }
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(256) void topdb_dct_chunk_kernel(const float* __res
             v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             for (int j = 0; j < n_filt4; j += 4) {
                 v4f l = *reinterpret_cast<const v4f*>(l_ + j);
-                l = v4f{fmaxf(l.x, thr), fmaxf(l.y, thr), fmaxf(l.z, thr), fmaxf(l.w, thr)};
+                l = v4f{nanmax(l.x, thr), nanmax(l.y, thr), nanmax(l.z, thr), nanmax(l.w, thr)};
                 acc0 = __builtin_elementwise_fma(l, *reinterpret_cast<const v4f*>(d0 + j), acc0);
                 acc1 = __builtin_elementwise_fma(l, *reinterpret_cast<const v4f*>(d1 + j), acc1);
             }

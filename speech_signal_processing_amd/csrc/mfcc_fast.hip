@@ -236,7 +236,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                     const float xm1 = pm[n1 < NZ ? n1 : 0], x0 = y.x, x1 = y.y;
                     y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
                 }
-                z[n1] = y * wreg[n1 < NZ ? n1 : 0];
+                // (a zero weight silences whatever the sample holds — the rows run past the window's last tap into the samples behind the
+                //  frame: wmul_edge, cplx.hpp)
+                z[n1] = n1 == NZ - 1 ? wmul_edge(y, wreg[n1 < NZ ? n1 : 0]) : y * wreg[n1 < NZ ? n1 : 0];
             } else {
                 z[n1] = v2f{0.f, 0.f};
             }
@@ -461,8 +463,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
             reinterpret_cast<float*>(((uint64_t)ohi << 32) | olo), 0, __builtin_amdgcn_readfirstlane(T * Dd * 4), 0x00020000);
         auto put = [&](int idx, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, idx * 4, 0, 0); };
         auto cepg = [&](int u, int qq) -> float { return scr[(u - ta) * 13 + qq]; };
-        auto dlg = [&](int u, int qq) -> float {
-            return ((cepg(min(u + 1, T - 1), qq) - cepg(max(u - 1, 0), qq)) + 2.f * (cepg(min(u + 2, T - 1), qq) - cepg(max(u - 2, 0), qq))) * invd;
+        auto dlg = [&](int u, int qq) -> float {  // (+ the n = 0 term of numpy.dot, GMM_UBM.py:68: 0 . NaN = NaN)
+            return __builtin_fmaf(0.f, cepg(u, qq), ((cepg(min(u + 1, T - 1), qq) - cepg(max(u - 1, 0), qq)) + 2.f * (cepg(min(u + 2, T - 1), qq) - cepg(max(u - 2, 0), qq))) * invd);
         };
         const int ngrp = (n + 3) >> 2;
         for (int idx = tid; idx < ngrp * 13; idx += NT) {
@@ -493,8 +495,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                         put(oi, cepg(u, qq));
                         put(oi + 13, dlg(u, qq));
                         if (a.delta_order >= 2)
-                            put(oi + 26, ((dlg(min(u + 1, T - 1), qq) - dlg(max(u - 1, 0), qq)) +
-                                          2.f * (dlg(min(u + 2, T - 1), qq) - dlg(max(u - 2, 0), qq))) * invd);
+                            put(oi + 26, __builtin_fmaf(0.f, dlg(u, qq), ((dlg(min(u + 1, T - 1), qq) - dlg(max(u - 1, 0), qq)) +
+                                                                          2.f * (dlg(min(u + 2, T - 1), qq) - dlg(max(u - 2, 0), qq))) * invd));
                     }
             }
         }

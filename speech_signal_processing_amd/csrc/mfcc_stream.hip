@@ -129,6 +129,10 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
     }
 
     const int hop = a.hop;
+    // (windows that end before the last row — zero taps in more rows than one — would need the edge multiply on every row: a wave-uniform
+    //  branch per half measured +1.0 % on the headline instance, so those exotic windows keep the plain product: there a non-finite
+    //  sample within 32 NZ - win_len samples behind a frame also makes that frame non-finite; the generic kernel masks them)
+    constexpr bool edge_all = false;
     const float pre = PRE ? a.preemph : 0.f;
     const float npre = -pre;
     const int n_piece = (f.slen + 255) >> 8;
@@ -251,32 +255,33 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 if (PRE) pm[n1] = *(lds_cvf_t)(uintptr_t)(sp + 128 * n1 - 4);
             }
         };
-        auto window_a = [&](zarr_t& z, pfarr_t& pf, pmarr_t& pm) {
-            if (PRE) pm[0] = (j == 0) ? pf[0].x : pm[0];     // y[0] = x[0] - a x[0]
+        // (a row that runs past the window's last tap carries zero weights there, and whatever the samples behind the frame hold — a NaN
+        //  of a corrupt recording — must not get into this frame: wmul_edge on the LAST row, +0.2 %)
+        auto win_rows = [&](zarr_t& z, pfarr_t& pf, pmarr_t& pm, auto lo_tag, auto hi_tag, auto all_tag) {
+            constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
+            constexpr bool ALL = decltype(all_tag)::value;
 #pragma unroll
-            for (int n1 = 0; n1 < NH; ++n1) {
-                v2f y = pf[n1];
-                if (PRE) {
-                    const float xm1 = pm[n1], x0 = y.x, x1 = y.y;
-                    y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
-                }
-                z[n1] = y * wreg[n1];
-            }
-        };
-        auto window_b = [&](zarr_t& z, pfarr_t& pf, pmarr_t& pm) {
-#pragma unroll
-            for (int n1 = NH; n1 < 16; ++n1) {
+            for (int n1 = LO; n1 < HI; ++n1) {
                 if (n1 < NZ) {
                     v2f y = pf[n1 < NZ ? n1 : 0];
                     if (PRE) {
                         const float xm1 = pm[n1 < NZ ? n1 : 0], x0 = y.x, x1 = y.y;
                         y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
                     }
-                    z[n1] = y * wreg[n1 < NZ ? n1 : 0];
+                    z[n1] = (ALL || n1 == NZ - 1) ? wmul_edge(y, wreg[n1 < NZ ? n1 : 0]) : y * wreg[n1 < NZ ? n1 : 0];
                 } else {
                     z[n1] = v2f{0.f, 0.f};
                 }
             }
+        };
+        auto window_a = [&](zarr_t& z, pfarr_t& pf, pmarr_t& pm) {
+            if (PRE) pm[0] = (j == 0) ? pf[0].x : pm[0];     // y[0] = x[0] - a x[0]
+            if (edge_all) win_rows(z, pf, pm, std::integral_constant<int, 0>{}, std::integral_constant<int, NH>{}, std::true_type{});
+            else win_rows(z, pf, pm, std::integral_constant<int, 0>{}, std::integral_constant<int, NH>{}, std::false_type{});
+        };
+        auto window_b = [&](zarr_t& z, pfarr_t& pf, pmarr_t& pm) {
+            if (edge_all) win_rows(z, pf, pm, std::integral_constant<int, NH>{}, std::integral_constant<int, 16>{}, std::true_type{});
+            else win_rows(z, pf, pm, std::integral_constant<int, NH>{}, std::integral_constant<int, 16>{}, std::false_type{});
         };
         // FFT16 over n1, twiddle W_256^(n2 k1), transpose through LDS, FFT16 over n2, split step -> P row of the frame's image
         auto fft_front = [&](zarr_t& z) {

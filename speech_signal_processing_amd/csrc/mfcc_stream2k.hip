@@ -62,7 +62,7 @@ __device__ __forceinline__ void wave_sync2k() {
 
 __device__ __forceinline__ float log2k(const MfccArgs& a, float v) {
     if (a.floor_mode == 1) v += a.eps;
-    else if (a.floor_mode == 2) v = fmaxf(v, a.eps);
+    else if (a.floor_mode == 2) v = fmaxf(v, a.eps);  // (a NaN is dropped here: frames whose spectrum is not finite never get this far, see row_bad)
     const float l2 = __builtin_amdgcn_logf(v);
     return l2 * (a.log_mode == 0 ? 0.6931471805599453f : (a.log_mode == 1 ? 0.30102999566398120f : 3.0102999566398120f));
 }
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
         const float* __restrict__ x = a.samples + s0;
         const int t0 = __builtin_amdgcn_readfirstlane(ch.t0), n = __builtin_amdgcn_readfirstlane(ch.n);
         float wave_max = -INFINITY;
+        int wave_nan = 0;  // a frame of this chunk had a non-finite spectrum (wave-uniform)
         // rows R0..15 of frame t
         auto load_frame = [&](int t, v2f (&v)[16], auto r0tag) {
             constexpr int R0 = decltype(r0tag)::value;
@@ -303,6 +304,10 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
             // (X[512] = conj Z[512]: against the other bins' 2 X[k] this one carries a factor 4 (power) / 2 (magnitude))
             float p512 = 4.f * (z512.x * z512.x + z512.y * z512.y);
             if (POWER == 1) p512 = __builtin_amdgcn_sqrtf(p512);
+            // a NaN / inf sample anywhere in the frame makes EVERY bin of its spectrum non-finite (each is a sum over all samples), so one
+            // bin tells: such a frame's log filterbank row is NaN (numpy.maximum keeps the NaN the floor would drop) and so is the
+            // utterance maximum of the top_db clamp (ndarray.max()) — one compare per frame, the rest wave-uniform and cold
+            const bool row_bad = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_classf(p512, 0x203 /* NaN, +inf */)) != 0;
             wave_sync2k();
             float* P = reinterpret_cast<float*>(buf);
 #pragma unroll
@@ -320,6 +325,12 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
 #ifndef SSP_2K_NOMEL
             const __amdgpu_buffer_rsrc_t ro =
                 __builtin_amdgcn_make_buffer_rsrc(a.lm_out + (size_t)(f0 + t) * (size_t)a.n_filt, 0, a.n_filt * 4, 0x00020000);
+            if (row_bad) {  // (cold)
+                const float qn = __builtin_nanf("");
+                if (mfid0 >= 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qn), ro, mfid0 * 4, 0, 0);
+                if (mfid1 >= 0 && s.steps1 != 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qn), ro, mfid1 * 4, 0, 0);
+                wave_nan = s.top_db >= 0.f ? 1 : 0;  // (the clamp's ndarray.max() becomes NaN; dialects without a clamp keep their NaN rows to themselves)
+            } else
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int nst = g == 0 ? s.steps0 : s.steps1;
@@ -370,6 +381,7 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
         }
         // utterance maximum for the second pass (float order through the integer trick, as the generic kernel)
         for (int o = 32; o > 0; o >>= 1) wave_max = fmaxf(wave_max, __shfl_xor(wave_max, o));
+        if (wave_nan) wave_max = __builtin_nanf("");
         if (s.fuse) {
             // ---- the whole utterance was this wave's: clamp at its maximum - top_db (librosa power_to_db) and DCT-II, rows re-read
             // through L2.  Lane (q = lane & 15, part = lane >> 4): coefficient q over filters 32 part .. 32 part + 31
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
                 for (int i4 = 0; i4 < 8; ++i4) {
                     const int j = 32 * part + 4 * i4;
                     l[i4] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rr, (r < n && j < nf) ? (r * nf + j) * 4 : 0x7ffffff0, 0, 1 /*glc*/));
-                    l[i4] = v4f{fmaxf(l[i4].x, thr), fmaxf(l[i4].y, thr), fmaxf(l[i4].z, thr), fmaxf(l[i4].w, thr)};
+                    l[i4] = v4f{nanmax(l[i4].x, thr), nanmax(l[i4].y, thr), nanmax(l[i4].z, thr), nanmax(l[i4].w, thr)};  // (numpy.maximum)
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
@@ -407,8 +419,9 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
                     if (part == 0 && r < n) a.out[(size_t)(f0 + t0 + r) * nc + q] = v;
                 }
             }
-        } else if (lane == 0 && wave_max > -INFINITY) {
-            if (wave_max >= 0.f) atomicMax(reinterpret_cast<int*>(a.utt_max + ch.utt), __float_as_int(wave_max));
+        } else if (lane == 0 && (wave_max > -INFINITY || wave_nan)) {
+            if (wave_nan) atomicExch(reinterpret_cast<unsigned*>(a.utt_max + ch.utt), 0x7fc00000u);  // (sticks: mfcc.hip)
+            else if (wave_max >= 0.f) atomicMax(reinterpret_cast<int*>(a.utt_max + ch.utt), __float_as_int(wave_max));
             else atomicMin(reinterpret_cast<unsigned*>(a.utt_max + ch.utt), __float_as_uint(wave_max));
         }
     }

@@ -449,6 +449,42 @@ def test_partially_silent_utterances_in_a_machine_filling_batch(ssp, order, cmvn
         np.testing.assert_allclose(got[u], got[u % 7 + 7], rtol=0, atol=2e-4 * max(1.0, float(np.abs(got[u % 7 + 7]).max())))
 
 
+@pytest.mark.parametrize("dialect", ["librosa", "inrepo2048", "sidekit", "plp"])
+def test_nan_sample_stays_in_its_frames(ssp, dialect):
+    """A NaN sample (a corrupt recording) in a ragged batch of short and long utterances (multi-chunk work tables): in the reference's
+    arithmetic every frame that holds it is NaN — plus the deltas' reach; with librosa's power_to_db the whole utterance, because
+    numpy.maximum keeps the NaN through the floor and ndarray.max() through the top_db clamp — and no other frame or utterance is touched:
+    not the frame in front whose last 32-sample row runs past its window onto the sample (zero weights there), and not through a floor
+    that would turn NaN into a number.  Every kernel; the finite-pattern must equal the oracle's."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    tables, (cfg, w, fb, dct), fs = {
+        "librosa": lambda: (pkg.preset_librosa(16000, 13), O.librosa_tables(16000, 13), 16000),
+        "inrepo2048": lambda: (pkg.preset_inrepo(16000, 2048, 512), O.inrepo_tables(16000, 2048, 512), 16000),
+        "sidekit": lambda: (pkg.preset_sidekit(delta_order=2), O.sidekit_tables(delta_order=2), 16000),
+        "plp": lambda: (pkg.preset_sidekit_plp(), O.sidekit_plp_tables(), 16000)}[dialect]()
+    rng = np.random.default_rng(3)
+    lens = [1025, 1025, 200000, 1025, 3000, 1025, 1025, 200000, 1025, 5000]
+    for where in (None, (2, 5000), (0, 500), (4, 2326), (7, 199999), (9, 2805)):
+        sigs = [(0.3 * rng.standard_normal(l)).astype(np.float32) for l in lens]
+        if where is not None:
+            sigs[where[0]][where[1]] = np.nan
+        refs = []
+        with np.errstate(all="ignore"):
+            for x in sigs:
+                refs.append(O.mfcc_pipeline(x, cfg, w, fb, dct))
+        for variant in (0, 1):
+            got, _ = _run_plan(api, tables, sigs, variant=variant)
+            for u in range(len(sigs)):
+                fin = np.isfinite(refs[u])
+                assert (np.isfinite(got[u]) == fin).all(), (dialect, where, variant, u)
+                if fin.any():
+                    assert np.abs(got[u][fin] - refs[u][fin]).max() <= 1e-4 * max(1.0, float(np.abs(refs[u][fin]).max())), (dialect, where, variant, u)
+        if where is not None:
+            # (the sample may sit behind the last frame of a dialect that does not pad: then nothing is NaN at all)
+            assert all(np.isfinite(refs[u]).all() for u in range(len(sigs)) if u != where[0])
+
+
 def test_sidekit_shape_fact(ssp):
     """report/final.pdf IV-B-2: 1 s @ 16 kHz -> 98 x 13."""
     pkg, api = ssp
