@@ -244,3 +244,29 @@ def test_vote_matches_the_reference_rule():
     assert vote(["b", "a", "a", "b"]) == "b"      # two each: the first met
     assert vote([7]) == 7
     assert vote(np.array([2, 2, 5, 5, 5])) == 5
+
+
+def test_flop_count_script_matches_known_transform_counts():
+    """tools/flop_count.py (the algorithmic roofline of bench.py's `roofline_flop`): its symbolic radix-4 run reproduces the textbook
+    operation counts of small complex FFTs (4: 16 additions; 8: 52 + 4; 16: 144 + 24 — equal to split-radix there), never undercuts the
+    split-radix count 4 N log2 N - 6 N + 8 on larger ones, counts structural zeros as free, and the headline dialect comes to 11 300."""
+    import importlib.util
+    import math
+    spec = importlib.util.spec_from_file_location("flop_count", os.path.join(ROOT, "tools", "flop_count.py"))
+    fc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fc)
+    for n, add, mul in ((4, 16, 0), (8, 52, 4), (16, 144, 24)):
+        c = fc.Count()
+        fc.dft(c, [fc.Z() for _ in range(n)])
+        assert (c.add, c.mul) == (add, mul)
+    for n in (64, 256, 1024):
+        c = fc.Count()
+        fc.dft(c, [fc.Z() for _ in range(n)])
+        assert c.flop >= 4 * n * math.log2(n) - 6 * n + 8
+    full, pruned = fc.Count(), fc.Count()
+    fc.dft(full, [fc.Z() for _ in range(256)])
+    fc.dft(pruned, [fc.Z(zero=k >= 200) for k in range(256)])
+    assert pruned.flop < full.flop
+    r = fc.count()
+    assert r["flop_per_frame"] == 11300 and r["ops_per_frame"] == 8917 and abs(r["fma_fraction_of_peak"] - 0.634) < 1e-3
+    assert r["stages"]["real FFT (pruned, N/2 complex + split)"]["flop"] == 7684   # the published real split-radix count is the smaller one
