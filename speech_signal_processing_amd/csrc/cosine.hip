@@ -626,47 +626,60 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
             }
         }
     };
-    float b1 = -INFINITY, b2 = -INFINITY;  // the two largest cosines of this lane's rows (b1: the first row that reaches it)
-    int i1 = 0x7fffffff;
-    bool bad = false;                      // a NaN went by
+    // the two largest cosines of this lane's rows and where the largest sits.  Per value FOUR vector instructions — the sweep is otherwise
+    // bound by this epilogue, not by the matrix pipe (the first version: 250 per 16-MFMA tile): b2 = med3(b1, b2, v) is the second largest
+    // of the three while b1 >= b2, b1 = max(b1, v), and the position is kept tile-relative (an inline constant) with the tile beside it.
+    // NaNs need no flag of their own: a NaN embedding makes every cosine of the lane NaN, v > b1 never holds and b1 stays -inf (checked
+    // below); a NaN centroid is the pack kernel's flag.
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int i1 = 0, t1 = 0;  // register index inside the tile, tile
     int slot = 0;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < a.n_tiles; ++t) {
         const int s1 = slot == 2 ? 0 : slot + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        f32x16 acc = zero16;  // (a literal zero accumulator operand of the tile's first MFMA, not sixteen moves)
         if (2 * t + 2 < n_steps) stage(2 * t + 2, s2);
         half_sweep(smem + slot * HALF_BYTES, 0, acc);
         __syncthreads();
         if (2 * t + 3 < n_steps) stage(2 * t + 3, slot);
         half_sweep(smem + s1 * HALF_BYTES, NK / 2, acc);
+        const float b1_in = b1;
+        if (t * 32 + 32 <= a.S) {  // (wave-uniform: every row of the tile is a centroid)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // ascending in i: a strict > keeps the first row of equal cosines
-            if (row < a.S) {
+            for (int i = 0; i < 16; ++i) {
                 const float v = acc[i];
-                bad = bad || v != v;
+                const bool gt = v > b1;  // ascending rows: a strict > keeps the first row of equal cosines
+                b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+                i1 = gt ? i : i1;
+                b1 = fmaxf(b1, v);
+            }
+        } else {  // the last, partly padded tile: rows past S must not take part (their zero vectors would score 0)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float v = row < a.S ? acc[i] : -INFINITY;
                 const bool gt = v > b1;
-                b2 = gt ? b1 : fmaxf(b2, v);
-                i1 = gt ? row : i1;
-                b1 = gt ? v : b1;
+                b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+                i1 = gt ? i : i1;
+                b1 = fmaxf(b1, v);
             }
         }
+        t1 = b1 > b1_in ? t : t1;
         __syncthreads();
         slot = s2;
     }
+    i1 = t1 * 32 + (i1 & 3) + 8 * (i1 >> 2) + 4 * h;
     // the two lane halves hold different rows of the same embedding
     {
         const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
         const int oi = __shfl_xor(i1, 32);
-        const bool ob = __shfl_xor((int)bad, 32) != 0;
         const bool take = o1 > b1 || (o1 == b1 && oi < i1);
         const float lose = take ? b1 : o1;
         b2 = fmaxf(fmaxf(b2, o2), lose);
         b1 = take ? o1 : b1;
         i1 = take ? oi : i1;
-        bad = bad || ob;
     }
+    const bool bad = !(b1 > -INFINITY);  // nothing ever compared greater on either half: the embedding's cosines are NaN
     const int64_t gc = col0 + fl;
     const bool mine = h == 0 && gc < Nn;
     const int64_t go = (a.rows && gc < Nn) ? (int64_t)a.rows[gc] : gc;  // the row this lane's embedding is
