@@ -102,6 +102,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
     v2f wreg[NZ];
 #pragma unroll
     for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
+    wreg[NZ - 1] = edge_row_taps(wreg[NZ - 1], 32 * (NZ - 1) + 2 * j, a.win_len);
     // this lane's twiddles stay in registers: W_256^(k1 j) for the step between the two radix-16 passes and
     // W_512^(8j+1+i) for the split step (LDS is the busiest unit of this kernel; registers are not)
     v2f twr[15], wpr[8];

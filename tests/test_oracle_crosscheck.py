@@ -1,0 +1,60 @@
+"""Cross-check of the oracle's restatement of the dialects whose third-party source is NOT in this image (librosa: MFCC_DTW.py:28-31;
+sidekit's mel edges: GMM_UBM.py:89) against an INDEPENDENT implementation that is: `transformers.audio_utils`, whose mel filter bank,
+spectrogram and dB conversion are documented as librosa-equivalent.  This corroborates the restatement; it does not pin it to the
+reference (the reference holds no fixture for these dialects and librosa / sidekit cannot be imported here): parity for rows a6 / a7 stays
+"unpinned" (DESIGN.md 2).  CPU only."""
+import numpy as np
+import pytest
+
+au = pytest.importorskip("transformers.audio_utils")
+
+from oracle import ref_cpu as O  # noqa: E402
+
+
+def _signal(seed, n, fs):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    x = 0.4 * np.sin(2 * np.pi * 220.0 * t) + 0.2 * np.sin(2 * np.pi * 1370.0 * t + 0.3) + 0.05 * rng.standard_normal(n)
+    return (x * np.hanning(n) ** 0.25).astype(np.float32)
+
+
+@pytest.mark.parametrize("sr,n_fft,n_mels", [(8000, 2048, 128), (16000, 2048, 128), (16000, 512, 40)])
+def test_librosa_mel_bank_vs_transformers(sr, n_fft, n_mels):
+    """librosa.filters.mel(sr, n_fft, n_mels, htk=False, norm='slaney') as the oracle restates it == mel_filter_bank(norm='slaney',
+    mel_scale='slaney') to rounding (both float64)."""
+    ours = O.librosa_mel_filters(sr, n_fft, n_mels)
+    theirs = au.mel_filter_bank(num_frequency_bins=1 + n_fft // 2, num_mel_filters=n_mels, min_frequency=0.0, max_frequency=sr / 2.0,
+                                sampling_rate=sr, norm="slaney", mel_scale="slaney").T
+    assert ours.shape == theirs.shape
+    assert np.abs(ours - theirs).max() <= 1e-12 * max(1.0, np.abs(theirs).max())
+
+
+def test_slaney_and_htk_mel_scales_vs_transformers():
+    """the two mel scales the dialects use: Slaney (librosa default) and HTK (sidekit's hz2mel / mel2hz: 2595 log10(1 + f / 700))."""
+    f = np.concatenate([np.linspace(0.0, 8000.0, 161), [999.9, 1000.0, 1000.1]])
+    assert np.allclose(O.slaney_hz_to_mel(f), au.hertz_to_mel(f, mel_scale="slaney"), rtol=1e-13, atol=1e-12)
+    m = O.slaney_hz_to_mel(f)
+    assert np.allclose(O.slaney_mel_to_hz(m), au.mel_to_hertz(m, mel_scale="slaney"), rtol=1e-13, atol=1e-9)
+    assert np.allclose(O.hz2mel(f), au.hertz_to_mel(f, mel_scale="htk"), rtol=1e-13, atol=1e-12)
+    mh = O.hz2mel(f)
+    assert np.allclose(O.mel2hz(mh), au.mel_to_hertz(mh, mel_scale="htk"), rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed,n", [(1, 8000), (2, 12345), (3, 4097)])
+def test_librosa_mfcc_vs_transformers(seed, n):
+    """MFCC_DTW.MFCC_lib = librosa.feature.mfcc(y, sr=8000, n_mfcc=13): centred reflect-padded frames of 2048 at hop 512, periodic Hann,
+    power spectrum, Slaney mel bank, 10 log10(max(1e-10, S)) clamped at max - 80 dB, DCT-II ortho.  The independent chain: spectrogram(
+    center, reflect, power 2, mel_filters, log_mel='dB', db_range 80) + scipy's DCT."""
+    from scipy.fft import dct
+    sr, n_fft, hop, n_mels, n_mfcc = 8000, 2048, 512, 128, 13
+    x = _signal(seed, n, sr)
+    ours = O.librosa_mfcc_flat(x, n_mfcc).reshape(-1, n_mfcc)
+    fb = au.mel_filter_bank(1 + n_fft // 2, n_mels, 0.0, sr / 2.0, sr, norm="slaney", mel_scale="slaney")
+    win = au.window_function(n_fft, "hann", periodic=True)
+    logmel = au.spectrogram(x.astype(np.float64), win, frame_length=n_fft, hop_length=hop, fft_length=n_fft, power=2.0, center=True,
+                            pad_mode="reflect", mel_filters=fb, mel_floor=1e-10, log_mel="dB", reference=1.0, min_value=1e-10,
+                            db_range=80.0, dtype=np.float64)
+    theirs = dct(logmel.T, type=2, norm="ortho", axis=1)[:, :n_mfcc]
+    assert ours.shape == theirs.shape
+    scale = float(np.abs(theirs).max())
+    assert np.abs(ours - theirs).max() <= 1e-4 * scale, (np.abs(ours - theirs).max(), scale)
