@@ -84,6 +84,10 @@ int ssp_ctx_destroy(ssp_ctx* ctx);
  * deterministically in the parity tests instead of depending on what the previous kernel left behind */
 int ssp_debug_poison_lds(ssp_ctx* ctx, uint32_t pattern);
 int ssp_ctx_sync(ssp_ctx* ctx);
+/* measurement aid (bench.py `env.calibration`): what this box sustains on two textbook loads, each run for about target_ms
+ * milliseconds (<= 0: 20) on the ctx stream and timed with HIP events — a float4 copy of 1 GiB buffers (GB/s, read + write) and
+ * eight packed-fp32 FMA chains per lane on every SIMD (TFLOP/s).  Blocks until both are measured; copy_ms / fma_ms may be NULL. */
+int ssp_calibrate(ssp_ctx* ctx, double target_ms, double* copy_gbs, double* fma_tflops, double* copy_ms, double* fma_ms);
 /* ordering against another stream of the same device without a host wait (a ctx that owns its stream, called with device pointers
  * produced / consumed on the caller's stream): wait = the ctx stream waits for everything queued on other_stream so far;
  * signal = other_stream waits for everything queued on the ctx stream so far.  other_stream: hipStream_t (NULL = the default stream) */

@@ -42,6 +42,7 @@ SIGNATURES = {
     "ssp_ctx_destroy": (C.c_int, [_P]),
     "ssp_debug_poison_lds": (C.c_int, [_P, C.c_uint32]),
     "ssp_ctx_sync": (C.c_int, [_P]),
+    "ssp_calibrate": (C.c_int, [_P, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ssp_ctx_wait_stream": (C.c_int, [_P, _P]),
     "ssp_ctx_signal_stream": (C.c_int, [_P, _P]),
     "ssp_comm_unique_id": (C.c_int, [_P]),

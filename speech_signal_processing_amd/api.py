@@ -56,6 +56,13 @@ class Context:
     def sync(self):
         _lib.check(self._lib.ssp_ctx_sync(self._h))
 
+    def calibrate(self, target_ms: float = 20.0) -> dict:
+        """what this box sustains on two textbook loads (ssp_calibrate): a float4 copy (GB/s) and packed-fp32 FMA chains (TFLOP/s), each
+        run for about target_ms on this context's stream — bench.py divides its headline by them to compare boxes"""
+        v = [C.c_double() for _ in range(4)]
+        _lib.check(self._lib.ssp_calibrate(self._h, float(target_ms), *[C.byref(x) for x in v]))
+        return {"copy_gbs": v[0].value, "fma_tflops": v[1].value, "copy_ms": v[2].value, "fma_ms": v[3].value}
+
     @contextlib.contextmanager
     def _ordered(self, where):
         """Stream ordering around a call that takes device pointers.  A context that BORROWS torch's stream needs none (the kernels

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsspgpu.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["ctx.hip", "comm.hip", "mfcc.hip", "mfcc_fast.hip", "mfcc_stream.hip", "mfcc_stream_walk.hip", "mfcc_stream2k.hip", "mfcc_plan.hip", "feat_ops.hip", "gmm.hip", "gmm_em.hip", "cosine.hip", "dense.hip", "dnn_chain.hip", "dtw.hip", "fastdtw.hip", "plp.hip"]
+SOURCES = ["ctx.hip", "calib.hip", "comm.hip", "mfcc.hip", "mfcc_fast.hip", "mfcc_stream.hip", "mfcc_stream_walk.hip", "mfcc_stream2k.hip", "mfcc_plan.hip", "feat_ops.hip", "gmm.hip", "gmm_em.hip", "cosine.hip", "dense.hip", "dnn_chain.hip", "dtw.hip", "fastdtw.hip", "plp.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-munsafe-fp-atomics", "-Wno-pass-failed"] + os.environ.get("SSP_EXTRA_FLAGS", "").split()

@@ -60,6 +60,11 @@ __device__ __forceinline__ void wave_sync2k() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// bounds-checked buffer atomics without a return value (the LLVM intrinsics: this clang has no builtin for them)
+extern "C" __device__ int buf_atomic_smax(int, __amdgpu_buffer_rsrc_t, int, int, int) __asm("llvm.amdgcn.raw.ptr.buffer.atomic.smax.i32");
+extern "C" __device__ int buf_atomic_umin(int, __amdgpu_buffer_rsrc_t, int, int, int) __asm("llvm.amdgcn.raw.ptr.buffer.atomic.umin.i32");
+extern "C" __device__ int buf_atomic_swap(int, __amdgpu_buffer_rsrc_t, int, int, int) __asm("llvm.amdgcn.raw.ptr.buffer.atomic.swap.i32");
+
 __device__ __forceinline__ float log2k(const MfccArgs& a, float v) {
     if (a.floor_mode == 1) v += a.eps;
     else if (a.floor_mode == 2) v = fmaxf(v, a.eps);  // (a NaN is dropped here: frames whose spectrum is not finite never get this far, see row_bad)
@@ -419,10 +424,22 @@ __global__ __launch_bounds__(64 * S2K_WAVES, 1) void mfcc_stream2048_kernel(Mfcc
                     if (part == 0 && r < n) a.out[(size_t)(f0 + t0 + r) * nc + q] = v;
                 }
             }
-        } else if (lane == 0 && (wave_max > -INFINITY || wave_nan)) {
-            if (wave_nan) atomicExch(reinterpret_cast<unsigned*>(a.utt_max + ch.utt), 0x7fc00000u);  // (sticks: mfcc.hip)
-            else if (wave_max >= 0.f) atomicMax(reinterpret_cast<int*>(a.utt_max + ch.utt), __float_as_int(wave_max));
-            else atomicMin(reinterpret_cast<unsigned*>(a.utt_max + ch.utt), __float_as_uint(wave_max));
+        } else {
+            // ---- the chunk's maximum joins its utterance's (float order through the integer trick, as the generic kernel; a NaN sticks:
+            // mfcc.hip).  ONE lane's atomic, but NO lane-0 block: a block of lane 0 at the bottom of this loop sits, across the back edge,
+            // right in front of the lane-0 block of the next claim; the compiler threads the other lanes around both, the chunk loop
+            // becomes a loop over lane masks whose lanes leave separately, and with lane 0 gone nobody claims — readfirstlane returns
+            // the initial 0 and the wave walks chunk 0 for ever (round 4's hang on ragged batches, the only ones that get here;
+            // tools/microbench/lane0_loop.hip).  So every lane issues the three bounds-checked buffer atomics, and all but
+            // the one that applies aim out of range.
+            const uint64_t ua = reinterpret_cast<uint64_t>(a.utt_max + ch.utt);
+            const uint32_t ulo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ua), uhi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ua >> 32));
+            const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((uint64_t)uhi << 32) | (uint64_t)ulo), 0, 4, 0x00020000);
+            const bool one = lane == 0;
+            const int bits = __float_as_int(wave_max);
+            buf_atomic_swap(0x7fc00000, ru, (one && wave_nan) ? 0 : 0x7ffffff0, 0, 0);
+            buf_atomic_smax(bits, ru, (one && !wave_nan && wave_max >= 0.f) ? 0 : 0x7ffffff0, 0, 0);
+            buf_atomic_umin(bits, ru, (one && !wave_nan && wave_max < 0.f && wave_max > -INFINITY) ? 0 : 0x7ffffff0, 0, 0);
         }
     }
 }

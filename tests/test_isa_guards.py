@@ -65,6 +65,43 @@ def test_stream2048_power_dialects_carry_no_square_root(tmp_path):
         assert _count(v, r"v_div_(scale|fmas|fixup)") == 0, n
 
 
+def _lane_mask_loops_behind(instrs, marker):
+    """loop tests on lane masks (`s_andn2_b64 exec, exec, s[..]`: lanes leave the loop separately) behind the first `marker` instruction"""
+    seen, n = False, 0
+    for t in instrs:
+        seen = seen or t.startswith(marker)
+        if seen and re.match(r"s_andn2_b64 exec, exec", t):
+            n += 1
+    return n
+
+
+def test_persistent_loops_stay_wave_uniform(tmp_path):
+    """Round 4's hang of mfcc_stream2048_kernel (a ragged batch), root-caused in round 5: a lane-0 block at the BOTTOM of a persistent
+    claim loop and the lane-0 block of the claim at its TOP are neighbours across the back edge; the compiler threads the other lanes
+    around both and rebuilds the loop as one over lane masks in which lanes leave separately — with lane 0 gone the claim is skipped,
+    readfirstlane returns the initial 0 and the wave walks item 0 for ever.  tools/microbench/lane0_loop.hip is the reduction: its
+    FORM 3 / 4 must still show the loop test on lane masks (the detector means something with this compiler), FORM 1 — the cure, stores
+    from all lanes with all but one out of range — must not; and no persistent-loop kernel of the library may show one behind its claim
+    (the 2048-point kernel has two honest divergent loops in FRONT of its barrier: table copies)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    red = os.path.join(ROOT, "tools", "microbench", "lane0_loop.hip")
+    counts = {}
+    for form in (1, 3, 4):
+        out = str(tmp_path / ("lane0_%d.s" % form))
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-DFORM=%d" % form, "-o", out, red], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        counts[form] = sum(1 for line in open(out) if re.match(r"\s*s_andn2_b64 exec, exec", line))
+    assert counts[1] == 0 and counts[3] >= 1 and counts[4] >= 1, counts
+    k = _isa("mfcc_stream2k.hip", tmp_path)
+    inst = {n: v for n, v in k.items() if "mfcc_stream2048_kernel" in n}
+    assert len(inst) >= 4
+    for n, v in inst.items():
+        assert sum(1 for t in v if t.startswith("s_barrier")) == 1, n
+        assert _lane_mask_loops_behind(v, "s_barrier") == 0, n
+        assert sum(1 for t in v if t.startswith("buffer_atomic_")) == 3, n  # the chunk maximum: three bounds-checked atomics, no lane-0 block
+
+
 def test_plp_cepstrum_kernel_is_lean(tmp_path):
     """plp_cep_fixed_kernel<21, 12>: a frame is ~800 instructions — one v_exp per band, twelve reciprocals, one logarithm; no division
     expansion, no ldexp / frexp (powf), no LDS reads for the tables (they are scalar operands)."""

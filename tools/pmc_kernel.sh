@@ -9,7 +9,7 @@ i=0
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_INSTS_VALU_TRANS SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL" ${PMC_EXTRA:+"$PMC_EXTRA"} ${PMC_EXTRA2:+"$PMC_EXTRA2"}; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pmck_${tag}_$i
-  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmck_${tag}_$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmck_${tag}_$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-env "$@" > /dev/null 2>&1
 done
 python3 - > $R/gpurun_out/pmc_$tag.txt <<PY
 import csv,glob,collections

@@ -15,7 +15,7 @@ if has bench; then
   echo "bench: $(python3 -c "import json;d=json.load(open('$O/bench_line.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac'])")"
 fi
 if has stats; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_all -o run -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/prof_all.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_all -o run -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-env > $O/prof_all.log 2>&1
   cp $(find $O/prof_all -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv && rm -rf $O/prof_all
   echo "stats: $(wc -l < $O/kernel_stats.csv) rows"
 fi
@@ -23,7 +23,7 @@ if has stages; then
   # one kernel trace per stage: the dominant kernel's launches can be read per launch (no other stage's launches of the same kernel in the file)
   for st in mfcc ref26 inrepo librosa gmm cosine plp; do
     extra=""; [ $st = gmm ] && extra="--no-gmm4-full"
-    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$st -o run -- python3 bench.py --steps 10 --warmup 3 --stages $st --no-cpu-baseline $extra > $O/stage_$st.log 2> $O/stage_$st.err
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$st -o run -- python3 bench.py --steps 10 --warmup 3 --stages $st --no-cpu-baseline --no-env $extra > $O/stage_$st.log 2> $O/stage_$st.err
     tail -1 $O/stage_$st.log > $O/stage_${st}_bench_line.json
     cp $(find $O/prof_$st -name "*kernel_trace.csv" | head -1) $O/stage_${st}_kernel_trace.csv
     cp $(find $O/prof_$st -name "*kernel_stats.csv" | head -1) $O/stage_${st}_kernel_stats.csv
@@ -33,7 +33,7 @@ if has stages; then
 fi
 pmc_pass() {  # tag, counters, bench args...
   local tag=$1 ctr=$2; shift; shift
-  rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$tag -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $O/pmc_$tag.log 2>&1 || echo "pmc pass $tag failed"
+  rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$tag -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-env "$@" > $O/pmc_$tag.log 2>&1 || echo "pmc pass $tag failed"
   cp $(find $O/pmc_$tag -name "*counter_collection.csv" | head -1) $O/pmc_$tag.csv 2>/dev/null; rm -rf $O/pmc_$tag
 }
 if has pmc512; then
