@@ -225,6 +225,8 @@ def kernel_source_sha256(names=("mfcc_stream.hip", "cplx.hpp", "mfcc.hpp", "comm
 
 
 # ---------------------------------------------------------------------------------------------- box state (`env` in the bench line)
+CLOSE_GMM_OFFSETS = (1.0, 0.1, 0.01)   # speaker-mean offsets (x std) of the close-call rows; 0.3 = the headline rows
+CLOSE_COS_NOISE = (3.0, 4.0, 10.0)       # embedding noise of the close-call rows; 0.7 = the headline rows
 HBM_COPY_REF_GBS = 6290.0    # MI355X_MICROARCH.md: measured float4 copy
 SYSFS_FILES = {"sclk_hz": "freq1_input", "mclk_hz": "freq2_input", "power_uw": "power1_input", "junction_mC": "temp2_input"}
 
@@ -323,7 +325,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused workgroup kernel | 3 fused wave-stream kernel (| 4: the 2048-point one, librosa stage only)")
     ap.add_argument("--ref26-variant", type=int, default=0, help="kernel variant of the 26-d + CMVN stage (as --variant)")
     ap.add_argument("--inrepo-variant", type=int, default=0, help="kernel variant of the in-repo MFCC stage (as --variant)")
-    ap.add_argument("--stages", default="mfcc,ref26,inrepo,librosa,gmm,gmm4,cosine,em,dnn,dvec,dtw,plp")
+    ap.add_argument("--stages", default="mfcc,ref26,inrepo,librosa,gmm,gmm4,cosine,closecalls,em,dnn,dvec,dtw,plp")
     ap.add_argument("--gmm4-utts", type=int, default=12000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU; SURVEY.md 8(d) asks for >= 12000)")
     ap.add_argument("--no-gmm4-full", dest="gmm4_full", action="store_false", help="skip the measured full per-GPU share of configs[3] (150000 utterances, bf16x3 path, ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -669,6 +671,32 @@ def main():
                          "frac": flop / (gp_ms * 1e-3) / 1e12 / 2500.0, "traffic": None, "kernel_ms": gp_ms, "algorithmic_flop_per_launch": flop}}
         r = r1
         del scorer, r, r0, r1, r2, rp
+        # ---- the same shape with the speaker models moved closer to the UBM (offset 0.3 std above): what the exact-arg-max guarantee
+        # of the split-precision path costs when many utterances are close calls (verdict r4: the rows above are the best case)
+        if "closecalls" in stages:
+            pts = []
+            for off in CLOSE_GMM_OFFSETS:
+                rngc = np.random.default_rng(70)
+                musc = np.stack([mu] + [mu + off * std * rngc.standard_normal((K, D)) for _ in range(S)])
+                sc = api.GmmScorer(ctx, np.stack([wts] * (S + 1)), musc, np.stack([cov] * (S + 1)), has_ubm=True)
+                ref = sc.score(feats, fseg, precision=0, timing=True)
+                pt = {"speaker_offset_std": off, "fp32_kernel_ms": ref["kernel_ms"], "utterances": int(n_utt)}
+                for prec, name in ((3, "heuristic_band"), (1, "proven_band")):
+                    sc.score(feats, fseg, precision=prec)
+                    ms2 = []
+                    for _ in range(2):
+                        rr = sc.score(feats, fseg, precision=prec, timing=True)
+                        ms2.append(rr["kernel_ms"])
+                    pt[name] = {"kernel_ms": float(np.mean(ms2)), "utterances_rescored_in_fp32": int(sc.last_rescored),
+                                "fraction_rescored": float(sc.last_rescored) / n_utt, "speedup_vs_fp32": ref["kernel_ms"] / float(np.mean(ms2)),
+                                "argmax_mismatches_vs_fp32_path": int((rr["argmax"] != ref["argmax"]).sum().item())}
+                pts.append(pt)
+                del sc, ref, rr
+            result["gmm_bf16x3_close_calls"] = {
+                "what": "configs[2] shape, speaker means at `speaker_offset_std` x std from the UBM's (0.3 in the rows above): the share of utterances whose "
+                        "top-2 margin falls inside the error band — scored again in fp32 on their candidate models — and what the pass then costs; "
+                        "arg-max equality with the fp32 path is checked on every utterance",
+                "points": pts}
 
     # ------------------------------------------------------------------ configs[3] shape: 512-mix UBM + 1251 speaker models, a measured sample
     if "gmm4" in stages:
@@ -816,6 +844,33 @@ def main():
                          "frac": flop / (cc * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, "traffic": None,
                          "kernel": "cosine_bf16x3_kernel<16, 1> (+ <16, 3> and cosine_reg_kernel<32> on the listed rows)", "kernel_ms": cc,
                          "algorithmic_flop_per_launch": flop}}
+
+        if "closecalls" in stages:
+            pts = []
+            Zc = torch.randn((N, d), generator=gen, device=device)
+            for noise in CLOSE_COS_NOISE:
+                Xc = Cn[lab] + noise * Zc
+                ref = api.cosine_identify(ctx, Xc, Cn, timing=True)
+                pt = {"embedding_noise": noise, "fp32_kernel_ms": ref["kernel_ms"], "rows": N,
+                      "argmin_accuracy": float((ref["argmin"].long() == lab).float().mean().item())}
+                for prec, name in ((1, "bf16x3"), (2, "cascade")):
+                    api.cosine_identify(ctx, Xc, Cn, precision=prec)
+                    ms2 = []
+                    for _ in range(3):
+                        rr = api.cosine_identify(ctx, Xc, Cn, timing=True, precision=prec)
+                        ms2.append(rr["kernel_ms"])
+                    pt[name] = {"kernel_ms": float(np.mean(ms2)), "rows_rescored_fp32": int(rr["rescored"]), "speedup_vs_fp32": ref["kernel_ms"] / float(np.mean(ms2)),
+                                "argmin_equals_fp32_path": bool((rr["argmin"] == ref["argmin"]).all().item())}
+                    if prec == 2:
+                        pt[name]["rows_to_bf16x3"] = int(rr["split_rows"])
+                        pt[name]["fraction_to_bf16x3"] = float(rr["split_rows"]) / N
+                pts.append(pt)
+                del Xc
+            result["cosine_close_calls"] = {
+                "what": "configs[4] shape, embeddings = centroid + `embedding_noise` x N(0, 1) (0.7 in the rows above: no close call at all): rows whose two "
+                        "best cosines lie inside a stage's proven band go to the next stage; arg-min equality with the fp32 path on every row",
+                "points": pts}
+            del Zc
 
     # ------------------------------------------------------------------ widened stages; reported, not part of `value`
     if "em" in stages:

@@ -205,8 +205,12 @@ int ssp_gmm_destroy(ssp_gmm* gmm);
  *  eps * S(x), S(x) = sum_d |x_d| max|mu P|_d + x_d^2 max(P/2)_d (maxima over every mixture of every model, taken at ssp_gmm_pack),
  *  eps = 3.01 * 2^-18 + 8 D 2^-23 (the products a two-term split leaves out + worst-case fp32 accumulation on both paths); the
  *  log-sum-exp is 1-Lipschitz and the mean a mean, so a margin between two models is resolved when it exceeds
- *  2 (eps mean_t S(x_t) + 2^-20 (|score| + 1)): gmm.hip gmm_band_kernel.  The call reads the flag count on the host, so it synchronises the
- *  stream even with device pointers and cannot be captured in a graph.  precision 0 is the parity path.)
+ *  2 (eps mean_t S(x_t) + 2^-20 (max_m |score_m| + 1)): gmm.hip gmm_band_kernel.  The call reads the flag count on the host, so it
+ *  synchronises the stream even with device pointers and cannot be captured in a graph.  precision 0 is the parity path.
+ *  What comes back for a close call (precision 1 / 3): the utterance's CANDIDATE models — those within the band of its best score, and
+ *  the UBM — are scored again in fp32 and only THEIR entries of its scores_out row are replaced; the row's other entries keep their
+ *  bf16x3 values (within the band of the fp32 path's).  The arg-max is the fp32 path's in every case.  A re-scoring pass too large for
+ *  one launch scores every model and replaces the whole row.)
  * Without loglik_out the per-utterance means are formed inside the scoring kernel (the [n_models x frames] matrix never exists). */
 int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_seg, float* loglik_out,
                   float* scores_out, int32_t* argmax_out, int where, int precision, float* kernel_ms);
@@ -273,10 +277,12 @@ int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, cons
 /* the same with a choice of arithmetic.  precision 0: fp32-input MFMA (the parity path; ssp_cosine_identify).  precision 1: the sweep on
  * bf16 MFMA with every operand split hi + lo (three products per k-step, fp32 accumulation) keeping each embedding's two largest
  * cosines; rows whose two best are closer than twice a PROVEN bound on |cos(bf16x3) - cos(fp32 path)| for unit vectors
- * (3.01 * 2^-18 + 4 d 2^-23: cosine.hip cos_band), and every row that meets a NaN or a zero norm, are scored again by the fp32 kernel from
- * a device-side list (no host round trip in between).  argmin_out is therefore the fp32 path's on EVERY row; min_out is within the bound
+ * (3.01 * 2^-18 + 4 d 2^-23 + (d + 8) 2^-24, the last term for the two paths' different normalisation roundings: cosine.hip cos_band),
+ * and every row that meets a NaN or a zero norm, are scored again by the fp32 kernel from a device-side list (no host round trip in
+ * between; the call ends with a stream synchronisation — it reads the list counts back for the diagnostics below — so it cannot be
+ * captured in a graph).  argmin_out is therefore the fp32 path's on EVERY row; min_out is within the bound
  * of it (exact on the re-scored rows).  precision 2: a cascade — a sweep on the hi parts alone (one product per k-step, bound
- * 2.01 * 2^-9 + 2 d 2^-23 = 4e-3) first, its close calls to the bf16x3 sweep, that one's to fp32: the same arg-min guarantee, three times
+ * 2.01 * 2^-9 + 2 d 2^-23 + (d + 8) 2^-24 = 4e-3) first, its close calls to the bf16x3 sweep, that one's to fp32: the same arg-min guarantee, three times
  * fewer matrix instructions on well-separated data (how many rows each later stage takes depends on the data); min_out is then only within
  * 4e-3 of the fp32 path's on rows the first sweep decided.  Arg-min / minimum only: dist_out must be NULL; d <= 256. */
 int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,

@@ -727,10 +727,13 @@ static int launch_cos16_nk(int nk, const Cos16Args& a, hipStream_t s) {
 // most 3.01 2^-18 sum |x_k| |c_k| <= 3.01 2^-18 (Cauchy-Schwarz, unit vectors).  Products of bf16 numbers are exact in fp32; the
 // accumulation of 3 d terms whose absolute sum is <= 1 + 2^-7 rounds (or truncates: the matrix core's internal order is not documented, so
 // the bound assumes the worst, 2^-23 per term) at most 3 d 2^-23 in total; the fp32 path's own sweep over d terms at most d 2^-23.
-static float cos_band(int d) { return 3.01f * 0x1p-18f + 4.0f * (float)d * 0x1p-23f * 1.01f; }
+// The two paths also NORMALISE differently: the row norm is summed in another lane / k order (1 / |x| differs by up to d 2^-24 relative),
+// and x / |x|, C / |c| and the final acc / |x| round once each on either path — (d + 8) 2^-24 covers all of it for cosines <= 1.
+static float cos_norm_slack(int d) { return (float)(d + 8) * 0x1p-24f; }
+static float cos_band(int d) { return 3.01f * 0x1p-18f + 4.0f * (float)d * 0x1p-23f * 1.01f + cos_norm_slack(d); }
 // ... of the hi parts alone: x = hi + r, |r| <= 2^-9 |x|, |hi| <= (1 + 2^-9) |x|: what hi.hi' leaves out is at most
 // (2 2^-9 (1 + 2^-9) + 2^-18) sum |x_k| |c_k| <= 2.01 2^-9; d exact products accumulated (2^-23 each, worst case) + the fp32 path's d
-static float cos_band1(int d) { return 2.01f * 0x1p-9f + 2.0f * (float)d * 0x1p-23f * 1.01f; }
+static float cos_band1(int d) { return 2.01f * 0x1p-9f + 2.0f * (float)d * 0x1p-23f * 1.01f + cos_norm_slack(d); }
 
 // d_vector.py:310-313 — one workgroup per speaker, rows summed IN ROW ORDER into a float64 accumulator (fixed summation order, like
 // numpy's mean on the reference's float64 `avg`).  The label array is scanned 2048 rows at a time with independent coalesced loads;

@@ -131,10 +131,10 @@ __device__ __forceinline__ void fft_small(v2f (&z)[R]) {
 extern "C" __device__ float ssp_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");
 __device__ __forceinline__ v2f wmul_edge(v2f y, v2f w) { return v2f{ssp_fmul_legacy(y.x, w.x), ssp_fmul_legacy(y.y, w.y)}; }
 
-// window taps of the row that takes wmul_edge (row NZ - 1 of the 16 x 32 sample matrix, taps 32 (NZ - 1) + 2 j, + 1): the legacy
-// product must silence only the PADDING behind the window.  A tap of the window itself that is exactly zero (numpy.hanning's last
-// one: the sidekit dialects) lets a NaN sample through in numpy (0 . NaN = NaN, the frame is NaN there): the smallest normal number
-// stands in for such a tap — a finite sample times it is 1e-38 of the frame's scale, nothing; NaN and inf stay non-finite.
+// window taps of a row that takes wmul_edge (taps first_tap, first_tap + 1 of the 16 x 32 sample matrix): the legacy product must silence
+// only the PADDING behind the window.  A tap of the window itself that is exactly zero (numpy.hanning's ends: the sidekit dialects) lets a
+// NaN sample through in numpy (0 . NaN = NaN, the frame is NaN there): the smallest normal number stands in for such a tap — a finite
+// sample times it is 1e-38 of the frame's scale, nothing; NaN and inf stay non-finite.
 __device__ __forceinline__ v2f edge_row_taps(v2f w, int first_tap, int win_len) {
     if (first_tap < win_len && w.x == 0.f) w.x = 1.17549435e-38f;
     if (first_tap + 1 < win_len && w.y == 0.f) w.y = 1.17549435e-38f;

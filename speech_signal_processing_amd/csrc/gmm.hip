@@ -569,13 +569,13 @@ __global__ __launch_bounds__(256) void gmm_piece_reduce_kernel(const double* __r
 // core's internal order is undocumented, so 2^-23 per term) at most 6 D 2^-23 sum |W| |aug| (1 + 2^-7); the fp32 path's own 2 D terms
 // another 2 D 2^-23.  sum_j |W_kj| |aug_j| <= S(x) = sum_d |x_d| A_d + x_d^2 B_d with A_d = max |mu P|, B_d = max P / 2 over every mixture
 // of every model (packed once).  The log-sum-exp moves by at most the largest exponent error (it is 1-Lipschitz in the max norm) plus
-// its own evaluation noise (a few ulp of its magnitude on either path: 2^-20 (|score| + 1) covers both), the utterance mean by the mean:
+// its own evaluation noise (a few ulp of its magnitude on either path: 2^-20 (max_m |score_m| + 1) covers both), the utterance mean by the mean:
 //   |score_bf16x3 - score_fp32| <= eps mean_t S(x_t) + 2^-20 (|score| + 1),  eps = 3.01 2^-18 + 8 D 2^-23 1.01
 // and a margin between two models by twice that.  One workgroup per utterance.
 __global__ __launch_bounds__(256) void gmm_band_kernel(const float* __restrict__ feats, const int64_t* __restrict__ frame_off, int D,
                                                        const float* __restrict__ tab, float eps, const float* __restrict__ scores,
                                                        int n_models, float* __restrict__ band) {
-    __shared__ float red[4];
+    __shared__ float red[4], redm[4];
     const int u = blockIdx.x, tid = threadIdx.x;
     if (eps < 0.f) {  // the calibrated (heuristic) band
         if (tid == 0) band[u] = 8.0e-5f * (fabsf(scores[(size_t)u * n_models]) + 1.0f);
@@ -603,11 +603,18 @@ __global__ __launch_bounds__(256) void gmm_band_kernel(const float* __restrict__
         }
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
+    // the log-sum-exp noise term takes the LARGEST |score| of the utterance's row (a speaker model's score may be larger than model 0's)
+    float mg = 0.f;
+    for (int m = tid; m < n_models; m += 256) mg = fmaxf(mg, fabsf(scores[(size_t)u * n_models + m]));
+    for (int o = 32; o > 0; o >>= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = s;
+        redm[tid >> 6] = mg;
+    }
     __syncthreads();
     if (tid == 0) {
         const float S = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(T > 0 ? T : 1);
-        const float mag = fabsf(scores[(size_t)u * n_models]) + 1.0f;
+        const float mag = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])) + 1.0f;
         band[u] = 2.0f * (eps * S * 1.001f + 0x1p-20f * mag);
     }
 }
@@ -691,11 +698,11 @@ __global__ __launch_bounds__(256) void gmm_candidates_kernel(const int32_t* __re
 __global__ __launch_bounds__(64) void gmm_scatter_cand_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cand, int n_models,
                                                               int has_ubm, const float* __restrict__ sub_scores,
                                                               const int32_t* __restrict__ sub_argmax, float* __restrict__ scores,
-                                                              int32_t* __restrict__ argmax_out) {
+                                                              int32_t* __restrict__ argmax_out, int all_scored) {
     const int i = blockIdx.x, u = list[i], lane = threadIdx.x;
     const int32_t* c = cand + (size_t)i * GMM_CAND;
     const float* __restrict__ src = sub_scores + (size_t)i * n_models;
-    const int n = c[0];
+    const int n = all_scored ? -1 : c[0];  // (a re-scoring call that had to be cut scored every model: the whole fp32 row goes back)
     if (n < 0) {
         if (scores)
             for (int m = lane; m < n_models; m += 64) scores[(size_t)u * n_models + m] = src[m];
@@ -1006,7 +1013,7 @@ static void piece_table(const int64_t* h_off, int64_t u0, int64_t u1, int gran, 
 // `sub`: use the second buffer set (the re-scoring pass runs while the first set still holds the batch's tables).
 static int score_fused(ssp_gmm* gmm, const float* d_feats, const int64_t* h_off, const int64_t* d_off, int64_t n_utt, uint64_t seg_serial,
                        bool bf16, bool sub, float* d_sc, int32_t* d_am, float* d_margin, hipStream_t s,
-                       const int32_t* block_models = nullptr, int bl_stride = 0) {
+                       const int32_t* block_models = nullptr, int bl_stride = 0, bool* used_lists = nullptr) {
     const int M = gmm->n_models;
     const int gran = piece_granule(gmm, bf16);
     const size_t cap = [] {
@@ -1075,6 +1082,7 @@ static int score_fused(ssp_gmm* gmm, const float* d_feats, const int64_t* h_off,
         a.n_utt = (int32_t)(u1 - u0);
         // (workgroup-indexed model lists belong to a batch that runs as ONE launch; a call that had to be cut scores every model)
         a.block_models = (whole && !bf16) ? block_models : nullptr;
+        if (used_lists) *used_lists = a.block_models != nullptr;
         a.bl_stride = bl_stride;
         SSP_TRY(launch_kernel_any(gmm, a, bf16, true, s));
         hipLaunchKernelGGL(gmm_piece_reduce_kernel, dim3((unsigned)(u1 - u0)), dim3(256), (size_t)M * sizeof(float), s, partial.as<double>(),
@@ -1238,10 +1246,11 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
                 if (!d_sc) d_sc_work = gmm->sub_scores.as<float>();
                 float* sub_sc = gmm->sub_scores.as<float>() + work_rows * M;
                 SSP_TRY(gmm->sub_argmax.reserve((size_t)n_flag * sizeof(int32_t)));
+                bool used_lists = false;
                 SSP_TRY(score_fused(gmm, gmm->sub_feats.as<float>(), gmm->sub_off_host.data(), gmm->sub_off.as<int64_t>(), n_flag, 0, false, true,
-                                    sub_sc, gmm->sub_argmax.as<int32_t>(), nullptr, s, gmm->blk.as<int32_t>(), 1 + BL));
+                                    sub_sc, gmm->sub_argmax.as<int32_t>(), nullptr, s, gmm->blk.as<int32_t>(), 1 + BL, &used_lists));
                 hipLaunchKernelGGL(gmm_scatter_cand_kernel, dim3((unsigned)n_flag), dim3(64), 0, s, gmm->flag_list.as<int32_t>(),
-                                   gmm->cand.as<int32_t>(), M, gmm->has_ubm, sub_sc, gmm->sub_argmax.as<int32_t>(), d_sc, d_am);
+                                   gmm->cand.as<int32_t>(), M, gmm->has_ubm, sub_sc, gmm->sub_argmax.as<int32_t>(), d_sc, d_am, used_lists ? 0 : 1);
                 SSP_HIP(hipGetLastError());
             }
         }

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
     v2f wreg[NZ];
 #pragma unroll
     for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = *reinterpret_cast<const v2f*>(a.window + 32 * n1 + 2 * j);
-    wreg[NZ - 1] = edge_row_taps(wreg[NZ - 1], 32 * (NZ - 1) + 2 * j, a.win_len);
+#pragma unroll
+    for (int n1 = 0; n1 < NZ; ++n1) wreg[n1] = edge_row_taps(wreg[n1], 32 * n1 + 2 * j, a.win_len);
     // this lane's twiddles stay in registers: W_256^(k1 j) for the step between the two radix-16 passes and
     // W_512^(8j+1+i) for the split step (LDS is the busiest unit of this kernel; registers are not)
     v2f twr[15], wpr[8];
@@ -237,9 +238,11 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                     const float xm1 = pm[n1 < NZ ? n1 : 0], x0 = y.x, x1 = y.y;
                     y = v2f{__builtin_fmaf(npre, xm1, x0), __builtin_fmaf(npre, x0, x1)};
                 }
-                // (a zero weight silences whatever the sample holds — the rows run past the window's last tap into the samples behind the
-                //  frame: wmul_edge, cplx.hpp)
-                z[n1] = n1 == NZ - 1 ? wmul_edge(y, wreg[n1 < NZ ? n1 : 0]) : y * wreg[n1 < NZ ? n1 : 0];
+                // (a zero weight of the PADDING silences whatever the sample holds — rows run past the window's last tap into the samples behind
+                //  the frame, in windows shorter than 32 (NZ - 1) + 1 taps more rows than one: the legacy product, cplx.hpp, on every row of
+                //  this fallback kernel: one instruction per row more than the packed product.  The wave-stream kernel takes the plain
+                //  product and sends the chunks a leak shows up in to its second kernel.)
+                z[n1] = wmul_edge(y, wreg[n1 < NZ ? n1 : 0]);
             } else {
                 z[n1] = v2f{0.f, 0.f};
             }
