@@ -1,16 +1,20 @@
 """GPU-backed mirror of the MFCC wrappers of the reference's ``MFCC_DTW.py`` (lines 28-54).
 
-``load_train`` / ``load_test`` of the reference take ``mfcc_extract=`` (MFCC_DTW.py:122,155): pass ``_MFCC`` or
-``MFCC_lib`` from this module there.  The matcher (distance_dtw / distance_train / distance_test, MFCC_DTW.py:57-108, and the
+``load_train`` / ``load_test`` (MFCC_DTW.py:122-184) walk ``<path>/<speaker>/*.wav`` like the reference's, with its ``mfcc_extract=`` plug
+point: with this module's own ``_MFCC`` / ``MFCC_lib`` / ``MFCC`` every file of the directory tree goes through ONE batched kernel launch,
+any other callable is applied per file as the reference applies it.  The matcher (distance_dtw / distance_train / distance_test, MFCC_DTW.py:57-108, and the
 arg-min classification of test(), MFCC_DTW.py:187-217) runs as one all-pairs DTW kernel (api.dtw_distances)."""
 from __future__ import annotations
 
 import functools
+import os
+import random
 
 import numpy as np
 
 from . import api, frontend
-from .utils.processing import MFCC
+from .utils.processing import MFCC, MFCC_batch
+from .utils.tools import get_time, read
 
 
 @functools.lru_cache(maxsize=8)
@@ -29,6 +33,82 @@ def MFCC_lib(raw_signal, n_mfcc=13):
 def _MFCC(raw_signal):
     """MFCC_DTW.py:33-54 — MFCC(raw_signal, fs=8000, frameSize=512, step=256).flatten()."""
     return MFCC(raw_signal, fs=8000, frameSize=512, step=256).flatten()
+
+
+def MFCC_lib_batch(signals, n_mfcc=13):
+    """MFCC_lib over a list of signals in one kernel launch."""
+    sig = [np.ascontiguousarray(np.asarray(x).astype("float32").reshape(-1)) for x in signals]
+    plan = _librosa_plan(int(n_mfcc))
+    seg = api.Segments.from_lengths(plan.ctx, [x.shape[0] for x in sig])
+    fseg = plan.frame_segments(seg)
+    feats = np.asarray(plan.run(np.concatenate(sig) if sig else np.zeros(0, np.float32), seg, fseg))
+    return [feats[fseg.offsets[i]:fseg.offsets[i + 1]].flatten() for i in range(len(sig))]
+
+
+def _extract_all(signals, mfcc_extract):
+    """``mfcc_extract`` over every signal: this module's own extractors run batched (one launch), anything else per signal."""
+    if mfcc_extract is _MFCC:
+        return [f.flatten() for f in MFCC_batch(signals, fs=8000, frameSize=512, step=256)]
+    if mfcc_extract is MFCC:
+        return MFCC_batch(signals)  # (the reference's default arguments: fs=8000, frameSize=512, step=256)
+    if mfcc_extract is MFCC_lib:
+        return MFCC_lib_batch(signals)
+    return [mfcc_extract(x) for x in signals]
+
+
+def _read_8k(path):
+    """MFCC_DTW.py:137-145 / 170-178: the file's first channel (some recordings have two), every second sample (16 kHz -> 8 kHz)."""
+    _, data = read(path)
+    data = np.asarray(data)
+    if data.ndim > 1:
+        data = data[:, 0]
+    return data[range(0, data.shape[0], 2)]
+
+
+def sample(x, y, sample_num=2, whole_num=8):
+    """MFCC_DTW.py:110-118 — ``sample_num`` of every speaker's ``whole_num`` consecutive utterances (four speakers), the same random
+    positions for each."""
+    index = random.sample(range(whole_num), sample_num)
+    sample_x, sample_y = [], []
+    for i in range(4):
+        for _index in index:
+            sample_x.append(x[_index + whole_num * i])
+            sample_y.append(y[_index + whole_num * i])
+    return sample_x, sample_y
+
+
+def load_train(path='dataset/ASR/train', mfcc_extract=_MFCC):
+    """MFCC_DTW.py:122-152 — one template per speaker directory (in os.listdir order): every wav of the directory read, down-sampled
+    to 8 kHz, ``mfcc_extract``-ed, then generate_template over the speaker's feature sequences.  Returns (templates, labels)."""
+    start_time = get_time()
+    wav_dir = os.listdir(path)
+    signals, owner = [], []
+    print("Generate template according to train set.")
+    for k, _dir in enumerate(wav_dir):
+        for _path in os.listdir(os.path.join(path, _dir)):
+            signals.append(_read_8k(os.path.join(path, _dir, _path)))
+            owner.append(k)
+    feats = _extract_all(signals, mfcc_extract)
+    x, y_label = [], []
+    for k, _dir in enumerate(wav_dir):
+        x.append(generate_template([f for f, o in zip(feats, owner) if o == k]))
+        y_label.append(_dir)
+    print('Loading train data, extract mfcc feature and generate template spend {}s'.format(get_time(start_time)))
+    return x, y_label
+
+
+def load_test(path='dataset/ASR/test', mfcc_extract=MFCC, template=False):
+    """MFCC_DTW.py:155-184 — every wav under ``<path>/<speaker>/`` read, down-sampled to 8 kHz and ``mfcc_extract``-ed; the label of a
+    file is its directory.  (``template`` is accepted and ignored, as in the reference.)  Returns (features, labels)."""
+    start_time = get_time()
+    signals, y_label = [], []
+    for _dir in os.listdir(path):
+        for _path in os.listdir(os.path.join(path, _dir)):
+            signals.append(_read_8k(os.path.join(path, _dir, _path)))
+            y_label.append(_dir)
+    x = _extract_all(signals, mfcc_extract)
+    print('Loading test data and extract mfcc feature spend {}s'.format(get_time(start_time)))
+    return x, y_label
 
 
 def distance_dtw(sample_x, sample_y, show=False, dtw_method=1, dist=None, normalize=False):

@@ -124,28 +124,86 @@ def _resolve_model(model_name, spk_model, default_name):
     return model_name if hasattr(model_name, "predict") else load_model(model_name)
 
 
+@functools.lru_cache(maxsize=8)
+def _feature_plan(feature_type, sample_rate):
+    if feature_type == 'PLP':  # d_vector.py:92-93: plp(x, fs)[0]
+        return api.MfccPlan(api.default_context(), frontend.preset_sidekit_plp(fs=sample_rate))
+    if feature_type != 'MFCC':
+        raise NameError  # d_vector.py:94-95
+    return api.MfccPlan(api.default_context(), frontend.preset_sidekit(fs=sample_rate))
+
+
 class Data_gen:
     """Feature front end of d_vector.Data_gen: 1-second chunks -> sidekit mfcc(x, fs)[0] -> (98, 13) (d_vector.py:80-98)."""
 
     def __init__(self, sample_rate=16000):
         self.sample_rate = sample_rate
+        self.path = None  # the dataset directory of _load() (the reference's load_data sets it)
 
     @staticmethod
     def delta(feat, N=2):
         """d_vector.py:143-160 (identical to GMM_UBM.delta)."""
         return _delta(feat, N)
 
-    @functools.lru_cache(maxsize=4)
     def _plan(self, feature_type):
-        if feature_type == 'PLP':  # d_vector.py:92-93: plp(x, fs)[0]
-            return api.MfccPlan(api.default_context(), frontend.preset_sidekit_plp(fs=self.sample_rate))
-        if feature_type != 'MFCC':
-            raise NameError  # d_vector.py:94-95
-        return api.MfccPlan(api.default_context(), frontend.preset_sidekit(fs=self.sample_rate))
+        return _feature_plan(feature_type, int(self.sample_rate))  # (keyed on the rate too: _load() takes it from the files)
 
-    def extract_feature(self, x, y, feature_type='MFCC'):
-        """x: list of audio arrays, y: labels.  Cuts each audio into 1 s chunks (d_vector.py:80-83), extracts
-        MFCC per chunk, drops chunks whose features contain NaN (d_vector.py:97-98).  Returns (feature, label)."""
+    def _load(self):
+        """d_vector.py:34-57 — every wav under ``self.path/<speaker>/<dir>/``: (list of audio arrays, list of speaker names); the sample
+        rate of the files becomes ``self.sample_rate``."""
+        from .utils.tools import read
+        x, y = [], []
+        for speaker in os.listdir(self.path):
+            path1 = os.path.join(self.path, speaker)
+            for _dir in os.listdir(path1):
+                path2 = os.path.join(path1, _dir)
+                for _wav in os.listdir(path2):
+                    self.sample_rate, audio = read(os.path.join(path2, _wav))
+                    y.append(speaker)
+                    x.append(audio)
+        return x, y
+
+    @staticmethod
+    def save(data, file_name):
+        """d_vector.py:133-136"""
+        with open('feature/{}.pkl'.format(file_name), 'wb') as f:
+            pkl.dump(data, f)
+
+    @staticmethod
+    def load(file_name):
+        """d_vector.py:138-141"""
+        with open('feature/{}.pkl'.format(file_name), 'rb') as f:
+            return pkl.load(f)
+
+    def extract_feature(self, *args, feature_type='MFCC', datatype='dev'):
+        """Two call shapes.  The reference's (d_vector.py:59-118): ``extract_feature(feature_type='MFCC', datatype='dev')`` — audio from
+        ``self._load()`` (``self.path`` set by the caller, as ``load_data`` does), features cached under ``feature/<datatype>_<type>_*.pkl``
+        exactly as the reference caches them.  And the in-memory one: ``extract_feature(x, y, feature_type='MFCC')`` with x a list of audio
+        arrays and y their labels.  Either way every audio is cut into 1 s chunks (d_vector.py:80-83), all chunks go through ONE kernel
+        launch, and chunks whose features contain NaN are dropped (d_vector.py:97-98).  Returns (feature, label)."""
+        if args and not isinstance(args[0], str):
+            if len(args) < 2 or len(args) > 3:
+                raise TypeError("extract_feature(x, y, feature_type='MFCC') or extract_feature(feature_type='MFCC', datatype='dev')")
+            if len(args) == 3:
+                feature_type = args[2]
+            return self._extract(args[0], args[1], feature_type)
+        if len(args) > 2:
+            raise TypeError("extract_feature(feature_type='MFCC', datatype='dev')")
+        if len(args) >= 1:
+            feature_type = args[0]
+        if len(args) == 2:
+            datatype = args[1]
+        if not os.path.exists('feature'):
+            os.mkdir('feature')
+        if os.path.exists('feature/{}_{}_feature.pkl'.format(datatype, feature_type)):
+            return self.load('{}_{}_feature'.format(datatype, feature_type)), self.load('{}_{}_label'.format(datatype, feature_type))
+        x, y = self._load()
+        feature, label = self._extract(x, y, feature_type)
+        self.save(feature, '{}_{}_feature'.format(datatype, feature_type))
+        self.save(label, '{}_{}_label'.format(datatype, feature_type))
+        return feature, label
+
+    def _extract(self, x, y, feature_type='MFCC'):
         plan = self._plan(feature_type)
         sr = self.sample_rate
         chunks, labels = [], []
@@ -177,7 +235,12 @@ class nn_model:
     stand-in for load_model('feature/d_vector/d_vector_{}.h5')) is given.  ``store``: path of the enrolment dictionary pickle
     (the reference always uses 'feature/d_vector/d_vector.pkl', d_vector.py:333-344,350-351); None keeps it in memory."""
 
-    def __init__(self, store=None):
+    def __init__(self, n_class=40, store=None):
+        # (n_class: the reference's only constructor argument, d_vector.py:165 — the width of the training network's softmax; the inference
+        #  half kept here never reads it, but nn_model(n_class=40) and nn_model(40) must construct)
+        if isinstance(n_class, (str, os.PathLike)) and store is None:  # (round 4's signature: nn_model('path.pkl'))
+            n_class, store = 40, n_class
+        self.n_class = n_class
         self.store = store
         self.d_vector = {}  # name -> mean embedding, the dict the reference pickles (d_vector.py:333-344)
 

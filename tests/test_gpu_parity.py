@@ -6,6 +6,8 @@ Tolerances (BASELINE.json north_star: "MFCC and log-likelihoods within 1e-4 rel 
   scores   : |gpu-ref| <= 1e-4 * |ref|
   argmax / argmin : exact
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -449,7 +451,7 @@ def test_partially_silent_utterances_in_a_machine_filling_batch(ssp, order, cmvn
         np.testing.assert_allclose(got[u], got[u % 7 + 7], rtol=0, atol=2e-4 * max(1.0, float(np.abs(got[u % 7 + 7]).max())))
 
 
-@pytest.mark.parametrize("dialect", ["librosa", "inrepo2048", "sidekit", "plp"])
+@pytest.mark.parametrize("dialect", ["librosa", "inrepo2048", "sidekit", "sidekit_short", "plp"])
 def test_nan_sample_stays_in_its_frames(ssp, dialect):
     """A NaN sample (a corrupt recording) in a ragged batch of short and long utterances (multi-chunk work tables): in the reference's
     arithmetic every frame that holds it is NaN — plus the deltas' reach; with librosa's power_to_db the whole utterance, because
@@ -462,12 +464,15 @@ def test_nan_sample_stays_in_its_frames(ssp, dialect):
         "librosa": lambda: (pkg.preset_librosa(16000, 13), O.librosa_tables(16000, 13), 16000),
         "inrepo2048": lambda: (pkg.preset_inrepo(16000, 2048, 512), O.inrepo_tables(16000, 2048, 512), 16000),
         "sidekit": lambda: (pkg.preset_sidekit(delta_order=2), O.sidekit_tables(delta_order=2), 16000),
+        # an 18 ms window: 288 taps, FOUR of the 512-point kernels' thirteen 32-sample rows are padding (round 4 excepted such windows)
+        "sidekit_short": lambda: (pkg.preset_sidekit(nwin=0.018, delta_order=2), O.sidekit_tables(nwin=0.018, delta_order=2), 16000),
         "plp": lambda: (pkg.preset_sidekit_plp(), O.sidekit_plp_tables(), 16000)}[dialect]()
     rng = np.random.default_rng(3)
     lens = [1025, 1025, 200000, 1025, 3000, 1025, 1025, 200000, 1025, 5000]
     # (2, 1999) / (2, 1600): the LAST and the FIRST tap of frame 10 of the sidekit dialects — numpy.hanning is exactly zero there, and
     # 0 . NaN = NaN in numpy: the frame is NaN although the weight is zero (the kernels silence only the padding BEHIND the window)
-    for where in (None, (2, 5000), (0, 500), (4, 2326), (7, 199999), (9, 2805), (2, 399 + 160 * 10), (2, 160 * 10)):
+    # (2, 1900): 12 samples behind frame 10's window in the 18 ms dialect (frame 10 = samples 1600 .. 1887), inside its padded rows
+    for where in (None, (2, 5000), (0, 500), (4, 2326), (7, 199999), (9, 2805), (2, 399 + 160 * 10), (2, 160 * 10), (2, 1900)):
         sigs = [(0.3 * rng.standard_normal(l)).astype(np.float32) for l in lens]
         if where is not None:
             sigs[where[0]][where[1]] = np.nan
@@ -475,7 +480,7 @@ def test_nan_sample_stays_in_its_frames(ssp, dialect):
         with np.errstate(all="ignore"):
             for x in sigs:
                 refs.append(O.mfcc_pipeline(x, cfg, w, fb, dct))
-        for variant in (0, 1):
+        for variant in ((0, 1, 2, 3) if dialect.startswith("sidekit") else (0, 1)):
             got, _ = _run_plan(api, tables, sigs, variant=variant)
             for u in range(len(sigs)):
                 fin = np.isfinite(refs[u])
@@ -2050,3 +2055,38 @@ def test_handles_may_outlive_their_context(ssp):
     for h in (plan, seg, fseg, sc, net):      # ... then everything that was created on it
         h.close()
     ctx.close()                               # (idempotent)
+
+
+@pytest.mark.gpu
+def test_mfcc_dtw_loaders_batch_the_packages_own_extractors(ssp, tmp_path):
+    """MFCC_DTW.load_train / load_test (MFCC_DTW.py:122-184) with this package's own extractors: every file of the tree through ONE launch,
+    the same numbers as the per-file calls the reference makes; load_train's templates = generate_template over a speaker's sequences."""
+    import wave
+    from speech_signal_processing_amd import MFCC_DTW
+    rng = np.random.default_rng(5)
+    files = {}
+    for spk in ("s1", "s2", "s3", "s4"):
+        (tmp_path / "train" / spk).mkdir(parents=True)
+        (tmp_path / "test" / spk).mkdir(parents=True)
+        for part, n in (("train", 3), ("test", 2)):
+            for i in range(n):
+                x = (4000 * rng.standard_normal(8000 + 512 * i + 100 * len(spk))).astype("<i2")
+                with wave.open(str(tmp_path / part / spk / ("%d.wav" % i)), "wb") as w:
+                    w.setnchannels(1), w.setsampwidth(2), w.setframerate(16000)
+                    w.writeframes(x.tobytes())
+                files[(part, spk, i)] = x[::2]
+    for ext in (MFCC_DTW._MFCC, MFCC_DTW.MFCC, MFCC_DTW.MFCC_lib):
+        x, y = MFCC_DTW.load_test(str(tmp_path / "test"), mfcc_extract=ext)
+        assert len(x) == 8 and sorted(set(y)) == ["s1", "s2", "s3", "s4"]
+        order = [(spk, name) for spk in os.listdir(tmp_path / "test") for name in os.listdir(tmp_path / "test" / spk)]
+        for f, (spk, name) in zip(x, order):
+            one = ext(files[("test", spk, int(name[0]))])
+            assert f.shape == one.shape
+            np.testing.assert_allclose(f, one, rtol=0, atol=1e-5 * max(1.0, float(np.abs(one).max())))
+    tpl, lab = MFCC_DTW.load_train(str(tmp_path / "train"))
+    assert lab == os.listdir(tmp_path / "train") and len(tpl) == 4
+    for t, spk in zip(tpl, lab):
+        seqs = [MFCC_DTW._MFCC(files[("train", spk, int(name[0]))]) for name in os.listdir(tmp_path / "train" / spk)]
+        np.testing.assert_allclose(t, MFCC_DTW.generate_template(seqs), rtol=0, atol=1e-4 * max(1.0, float(np.abs(t).max())))
+    d, pred = MFCC_DTW.classify(MFCC_DTW.load_test(str(tmp_path / "test"), mfcc_extract=MFCC_DTW._MFCC)[0], tpl, lab)
+    assert d.shape == (8, 4) and len(pred) == 8

@@ -270,3 +270,59 @@ def test_flop_count_script_matches_known_transform_counts():
     r = fc.count()
     assert r["flop_per_frame"] == 11300 and r["ops_per_frame"] == 8917 and abs(r["fma_fraction_of_peak"] - 0.634) < 1e-3
     assert r["stages"]["real FFT (pruned, N/2 complex + split)"]["flop"] == 7684   # the published real split-radix count is the smaller one
+
+
+def _write_wav(path, data, rate=16000):
+    import wave
+    data = np.asarray(data)
+    ch = 1 if data.ndim == 1 else data.shape[1]
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(ch)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes(np.ascontiguousarray(data.astype("<i2")).tobytes())
+
+
+def test_mfcc_dtw_load_test_walks_the_tree_like_the_reference(tmp_path):
+    """MFCC_DTW.load_test (MFCC_DTW.py:155-184): <path>/<speaker>/*.wav, first channel of a stereo file, every second sample, the label
+    of a file is its directory; a caller's own mfcc_extract is applied per file (this module's own go through one batched launch, which
+    needs the GPU: tests/test_gpu_parity.py)."""
+    from speech_signal_processing_amd import MFCC_DTW
+    rng = np.random.default_rng(0)
+    want = {}
+    for spk, n in (("anna", 2), ("ben", 1)):
+        (tmp_path / spk).mkdir()
+        for i in range(n):
+            mono = (3000 * rng.standard_normal(400 + 37 * i)).astype(np.int16)
+            data = np.stack([mono, -mono], axis=1) if (spk, i) == ("anna", 1) else mono
+            _write_wav(tmp_path / spk / ("u%d.wav" % i), data)
+            want[(spk, "u%d.wav" % i)] = mono[::2]
+    seen = []
+    x, y = MFCC_DTW.load_test(str(tmp_path), mfcc_extract=lambda a: (seen.append(np.asarray(a).copy()), np.asarray(a, dtype=np.float64)[:5])[1])
+    assert sorted(y) == ["anna", "anna", "ben"] and len(x) == 3 and all(v.shape == (5,) for v in x)
+    got = sorted(a.tobytes() for a in seen)
+    assert got == sorted(v.tobytes() for v in want.values())
+    sx, sy = MFCC_DTW.sample(list(range(32)), [i // 8 for i in range(32)], sample_num=2, whole_num=8)
+    assert len(sx) == 8 and sy == [0, 0, 1, 1, 2, 2, 3, 3] and [v % 8 for v in sx[:2]] == [v % 8 for v in sx[2:4]]
+
+
+def test_d_vector_constructors_take_the_reference_arguments(tmp_path, monkeypatch):
+    """d_vector.nn_model(n_class=40) (d_vector.py:165) constructs, positionally too; the store stays a keyword (or round 4's positional
+    path).  Data_gen.extract_feature(feature_type, datatype) — the reference's signature (d_vector.py:59) — serves a cached
+    feature/<datatype>_<type>_*.pkl pair without touching audio or the GPU, like the reference does."""
+    from speech_signal_processing_amd import d_vector
+    assert d_vector.nn_model(n_class=40).n_class == 40 and d_vector.nn_model(17).n_class == 17
+    m = d_vector.nn_model(str(tmp_path / "d.pkl"))
+    assert m.store == str(tmp_path / "d.pkl") and m.n_class == 40
+    assert d_vector.nn_model(n_class=3, store="x.pkl").store == "x.pkl"
+    monkeypatch.chdir(tmp_path)
+    gen = d_vector.Data_gen()
+    (tmp_path / "feature").mkdir()
+    gen.save([np.ones((98, 13))], "dev_MFCC_feature")
+    gen.save(["spk"], "dev_MFCC_label")
+    f, lab = gen.extract_feature(feature_type="MFCC", datatype="dev")
+    assert lab == ["spk"] and f[0].shape == (98, 13)
+    f2, lab2 = gen.extract_feature("MFCC", "dev")
+    assert lab2 == ["spk"]
+    with pytest.raises(TypeError):
+        gen.extract_feature([np.zeros(16000)])
