@@ -213,7 +213,7 @@ def cpu_baseline_plp(n_samp, fs, budget_s=4.0):
                       "%d-sample utterances, one process, %.1f s" % (n_samp, dt)}
 
 
-def kernel_source_sha256(names=("mfcc_stream.hip", "cplx.hpp", "mfcc.hpp", "common.hpp")):
+def kernel_source_sha256(names=("mfcc_stream_kernel.hpp", "mfcc_stream.hip", "cplx.hpp", "mfcc.hpp", "common.hpp")):
     """identity of the headline kernel's source: the PMC files under profiles/ record the value they were taken on, and a counter
     reading is only quoted for the binary built from the same source"""
     import hashlib
@@ -496,7 +496,7 @@ def main():
                    "backend": (dist.get_backend() if world > 1 else None), "kernel_ms_per_rank": per_rank_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "mfcc_stream512_kernel" if args.variant in (0, 3) else "mfcc fused pass", "kernel_ms": ms_kernel,
+                     "kernel": "mfcc_stream512_kernel<13,2,1,3,6,2,3,0,0> (+ its second kernel <...,1>: no chunk flagged, exits on one load)" if args.variant in (0, 3) else "mfcc fused pass", "kernel_ms": ms_kernel,
                      "kernel_ms_stat": "median of the timed launches (hipEvents on the launch stream)",
                      "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame},
         "roofline_flop": flop_roof,

@@ -86,13 +86,13 @@ for st, (kern, key) in DOM.items():
 
 
 # ---- PMC
-def pmc(prefix, kern):
+def pmc(prefix, kern, also=""):
     agg = collections.OrderedDict()
     i = 1
     while have("pmc_%s_%d.csv" % (prefix, i)):
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(os.path.join(S, "pmc_%s_%d.csv" % (prefix, i)))):
-            if kern in r["Kernel_Name"]:
+            if kern in r["Kernel_Name"] and also in r["Kernel_Name"]:
                 per[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in per.items():
             agg[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
@@ -100,7 +100,7 @@ def pmc(prefix, kern):
     return agg
 
 
-a = pmc("512", "mfcc_stream512")
+a = pmc("512", "mfcc_stream512", ", 0>(")  # (the first kernel of the launch: <..., WALK = 0>; the second exits on one load)
 if a:
     line = json.load(open(os.path.join(S, "stage_mfcc_bench_line.json"))) if have("stage_mfcc_bench_line.json") else None
     algo = 23848800000
@@ -108,7 +108,7 @@ if a:
     rd = 2.0 * g("FETCH_SIZE") * 1024 if g("FETCH_SIZE") is not None else None
     wr = g("WRITE_SIZE") * 1024 if g("WRITE_SIZE") is not None else None
     if rd is not None and wr is not None:
-        doc = {"kernel": "ssp::mfcc_stream512_kernel<13,2,1,3,6,2,3,0> (wave-stream, 3 workgroups per CU)", "round": R, "git": git, "kernel_source_sha256": sha,
+        doc = {"kernel": "ssp::mfcc_stream512_kernel<13,2,1,3,6,2,3,0,0> (wave-stream, 3 workgroups per CU)", "round": R, "git": git, "kernel_source_sha256": sha,
                "workload": "configs[1]: 100000 x 3 s @16 kHz, 39-d",
                "command": "tools/profile_round.sh %s pmc512  (rocprofv3 --pmc <counter group> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --stages mfcc --no-cpu-baseline; one pass per counter group; mean over the kernel's launches of the pass)" % R,
                "raw": {k: v["mean_per_launch"] for k, v in a.items() if k.startswith(("FETCH", "WRITE", "TCC"))},
@@ -124,7 +124,7 @@ if a:
         cf = os.path.join(S, "isa_census.json")
         if os.path.exists(cf):
             census = json.load(open(cf))
-        doc = {"kernel": "ssp::mfcc_stream512_kernel<13,2,1,3,6,2,3,0>", "round": R, "git": git, "kernel_source_sha256": sha,
+        doc = {"kernel": "ssp::mfcc_stream512_kernel<13,2,1,3,6,2,3,0,0>", "round": R, "git": git, "kernel_source_sha256": sha,
                "workload": "configs[1] at FULL size: 100000 x 3 s @16 kHz per pass (7.5e6 quads of 4 frames), 39-d",
                "command": "tools/profile_round.sh %s pmc512" % R,
                "raw_per_launch": {k: v["mean_per_launch"] for k, v in a.items() if k.startswith(("SQ_", "GRBM"))},
