@@ -326,3 +326,27 @@ def test_d_vector_constructors_take_the_reference_arguments(tmp_path, monkeypatc
     assert lab2 == ["spk"]
     with pytest.raises(TypeError):
         gen.extract_feature([np.zeros(16000)])
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under speech_signal_processing_amd/ (Python or C++) names it, and in bench.py /
+    __graft_entry__.py only the cpu_baseline_* legs and smoke() import it"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "speech_signal_processing_amd")
+    for dp, _, files in os.walk(pkg):
+        if "_obj" in dp or "__pycache__" in dp:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dp, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dp, f)  # (comments may cite it)
+                assert not re.search(r"(dlopen|LoadLibrary|CDLL)\([^)]*oracle", text), os.path.join(dp, f)
+    bench = open(os.path.join(root, "bench.py")).read()
+    for m in re.finditer(r"from oracle import", bench):
+        head = bench[:m.start()]
+        fn = re.findall(r"^def (\w+)\(", head, re.M)[-1]
+        assert fn.startswith("cpu_baseline"), fn
+    entry = open(os.path.join(root, "__graft_entry__.py")).read()
+    for m in re.finditer(r"from oracle import|import oracle", entry):
+        fn = re.findall(r"^def (\w+)\(", entry[:m.start()], re.M)[-1]
+        assert fn == "smoke", fn

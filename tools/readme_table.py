@@ -6,11 +6,13 @@ rows = []
 r = d["roofline"]
 rows.append(("fused 39-d MFCC, 100k × 3 s utterances resident in HBM (configs[1]; wave-stream kernel, software-pipelined quad loop, DCT / Δ / ΔΔ on the matrix cores)",
              "%.3g frames/s (%.2f ms/pass)" % (d["value"], r["kernel_ms"]),
-             "%.2f of 8 TB/s HBM; HBM traffic %s × algorithmic (`profiles/mfcc_hbm_traffic.json`); %s of the 157.3 TFLOP/s packed-FMA vector peak on %s counted flop per frame (`tools/flop_count.py`), %s of the add / multiply-mix-weighted peak; the pass holds 1.96 GHz on the 1400 W package cap (`profiles/r03_clock_power.md`)" % (
+             "%.2f of 8 TB/s HBM; HBM traffic %s × algorithmic (`profiles/mfcc_hbm_traffic.json`); %s of the 157.3 TFLOP/s packed-FMA vector peak on %s counted flop per frame (`tools/flop_count.py`), %s of the add / multiply-mix-weighted peak; the pass holds %s GHz at %s W of the 1400 W package cap (the line's `env.sustained_mfcc`)" % (
                  r["frac"], ("%.3f" % (r["traffic"] / r["algorithmic_bytes_per_launch"])) if r.get("traffic") else "n/a",
                  ("%.2f" % d["roofline_flop"]["frac"]) if (d.get("roofline_flop") or {}).get("frac") else "n/a",
                  (d.get("roofline_flop") or {}).get("flop_per_frame", "n/a"),
-                 ("%.2f" % d["roofline_flop"]["frac_mix_weighted"]) if (d.get("roofline_flop") or {}).get("frac_mix_weighted") else "n/a")))
+                 ("%.2f" % d["roofline_flop"]["frac_mix_weighted"]) if (d.get("roofline_flop") or {}).get("frac_mix_weighted") else "n/a",
+                 ("%.2f" % (d["env"]["sustained_mfcc"]["sclk_mhz"]["mean"] / 1e3)) if "env" in d and "sustained_mfcc" in d["env"] and "sclk_mhz" in d["env"]["sustained_mfcc"] else "n/a",
+                 ("%.0f" % d["env"]["sustained_mfcc"]["power_w"]["mean"]) if "env" in d and "sustained_mfcc" in d["env"] and "power_w" in d["env"]["sustained_mfcc"] else "n/a")))
 v = d["mfcc_ref26_cmvn"]
 rows.append(("the reference's `extract_feature` output: 13 cepstra + Δ, scaled per utterance (26-d), scaling inside the same kernel at three waves per SIMD",
              "%.3g frames/s (%.1f ms)" % (v["value"], v["roofline"]["kernel_ms"]), "%.2f of HBM" % v["roofline"]["frac"]))
@@ -34,6 +36,14 @@ if "gmm_bf16x3_proven_band" in d:
     v = d["gmm_bf16x3_proven_band"]
     rows.append(("same with the PROVEN error bound as the band (`ssp_gmm_score` precision 1: %d of %d listed; arg-max mismatches against fp32: %d)" % (v["utterances_rescored_in_fp32"], v["utterances"], v["argmax_mismatches_vs_fp32_path"]),
                  "%.2g frame-scores/s (%.1f ms)" % (v["value"], v["kernel_ms"]), "%.2f of the dense bf16 peak on algorithmic FLOPs" % v["roofline"]["frac"]))
+if "gmm_bf16x3_close_calls" in d:
+    pts = d["gmm_bf16x3_close_calls"]["points"]
+    rows.append(("same shape OFF the best case: speaker means at %s std from the UBM's (0.3 above) — share of utterances listed for fp32 re-scoring, proven band / heuristic band; arg-max mismatches against fp32: %d" % (
+                     " / ".join("%g" % p["speaker_offset_std"] for p in pts), sum(p[k]["argmax_mismatches_vs_fp32_path"] for p in pts for k in ("proven_band", "heuristic_band"))),
+                 "proven %s ms (%s listed); heuristic %s ms (%s); fp32 path %.0f ms" % (
+                     " / ".join("%.1f" % p["proven_band"]["kernel_ms"] for p in pts), " / ".join("%.0f %%" % (100 * p["proven_band"]["fraction_rescored"]) for p in pts),
+                     " / ".join("%.1f" % p["heuristic_band"]["kernel_ms"] for p in pts), " / ".join("%.2g %%" % (100 * p["heuristic_band"]["fraction_rescored"]) for p in pts),
+                     pts[0]["fp32_kernel_ms"]), "—"))
 c3 = d["gmm_cfg3_shape"]
 fs = c3.get("bf16x3_full_share")
 rows.append(("configs[3] model shape (K = 512, 1251 speakers + UBM): 12 000 utterances per GPU fp32 / bf16×3" + ("; the FULL per-GPU share (150 000 utterances) on bf16×3, measured" if fs else ""),
@@ -50,6 +60,14 @@ if "cosine_bf16x3" in d:
                  + ("; the cascade with a bf16 sweep in front (equal: %s; rows to later stages: %d / %d — well-separated synthetic embeddings)" % (c["argmin_equals_fp32_path"], c["rows_to_bf16x3"], c["rows_rescored_fp32"]) if c else ""),
                  "%.2g pair-scores/s (%.2f ms)" % (v["value"], v["roofline"]["kernel_ms"]) + ("; %.2g (%.2f ms)" % (c["value"], c["roofline"]["kernel_ms"]) if c else ""),
                  "%.2f of the dense bf16 peak executed (%.2f algorithmic)" % (v["roofline"]["frac_executed"], v["roofline"]["frac"]) + ("; cascade %.2f algorithmic" % c["roofline"]["frac"] if c else "")))
+if "cosine_close_calls" in d:
+    pts = d["cosine_close_calls"]["points"]
+    rows.append(("same shape OFF the best case: embedding noise %s (0.7 above) — rows the cascade hands to its second / third stage; arg-min equal to fp32 on every row: %s" % (
+                     " / ".join("%g" % p["embedding_noise"] for p in pts), all(p[k]["argmin_equals_fp32_path"] for p in pts for k in ("bf16x3", "cascade"))),
+                 "cascade %s ms (%s to bf16×3, %s to fp32); bf16×3 alone %s ms; fp32 path %.1f ms" % (
+                     " / ".join("%.2f" % p["cascade"]["kernel_ms"] for p in pts), " / ".join("%.1f %%" % (100 * p["cascade"]["fraction_to_bf16x3"]) for p in pts),
+                     " / ".join("%.2f %%" % (100.0 * p["cascade"]["rows_rescored_fp32"] / p["rows"]) for p in pts),
+                     " / ".join("%.2f" % p["bf16x3"]["kernel_ms"] for p in pts), pts[0]["fp32_kernel_ms"]), "—"))
 v = d["dvector_dnn"]
 rows.append(("d-vector network forward 1274→256×4 (one packed object, hidden layers chained in registers), 5e5 embeddings", "%.2g embeddings/s (%.1f ms)" % (v["value"], v["kernel_ms"]), "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
 v = d["dvector_pipeline"]
