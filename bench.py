@@ -665,10 +665,11 @@ def main():
                          "kernel_ms": g1_ms, "algorithmic_flop_per_launch": flop, "executed_mfma_flop_per_launch": 3 * flop * 80.0 / 78.0},
         }
         result["gmm_bf16x3"]["band"] = "calibrated (heuristic): 8e-5 (|UBM score| + 1) — ssp_gmm_score precision 3"
+        result["gmm_bf16x3"]["precision"] = 3  # (until round 3 this key measured precision 1, then the only band)
         result["gmm_bf16x3_proven_band"] = {
             "metric": "GMM frame-scores/s, bf16x3 MFMA + fp32 re-scoring of every utterance whose top-2 margin is inside the PROVEN error bound (ssp_gmm_score precision 1)",
             "value": fscores / gp_elapsed, "unit": "frame-scores/s", "kernel_ms": gp_ms, "dtype": "bf16x3->f32",
-            "utterances_rescored_in_fp32": int(n_rescored_proven), "utterances": int(n_utt),
+            "utterances_rescored_in_fp32": int(n_rescored_proven), "utterances": int(n_utt), "precision": 1,
             "argmax_mismatches_vs_fp32_path": int((r0["argmax"] != rp["argmax"]).sum().item()),
             "roofline": {"bound": "mfma", "achieved": flop / (gp_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": flop / (gp_ms * 1e-3) / 1e12 / 2500.0, "traffic": None, "kernel_ms": gp_ms, "algorithmic_flop_per_launch": flop}}
@@ -817,14 +818,18 @@ def main():
         am0 = rc["argmin"].clone()
         r16 = api.cosine_identify(ctx, X, Cn, precision=1)
         ms16 = []
+        torch.cuda.synchronize()
+        tw0 = time.perf_counter()
         for _ in range(c_steps):
             r16 = api.cosine_identify(ctx, X, Cn, timing=True, precision=1)
             ms16.append(r16["kernel_ms"])
+        torch.cuda.synchronize()
+        wall16 = (time.perf_counter() - tw0) / c_steps * 1e3  # (what a caller waits: per-call list / image allocation and the end-of-call sync included)
         c16 = float(np.mean(ms16))
         result["cosine_bf16x3"] = {
             "metric": "cosine pair-scores/s, split precision (bf16 x 3 MFMA + fp32 re-scoring of close calls), arg-min only", "value": N * S / (c16 * 1e-3),
             "unit": "pair-scores/s", "dtype": "bf16x3 (fp32 accumulate)", "argmin_equals_fp32_path": bool((r16["argmin"] == am0).all().item()),
-            "rows_rescored_fp32": int(r16["rescored"]), "speedup_vs_fp32": c_ms / c16,
+            "rows_rescored_fp32": int(r16["rescored"]), "speedup_vs_fp32": c_ms / c16, "precision": 1, "wall_ms_per_call": wall16,
             "roofline": {"bound": "mfma", "achieved": flop / (c16 * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": flop / (c16 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, "frac_executed": 3.0 * flop / (c16 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
                          "traffic": None, "kernel": "cosine_bf16x3_kernel<16> + cosine_reg_kernel<32> on the listed rows", "kernel_ms": c16,
@@ -833,14 +838,18 @@ def main():
         # bf16 x 3 sweep, that one's to fp32.  How many rows each later stage takes depends on the data (here: well-separated embeddings)
         rcs = api.cosine_identify(ctx, X, Cn, precision=2)
         msc = []
+        torch.cuda.synchronize()
+        tw0 = time.perf_counter()
         for _ in range(c_steps):
             rcs = api.cosine_identify(ctx, X, Cn, timing=True, precision=2)
             msc.append(rcs["kernel_ms"])
+        torch.cuda.synchronize()
+        wallc = (time.perf_counter() - tw0) / c_steps * 1e3
         cc = float(np.mean(msc))
         result["cosine_bf16_cascade"] = {
             "metric": "cosine pair-scores/s, cascade (bf16 sweep -> bf16 x 3 on its close calls -> fp32 on theirs), arg-min only", "value": N * S / (cc * 1e-3),
             "unit": "pair-scores/s", "dtype": "bf16 / bf16x3 / f32 (fp32 accumulate)", "argmin_equals_fp32_path": bool((rcs["argmin"] == am0).all().item()),
-            "rows_to_bf16x3": int(rcs["split_rows"]), "rows_rescored_fp32": int(rcs["rescored"]), "speedup_vs_fp32": c_ms / cc,
+            "rows_to_bf16x3": int(rcs["split_rows"]), "rows_rescored_fp32": int(rcs["rescored"]), "speedup_vs_fp32": c_ms / cc, "precision": 2, "wall_ms_per_call": wallc,
             "data_dependence": "synthetic embeddings with a smallest top-2 cosine gap of 0.44: no row needs a later stage; on data with closer "
                                "calls the later stages take the rows inside 8e-3 / 2.7e-4",
             "roofline": {"bound": "mfma", "achieved": flop / (cc * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",

@@ -19,7 +19,7 @@ tot={}
 for f in sorted(glob.glob('$R/gpurun_out/pmck_${tag}_*/*/*_counter_collection.csv')):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if kn in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+        if kn in r['Kernel_Name'] and '${PMC_ALSO:-}' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in agg.items():
         tot[k]=sum(v)/len(v)
         print(k, '%.5g'%(sum(v)/len(v)), 'n=%d'%len(v))
