@@ -92,10 +92,10 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
     // W_512^(j + 16 i) resident for i < NWP and times W_8 above; that pays for the DCT matrix as resident MFMA A operand
     // (lane (ceps = j, kq = g), k-step s <-> filter KS g + s)
 #ifndef SSP_STREAM_NTW
-#define SSP_STREAM_NTW 12  // resident twiddles W_256^(k1 j), k1 <= NTW (the largest sets that leave no spill inside the loop; a spill
+#define SSP_STREAM_NTW 15  // resident twiddles W_256^(k1 j), k1 <= NTW (all of them since the unit is compiled without the SLP vectorizer — build.py —; 12 before: the largest sets that leave no spill inside the loop; a spill
 #endif                     // reload there waits on vmcnt behind the sample DMA and exposes its whole latency every quad)
 #ifndef SSP_STREAM_NTW_CM
-#define SSP_STREAM_NTW_CM 9   // ... of the instances that also carry the column sums of the scaling (CM)
+#define SSP_STREAM_NTW_CM 12  // ... of the instances that also carry the column sums of the scaling (CM); 9 with the SLP vectorizer
 #endif
 #ifndef SSP_STREAM_NWP
 #define SSP_STREAM_NWP 8   // resident split twiddles

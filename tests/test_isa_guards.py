@@ -4,6 +4,7 @@ loop — must not come back unnoticed.  Each check compiles ONE small source to 
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -17,6 +18,9 @@ def _isa(src, tmp_path, extra=(), with_depth=False):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
     out = str(tmp_path / (src + ".s"))
+    sys.path.insert(0, ROOT)
+    from speech_signal_processing_amd.build import SOURCE_FLAGS  # (the per-source flags of the shipped build: the guards read what ships)
+    extra = tuple(SOURCE_FLAGS.get(src, [])) + tuple(extra)
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-munsafe-fp-atomics", "-Wno-pass-failed", *extra,
                         "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
