@@ -279,15 +279,16 @@ int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, cons
  * cosines; rows whose two best are closer than twice a PROVEN bound on |cos(bf16x3) - cos(fp32 path)| for unit vectors
  * (3.01 * 2^-18 + 4 d 2^-23 + (d + 8) 2^-24, the last term for the two paths' different normalisation roundings: cosine.hip cos_band),
  * and every row that meets a NaN or a zero norm, are scored again by the fp32 kernel from a device-side list (no host round trip in
- * between; the call ends with a stream synchronisation — it reads the list counts back for the diagnostics below — so it cannot be
- * captured in a graph).  argmin_out is therefore the fp32 path's on EVERY row; min_out is within the bound
+ * between; with device pointers the call is asynchronous on the ctx stream — its scratch lives on the ctx — and the diagnostics
+ * below fetch their counts when asked).  argmin_out is therefore the fp32 path's on EVERY row; min_out is within the bound
  * of it (exact on the re-scored rows).  precision 2: a cascade — a sweep on the hi parts alone (one product per k-step, bound
  * 2.01 * 2^-9 + 2 d 2^-23 + (d + 8) 2^-24 = 4e-3) first, its close calls to the bf16x3 sweep, that one's to fp32: the same arg-min guarantee, three times
  * fewer matrix instructions on well-separated data (how many rows each later stage takes depends on the data); min_out is then only within
  * 4e-3 of the fp32 path's on rows the first sweep decided.  Arg-min / minimum only: dist_out must be NULL; d <= 256. */
 int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,
                          int32_t* argmin_out, float* min_out, int where, int precision, float* kernel_ms);
-/* diagnostics: rows the last precision >= 1 call scored again in fp32; rows its precision-2 cascade handed to the bf16x3 sweep */
+/* diagnostics: rows the last precision >= 1 call scored again in fp32; rows its precision-2 cascade handed to the bf16x3 sweep
+ * (these wait for the ctx stream when the counts of a device-pointer call have not been read yet) */
 int ssp_cosine_last_rescored(const ssp_ctx* ctx, int32_t* n_out);
 int ssp_cosine_last_split_rows(const ssp_ctx* ctx, int32_t* n_out);
 

@@ -634,12 +634,13 @@ class DnnForward:
 
 
 def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True, minval: bool = True,
-                    timing: bool = False, precision: int = 0) -> dict:
+                    timing: bool = False, precision: int = 0, counts: bool = True) -> dict:
     """dist[i,j] = clip(1 - cos(X[i], C[j]), 0, 2); argmin over j (first index on ties) — d_vector.py:315-319.
     precision 0: fp32 MFMA (parity path).  precision 1: bf16x3 MFMA sweep + fp32 re-scoring of the rows whose two best cosines are
     closer than a proven error bound — the arg-min of the fp32 path on every row, about 3x faster; no distance matrix (dist=False);
     the result then carries "rescored" (rows that went through fp32 again).  precision 2: a bf16 sweep in front (bound 4e-3), its close
-    calls to the bf16x3 sweep: same arg-min guarantee, the minimum only within 4e-3 on rows the first sweep decided."""
+    calls to the bf16x3 sweep: same arg-min guarantee, the minimum only within 4e-3 on rows the first sweep decided.
+    ``counts=False`` skips the "rescored" / "split_rows" diagnostics: with CUDA tensors the call then returns without waiting for the GPU."""
     xk, xp, where = _as_f32(X, "X")
     ck, cp, cwhere = _as_f32(Cn, "C")
     if cwhere != where:
@@ -661,7 +662,7 @@ def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True
         _lib.check(ctx._lib.ssp_cosine_identify2(ctx._h, xp, N, d, cp, S, p(dm), p(am), p(mv), where, int(precision),
                                                  C.byref(ms) if timing else None))
     res = {}
-    if precision >= 1:
+    if precision >= 1 and counts:
         n = C.c_int32(0)
         _lib.check(ctx._lib.ssp_cosine_last_rescored(ctx._h, C.byref(n)))
         res["rescored"] = n.value

@@ -873,14 +873,29 @@ int ssp_cosine_identify(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, cons
     return ssp_cosine_identify2(ctx, X, N, d, C, S, dist_out, argmin_out, min_out, where, 0, kernel_ms);
 }
 
+// the close-call counts of the last split-precision call: read back when somebody asks (a device-pointer call does not wait for them)
+static int cos_fetch_counts(const ssp_ctx* ctx) {
+    if (!ctx->cos_counts_pending) return SSP_OK;
+    int32_t hc[2] = {0, 0};
+    SSP_HIP(hipSetDevice(ctx->device));
+    SSP_HIP(hipMemcpyAsync(hc, ctx->cos_count.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SSP_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->cos_last_split = hc[0];
+    ctx->cos_last_rescored = hc[1];
+    ctx->cos_counts_pending = false;
+    return SSP_OK;
+}
+
 int ssp_cosine_last_rescored(const ssp_ctx* ctx, int32_t* n_out) {
     if (!ctx || !n_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_last_rescored: null");
+    SSP_TRY(cos_fetch_counts(ctx));
     *n_out = ctx->cos_last_rescored;
     return SSP_OK;
 }
 
 int ssp_cosine_last_split_rows(const ssp_ctx* ctx, int32_t* n_out) {
     if (!ctx || !n_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_last_split_rows: null");
+    SSP_TRY(cos_fetch_counts(ctx));
     *n_out = ctx->cos_last_split;
     return SSP_OK;
 }
@@ -913,21 +928,23 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
     SSP_TRY(rc);
     float* dM = (float*)sm.out(min_out, (size_t)N * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    DevBuf inc, img;
+    // (scratch lives on the ctx, grow-only: no allocation and no implicit synchronisation per call; calls on one ctx are stream-ordered)
+    DevBuf &inc = ctx->cos_inc, &img = ctx->cos_img;
     Timer tm;
     ctx->cos_last_rescored = ctx->cos_last_split = 0;
+    ctx->cos_counts_pending = false;
     if (precision >= 1) {
         // split-precision sweep(s) keeping the two best cosines per embedding, then the fp32 kernel on the rows whose call is closer than
         // the error bound — device-side lists and counts: nothing comes back to the host in between.  precision 2 puts a hi-parts-only
         // sweep (one MFMA per k-step, bound 4e-3) in front: its close calls go to the bf16 x 3 sweep, that one's to fp32
         const int nk = d <= 64 ? 4 : (d <= 128 ? 8 : (d <= 192 ? 12 : 16)), nq = 2 * nk;
         const int n_tiles = (S + 31) / 32;
-        DevBuf img16, list1, list2, count;
-        SSP_TRY(img16.alloc((size_t)n_tiles * nk * 2048));
-        SSP_TRY(img.alloc((size_t)n_tiles * nq * 256 * sizeof(float)));
-        SSP_TRY(list2.alloc((size_t)N * sizeof(int32_t)));
-        if (precision == 2) SSP_TRY(list1.alloc((size_t)N * sizeof(int32_t)));
-        SSP_TRY(count.alloc(4 * sizeof(int32_t)));  // [0] rows for the bf16 x 3 sweep (precision 2), [1] rows for fp32, [2] centroid flag
+        DevBuf &img16 = ctx->cos_img16, &list1 = ctx->cos_list1, &list2 = ctx->cos_list2, &count = ctx->cos_count;
+        SSP_TRY(img16.reserve((size_t)n_tiles * nk * 2048));
+        SSP_TRY(img.reserve((size_t)n_tiles * nq * 256 * sizeof(float)));
+        SSP_TRY(list2.reserve((size_t)N * sizeof(int32_t)));
+        if (precision == 2) SSP_TRY(list1.reserve((size_t)N * sizeof(int32_t)));
+        SSP_TRY(count.reserve(4 * sizeof(int32_t)));  // [0] rows for the bf16 x 3 sweep (precision 2), [1] rows for fp32, [2] centroid flag
         int32_t* cnt = count.as<int32_t>();
         Cos16Args c3{dX, img16.as<__bf16>(), dA, dM, list2.as<int32_t>(), cnt + 1, cnt + 2, N, d, S, n_tiles, 2.0f * cos_band(d), nullptr, nullptr};
         CosRegArgs ra{dX, img.as<float>(), nullptr, 0, nullptr, dA, dM, N, d, S, n_tiles};
@@ -957,17 +974,14 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
         SSP_TRY(tm.stop(s, kernel_ms));
         SSP_TRY(sa.back(ctx, argmin_out, (size_t)N * sizeof(int32_t), where));
         SSP_TRY(sm.back(ctx, min_out, (size_t)N * sizeof(float), where));
-        int32_t hc[2] = {0, 0};
-        SSP_HIP(hipMemcpyAsync(hc, count.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        SSP_HIP(hipStreamSynchronize(s));  // the images / lists are freed at return
-        ctx->cos_last_split = hc[0];
-        ctx->cos_last_rescored = hc[1];
+        ctx->cos_counts_pending = true;  // (ssp_cosine_last_rescored / _split_rows fetch them)
+        if (where == SSP_HOST) SSP_TRY(cos_fetch_counts(ctx));  // (host outputs: the call waits for its copies anyway)
         return SSP_OK;
     }
     if (d <= 256) {  // register-resident embeddings, LDS-DMA streamed centroid tiles
         const int nq = d <= 64 ? 8 : (d <= 128 ? 16 : (d <= 192 ? 24 : 32));
         const int n_tiles = (S + 31) / 32;
-        SSP_TRY(img.alloc((size_t)n_tiles * nq * 256 * sizeof(float)));
+        SSP_TRY(img.reserve((size_t)n_tiles * nq * 256 * sizeof(float)));
         CosRegArgs ra{dX, img.as<float>(), nullptr, 0, dD, dA, dM, N, d, S, n_tiles};
         SSP_TRY(tm.start(kernel_ms != nullptr, s));
         hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>(), 1);
@@ -980,7 +994,7 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
         }
         SSP_TRY(tm.stop(s, kernel_ms));
     } else {
-        SSP_TRY(inc.alloc((size_t)S * sizeof(float)));
+        SSP_TRY(inc.reserve((size_t)S * sizeof(float)));
         const int64_t grid = ceil_div<int64_t>(N, BN);
         if (grid > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "cosine: too many embeddings for one launch");
         CosArgs a{dX, dC, inc.as<float>(), dD, dA, dM, N, d, S};
@@ -995,7 +1009,7 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
     SSP_TRY(sd.back(ctx, dist_out, (size_t)N * S * sizeof(float), where));
     SSP_TRY(sa.back(ctx, argmin_out, (size_t)N * sizeof(int32_t), where));
     SSP_TRY(sm.back(ctx, min_out, (size_t)N * sizeof(float), where));
-    SSP_HIP(hipStreamSynchronize(s));  // `inc` / `img` are freed at return
+    if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(s));  // (device pointers: asynchronous on the ctx stream, like every other entry point)
     return SSP_OK;
 }
 
