@@ -94,6 +94,7 @@ struct StreamArgs {
     int32_t wave_bytes;       // LDS per wave: 4 frame images + sample stage + cepstrum ring
     int32_t stage_bytes;      // sample stage (whole 1-KiB DMA pieces + a trailing 512-B half piece)
     int32_t table_bytes;      // workgroup-shared DCT operand table in front of the wave regions
+    int32_t tstep;            // the instance has the transposed step form (scan kernel: without deltas one row per step tells)
     const float* dense_w;     // dense-band instances: [lane][6 bands][20] weights (16 bins of the lane's chunk, bin 256, pad), pscale folded in
 };
 

@@ -1,5 +1,5 @@
-// Host side of the wave-stream MFCC kernel (mfcc_stream_kernel.hpp) and its FIRST kernel's instances; the second kernel's — the rare
-// walk over chunks that held a non-finite cepstrum — are compiled in mfcc_stream_walk.hip.
+// Host side of the wave-stream MFCC kernel (mfcc_stream_kernel.hpp), its FIRST kernel's instances and the scan kernel behind them; the
+// third kernel's instances — the rare walk over chunks that held a non-finite cepstrum — are compiled in mfcc_stream_walk.hip.
 #include "mfcc_stream_kernel.hpp"
 
 namespace ssp {
@@ -64,12 +64,82 @@ int build_stream_tables(ssp_mfcc_plan* p) {
     return SSP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ the scan between the two
+// mfcc_stream_scan_kernel — the SECOND kernel of a launch: which chunks did the first kernel get wrong?  It reads the answer off the rows
+// the first kernel stored, a wave per chunk, and writes redo_flags[chunk] (+ the "any" word the third kernel asks first).
+//
+// What the first kernel's arithmetic guarantees (mfcc_stream512_kernel, WALK = 0).  A frame's cepstra are finite or non-finite TOGETHER
+// (each is a sum over the same log-mel row; a non-finite term times any weight, zero included, is non-finite; finite rows of O(10) cannot
+// overflow), and a matrix product spreads a non-finite operand over every element it contributes to with ANY weight, zero included:
+//   * transposed step (interior steps of the non-scaling instances): the delta product contracts over all 24 frames of the step's window
+//     and the selection product (delta_order 0) over exactly the 16 frames it emits — one non-finite frame in reach makes the delta
+//     columns (delta_order 0: the cepstra) of EVERY emitted row of the step non-finite;
+//   * chained step (utterance ends; every step of the scaling instances): cepstra leave straight from the ring (a row is wrong only if
+//     its own frame is), delta tile 0 = emitted rows up to rb + 9 contracts over frames rb - 8 .. rb + 11, tile 1 = rows rb + 10,
+//     rb + 11 over rb + 8 .. rb + 15, delta-delta over both tiles — so the delta columns of the FIRST and the LAST emitted row of a step
+//     tell for every emitted row of it (a step that emits rows of one tile only has both in that tile);
+//   * scaling (CM): a non-finite entry makes its column's mean — and with it the column of the whole utterance — NaN.
+// A row is wrong in the first kernel's output only if it is non-finite there (finite rows were formed from finite operands by the same
+// sums as ever), so: delta_order >= 1 — the first delta column of the first and the last emitted row of every step; delta_order 0 — the
+// first cepstrum of the same two rows of a transposed step, of every emitted row of a chained one (it has no product that would spread a
+// leaked NaN sample's frame).  Rows that are non-finite in the reference too are flagged as well; the third kernel reproduces them.
+// Cost: one 4-byte load per 8 to 16 rows (1 / 40 of the lines the first kernel wrote with deltas; 0.06 ms at configs[1]).
+__global__ __launch_bounds__(256) void mfcc_stream_scan_kernel(MfccArgs a, StreamArgs sa) {
+    const int lane = threadIdx.x & 63;
+    const int cidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cidx >= sa.n_chunks) return;
+    const MfccChunk ch = a.chunks[cidx];
+    const int64_t f0 = a.frame_off[ch.utt];
+    const int dord = a.delta_order, Dd = a.d_out, t0 = ch.t0, n = ch.n;
+    const float* __restrict__ out = a.out + (size_t)f0 * Dd;
+    auto bad_at = [&](int F, int col) -> bool {
+        const float v = out[(size_t)F * Dd + col];
+        return !(__builtin_fabsf(v) < INFINITY);  // NaN or +-inf
+    };
+    bool bad = false;
+    // the step geometry of the first kernel: ta = first computed frame (no halo without deltas), step b emits rows
+    // [ta + 16 b - 4, ta + 16 b + 12) of the chunk's; a step whose window lies strictly inside the utterance takes the transposed form
+    const int T = (int)(a.frame_off[ch.utt + 1] - f0);
+    const int ta = dord > 0 ? max(t0 - 4 - ch.pad, 0) : t0;
+    const int n_steps = (t0 + n - ta + 4 + 15) >> 4;
+    if (dord > 0) {
+        for (int i = lane; i < 2 * n_steps; i += 64) {
+            const int rb = ta + 16 * (i >> 1);
+            const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
+            if (lo < hi) bad |= bad_at((i & 1) ? hi - 1 : lo, 13);
+        }
+    } else {
+        // without deltas: the selection product of a transposed step spreads over its 16 rows (two rows tell), a chained step stores the
+        // ring's rows as they are (every row is looked at)
+        for (int i = lane; i < 16 * n_steps; i += 64) {
+            const int rb = ta + 16 * (i >> 4), k = i & 15;
+            const bool spread = sa.tstep != 0 && rb - 8 >= 1 && rb + 16 <= T - 2;
+            const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
+            const int F = spread ? (k == 0 ? lo : (k == 1 ? hi - 1 : -1)) : rb - 4 + k;
+            if (F >= lo && F < hi) bad |= bad_at(F, 0);
+        }
+    }
+    const bool any = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if (lane == 0) {
+        sa.redo_flags[cidx] = any ? 1 : 0;
+        if (any) sa.work_counter[1] = 1;  // (any writer)
+    }
+}
+
 int launch_mfcc_stream_walk(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStream_t stream);  // mfcc_stream_walk.hip
 
 int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hipStream_t stream, bool dry_run) {
     SSP_TRY(launch_mfcc_stream_impl<0>(args, p, n_chunks, stream, dry_run));
     if (dry_run || n_chunks <= 0 || mfcc_stream_dense(p)) return SSP_OK;
-    // the second kernel: the chunks the first one listed (normally none: every workgroup reads the count and leaves)
+    // the second kernel: which chunks came out polluted by a non-finite cepstrum (normally none) ...
+    StreamArgs sa{};
+    sa.n_chunks = n_chunks;
+    sa.work_counter = p->f_counter.as<int32_t>();
+    sa.redo_flags = sa.work_counter + 16;
+    sa.tstep = (args.cmvn == 0 && !(p->fast.melv >= 4 && p->fast.mel_ns > 2)) ? 1 : 0;  // (mfcc_stream512_kernel: TSTEP)
+    hipLaunchKernelGGL(mfcc_stream_scan_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, stream, args, sa);
+    SSP_HIP(hipGetLastError());
+    // ... and the third: those chunks once more, term by term (every workgroup reads the "any" word and leaves when it is zero)
     return launch_mfcc_stream_walk(args, p, n_chunks, stream);
 }
 

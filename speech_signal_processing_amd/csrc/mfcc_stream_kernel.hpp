@@ -64,7 +64,7 @@ __device__ __forceinline__ float delta_weight(float t, float tp, float Tm1, floa
 // VGPRs, every twiddle resident) where the sample stage of a longer hop or a wider DCT operand does not fit three workgroups per CU
 // CM: per-utterance mean / variance scaling (sklearn.preprocessing.scale, GMM_UBM.py:93) inside the kernel, for batches whose utterances
 // are all single chunks: the wave sums x and x^2 of every column it stores (float64), then re-reads its own rows and rewrites them
-// WALK: the SECOND kernel of a launch (mfcc_stream_walk.hip).  It walks the chunks the first one flagged (a non-finite cepstrum in a time
+// WALK: the THIRD kernel of a launch (mfcc_stream_walk.hip).  It walks the chunks the scan kernel flagged (a non-finite cepstrum in a time
 // step's window: a digitally silent frame, a NaN sample) once more, sequentially, with every step formed term by term as the reference
 // forms it, and rewrites every row of them; nothing flagged — the normal case — costs one load per workgroup.
 template <int NZ, int POWER, int PRE, int MELV, int KS, int NS, int OCC, int CM, int WALK>
@@ -235,30 +235,15 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
         }
         prefetch(0);
         int stores_pending = 0;  // buffer stores issued behind the DMA that is waited for at the top of the next iteration
-        // non-finite cepstra (a digitally silent frame: ln 0 = -inf in the dialects without a floor, GMM_UBM.py:89 / d_vector.py:96-98): the
-        // time products spread one over the whole 16-row step (0 . inf = NaN) — which is also how a step finds out, for one compare and no
-        // wait of its own: a frame's cepstra are finite or non-finite TOGETHER (each is a sum over the same log-mel row, a non-finite term
-        // times any weight, zero included, is non-finite, and finite rows of O(10) cannot overflow; the padded columns 13..15 have zero DCT
-        // rows: 0 . inf = NaN), so ONE non-finite value anywhere in the step's 24-frame window makes EVERY element of the delta product
-        // non-finite, in every lane.  The step looks at one element of the product it forms anyway and ORs the verdict into a scalar; it
-        // stores what it has (rows that may be polluted) and flags the chunk for the SECOND kernel (WALK), which walks it once more,
-        // sequentially, every step formed term by term as the reference forms it, and rewrites every row.  No branch and no block of
-        // the rare case sits in this kernel's quad loop, nor anywhere else in it: inside the loop, however small, such a block costs
-        // the loop its register assignment (measured: 16 to 50 resident registers spilled and reloaded per quad for a block behind
-        // the products; round 4's check in front of the step, one wait on the ring reads + the block inline, cost 3 to 6 %), and the
-        // second walk as a block behind the loop still cost the headline instance 2.7 %.
-        // (per step ONE fused multiply-add into a sticky vector register — t . 0 is NaN exactly when t is not finite — and one compare per
-        //  chunk.  Measured the same within 0.3 %: a compare + scalar OR per step; the verdict in a word of wave-private LDS.)
-        float nf_acc = 0.f;
-        auto note_nonfinite = [&](float t) {
-#ifndef SSP_S_NONF  // (ablation: no check)
-            nf_acc = __builtin_fmaf(t, 0.f, nf_acc);
-#endif
-        };
-        auto chunk_nonfinite = [&]() -> bool {
-            const uint64_t m = __builtin_amdgcn_ballot_w64(nf_acc != nf_acc);
-            return __builtin_amdgcn_readfirstlane((uint32_t)(m | (m >> 32))) != 0u;  // (a scalar, and known to the compiler as one)
-        };
+        // Non-finite cepstra (a digitally silent frame: ln 0 = -inf in the dialects without a floor, GMM_UBM.py:89 / d_vector.py:96-98; a NaN
+        // sample): the time products spread one over the whole 16-row step (0 . inf = NaN), where the reference's delta reaches +-2 / +-4
+        // frames.  THIS kernel does nothing about it — it stores what it has.  mfcc_stream_scan_kernel (mfcc_stream.hip) reads the pollution off the
+        // stored rows afterwards and flags such chunks, and the kernel's WALK = 1 instance walks flagged chunks once more, every step
+        // formed term by term as the reference forms it, and rewrites their rows.  Nothing of the rare case may sit in this kernel: a
+        // cold block inside the quad loop costs the loop its registers (16 to 50 resident registers spilled and reloaded per quad for a
+        // block behind the products; round 4's check in front of the step cost 3 to 6 %), a block behind the loop 2.7 %, and even one
+        // sticky instruction per time step + one flag store per chunk put the kernel into its slow state (2.4 % on the headline, 4.8 %
+        // on the in-repo 8 kHz instance: DESIGN 4.1a) — the instruction stream without either is the fast one.
         int cm_nf = WALK;  // CM, second kernel: no column sums were kept, and entries may be NaN: the scaling pass counts (nanmean / nanstd)
         // CM: sums of this lane's stored values per block (column = lane & 15), fp32: a lane adds ~T / 4 terms, and the cepstra are
         // summed relative to a pivot — the utterance's first frame — so that var = E[(x - p)^2] - E[x - p]^2 does not cancel when a
@@ -590,7 +575,6 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 }
                 // delta rows leave from their own layout: tile 0 register r <-> frame rb - 6 + 4 g + r = row Fo + r - 2 (the first two
                 // belong to the previous step's window), tile 1 register 0 <-> frame rb + 10 + g = row Fo + 14 - 3 g (g < 2)
-                note_nonfinite(d0[0] + d1[0]);  // (tile 0: frames rb - 8 .. rb + 11 of the window, tile 1: rb + 8 .. rb + 15)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) put(r - 2, 1, d0[r], r >= 2 || g > 0);
                 put(14 - 3 * g, 1, d1[0], g < 2);
@@ -635,7 +619,6 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 v4f c = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 1; s < 5; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[s], (ef + (float)(4 * s)) == 0.f ? 1.f : 0.f, c, 0, 0, 0);
-                if (dord == 0) note_nonfinite(c.x);  // (the selection product covers the 16 frames it selects from; with deltas their product tells)
                 store(c, 0);
             }
             if (dord >= 1) {
@@ -645,7 +628,6 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                     const float ds = ef + (float)(4 * s);
                     d = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[s], __builtin_fabsf(ds) <= 2.f ? ds * inv : 0.f, d, 0, 0, 0);
                 }
-                note_nonfinite(d.x);
                 store(d, 1);
             }
             if (dord >= 2) {
@@ -711,7 +693,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
 #ifdef SSP_S_NOTSTEP
             time_step(b, cb);
 #else
-            const bool interior = ta + 16 * b - 8 >= 1 && ta + 16 * b + 16 <= T - 2;  // wave-uniform
+            const bool interior = ta + 16 * b - 8 >= 1 && ta + 16 * b + 16 <= T - 2;  // wave-uniform (the scan kernel repeats this test)
             // (not the scaling instances — their column sums live in the row-major layout — nor the widest filterbank instance, which has no
             //  register left for the second form)
             constexpr bool TSTEP = !CM && !(MELV >= 4 && NS >= 4);
@@ -879,30 +861,8 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             }
 #endif
         }
-        // Every chunk leaves its verdict in redo_flags (one store, no branch around the rare case, no atomic: a second atomic in this kernel
-        // — a list of the flagged chunks — was merged with the claim's by the compiler into one block with a dispatch on lane masks, and a
-        // `continue` behind it turned the chunk loop into a loop over lane masks: that kernel hung).  `flagged` is a scalar.
-        // (in front of the chunk's final wait, which completes the store with the step's)
-        bool flagged = false;
-        if constexpr (!DENSE && !WALK) {
-            flagged = chunk_nonfinite();
-            // ONE lane stores, through a bounds-checked buffer store whose other lanes aim out of range — no lane-0 block: such a block here
-            // sits right in front of the lane-0 block of the next claim, and the compiler threads the other lanes around both (a chunk loop
-            // over lane masks again).  (Measured on the way: all 64 lanes storing the same word are 64 writes in a row at one L2 address,
-            // 2.7 us per chunk — +2.7 % on the headline, +5 % on the in-repo dialect.)  Word 1 of the counters says whether any chunk
-            // was flagged: the second kernel asks that first.  (The flags sit 64 bytes behind the counters, one buffer.)
-            {
-                const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
-                    sa.work_counter, 0, __builtin_amdgcn_readfirstlane(64 + sa.n_chunks * 4), 0x00020000);
-                const int fv = flagged ? 1 : 0;
-#ifndef SSP_S_NOFLAG  // (ablation)
-                __builtin_amdgcn_raw_buffer_store_b32(fv, rf, lane == 0 ? 64 + cidx * 4 : 0x7ffffff0, 0, 0);
-                if (flagged) __builtin_amdgcn_raw_buffer_store_b32(fv, rf, lane == 0 ? 4 : 0x7ffffff0, 0, 0);
-#endif
-            }
-        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetch (zeros) and every store have completed
-        if (CM && !flagged) {
+        if (CM) {
             // ---- scaling pass: column statistics over the four lane groups, then the utterance's rows once more through L2
             int ol = lane;
             asm volatile("" : "+v"(ol));
@@ -1013,7 +973,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------ launch (both kernels)
+// ------------------------------------------------------------------------------------------------ launch (first / third kernel)
 // k-steps of the DCT product the instances are built for: 6 (<= 24 filters: the sidekit dialects) or 10 (<= 40: the in-repo MFCC)
 static inline int stream_ks(const ssp_mfcc_cfg& c) { return (c.n_filt + 3) / 4 <= 6 ? 6 : 10; }
 
@@ -1042,6 +1002,7 @@ int launch_mfcc_stream_impl(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks
     sa.n_chunks = n_chunks;
     if (!dry_run) {
         // one buffer: a 64-byte head ([0] next chunk to claim, [1] a chunk was flagged: zeroed by the first launch) + one flag per chunk
+        // (written by the scan kernel)
         SSP_TRY(p->f_counter.reserve(64 + (size_t)std::max(n_chunks, 1) * sizeof(int32_t)));
         sa.work_counter = p->f_counter.as<int32_t>();
         sa.redo_flags = sa.work_counter + 16;

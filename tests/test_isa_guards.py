@@ -133,27 +133,28 @@ def test_dtw_cell_is_three_instructions(tmp_path):
 def test_stream512_quad_loops_are_free_of_scratch(tmp_path):
     """mfcc_stream512_kernel<..., WALK = 0> (benchmark instances): a spill reload inside the quad loop waits on vmcnt behind the sample DMA —
     its whole latency, every quad (12.4 instead of 10.1 ms with 16 spilled registers once).  No instance carries scratch at all since
-    round 5 (the scaling instance <..., CM = 1> spilled five registers per chunk in round 4).  The non-finite check of a time step is ONE
-    fused multiply-add into a sticky register — no compare against infinity and no branch of the rare case inside the kernel's loops: the
-    flagged chunks are the second kernel's (WALK = 1, mfcc_stream_walk.hip).  And the chunk loop stays a plain wave-uniform loop: three
-    formulations of the chunk's verdict turned it into a loop over lane masks (`s_andn2_b64 exec, exec, ...` as the loop test), one of
-    which hung on the GPU."""
+    round 5 (the scaling instance <..., CM = 1> spilled five registers per chunk in round 4).  NOTHING of the non-finite case sits in
+    this kernel: no compare against infinity, no sticky accumulate, no flag store, no branch of the rare case — the scan kernel reads
+    the pollution off the stored rows and the third kernel (WALK = 1, mfcc_stream_walk.hip) redoes flagged chunks.  And the chunk loop
+    stays a plain wave-uniform loop: three formulations of a chunk verdict turned it into a loop over lane masks
+    (`s_andn2_b64 exec, exec, ...` as the loop test), one of which hung on the GPU."""
     k = _isa("mfcc_stream.hip", tmp_path, extra=("-DSSP_FAST_MINIMAL",), with_depth=True)
     inst = {n: v for n, v in k.items() if "mfcc_stream512_kernel" in n}
     head = [n for n in inst if "ILi13ELi2ELi1ELi3ELi6ELi2ELi3ELi0ELi0E" in n]
     assert len(head) == 1, list(inst)
     for n, v in inst.items():
-        assert n.endswith("Li0EEEvNS_8MfccArgsENS_8FastArgsENS_10StreamArgsE") or "Li0EEEv" in n, n  # first kernels only in this unit
+        assert "Li0EEEv" in n, n  # first kernels only in this unit
         assert not [t for _, t in v if t.startswith("scratch_")], n
         assert not [t for _, t in v if re.match(r"s_andn2_b64 exec, exec", t)], n
         assert not [t for d, t in v if d >= 2 and re.match(r"v_cmp_(nlg|class)_f32", t)], n
         assert not [t for _, t in v if t.startswith(("s_swappc", "s_setpc"))], n
-    # the sticky accumulate: a multiply by the literal zero with the accumulator as addend, once per step form and loop copy
-    assert 2 <= sum(1 for d, t in inst[head[0]] if d >= 2 and re.match(r"v_fma(c)?_f32\S* v\d+, 0, ", t)) <= 8
+        assert not [t for d, t in v if d >= 1 and re.match(r"v_fma(c)?_f32\S* v\d+, 0, ", t)], n  # (round 5's sticky verdict: gone)
+    scan = [v for n, v in k.items() if "mfcc_stream_scan_kernel" in n]
+    assert len(scan) == 1 and not [t for _, t in scan[0] if t.startswith("scratch_")]
 
 
 def test_stream512_walk_kernels(tmp_path):
-    """the second kernel of a wave-stream launch (mfcc_stream_walk.hip): a plain wave-uniform loop nest as well (no loop over lane masks),
+    """the third kernel of a wave-stream launch (mfcc_stream_walk.hip): a plain wave-uniform loop nest as well (no loop over lane masks),
     no scratch, the legacy product on the window rows, and an early exit on the "any chunk flagged" word in front of everything else"""
     k = _isa("mfcc_stream_walk.hip", tmp_path, extra=("-DSSP_FAST_MINIMAL",), with_depth=True)
     inst = {n: v for n, v in k.items() if "mfcc_stream512_kernel" in n}
