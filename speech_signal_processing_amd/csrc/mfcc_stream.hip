@@ -80,7 +80,8 @@ int build_stream_tables(ssp_mfcc_plan* p) {
 //     tell for every emitted row of it (a step that emits rows of one tile only has both in that tile);
 //   * scaling (CM): a non-finite entry makes its column's mean — and with it the column of the whole utterance — NaN.
 // A row is wrong in the first kernel's output only if it is non-finite there (finite rows were formed from finite operands by the same
-// sums as ever), so: delta_order >= 1 — the first delta column of the first and the last emitted row of every step; delta_order 0 — the
+// sums as ever), so: delta_order >= 1 — the first column of the HIGHEST-order block (its product sees everything the lower ones saw: the
+// chained delta-delta contracts over both delta tiles) of the first and the last emitted row of every step; delta_order 0 — the
 // first cepstrum of the same two rows of a transposed step, of every emitted row of a chained one (it has no product that would spread a
 // leaked NaN sample's frame).  Rows that are non-finite in the reference too are flagged as well; the third kernel reproduces them.
 // Cost: one 4-byte load per 8 to 16 rows (1 / 40 of the lines the first kernel wrote with deltas; 0.06 ms at configs[1]).
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void mfcc_stream_scan_kernel(MfccArgs a, Strea
         for (int i = lane; i < 2 * n_steps; i += 64) {
             const int rb = ta + 16 * (i >> 1);
             const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
-            if (lo < hi) bad |= bad_at((i & 1) ? hi - 1 : lo, 13);
+            if (lo < hi) bad |= bad_at((i & 1) ? hi - 1 : lo, 13 * dord);
         }
     } else {
         // without deltas: the selection product of a transposed step spreads over its 16 rows (two rows tell), a chained step stores the

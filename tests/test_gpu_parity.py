@@ -2090,3 +2090,35 @@ def test_mfcc_dtw_loaders_batch_the_packages_own_extractors(ssp, tmp_path):
         np.testing.assert_allclose(t, MFCC_DTW.generate_template(seqs), rtol=0, atol=1e-4 * max(1.0, float(np.abs(t).max())))
     d, pred = MFCC_DTW.classify(MFCC_DTW.load_test(str(tmp_path / "test"), mfcc_extract=MFCC_DTW._MFCC)[0], tpl, lab)
     assert d.shape == (8, 4) and len(pred) == 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order,cmvn", [(0, 0), (1, 0), (2, 0), (1, 1)])
+def test_nonfinite_positions_sweep_against_chunk_and_step_borders(ssp, order, cmvn):
+    """The wave-stream launch finds polluted chunks by looking at two rows per 16-row time step of what its first kernel stored
+    (mfcc_stream_scan_kernel) — a sweep of a NaN sample and of a digitally silent stretch over 48 positions (a step is 16 frames = 2560
+    samples, latency chunks of a small batch are a few steps) must give the oracle's finite pattern and values at every one of them;
+    long multi-chunk utterances and short single-chunk ones (the scaling instance) in one batch."""
+    pkg, api = ssp
+    from oracle import ref_cpu as O
+    tables = pkg.preset_sidekit(delta_order=order, cmvn=cmvn)
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=order, cmvn=cmvn)
+    rng = np.random.default_rng(17)
+    base = [(0.3 * rng.standard_normal(l)).astype(np.float32) for l in (60000, 9000, 16000)]
+    for k in range(48):
+        pos = 20000 + 167 * k + (k // 16) * 2560
+        sigs = [b.copy() for b in base]
+        if k % 2 == 0:
+            sigs[0][pos] = np.nan
+            sigs[2][min(pos // 4, 15999)] = np.nan
+        else:
+            sigs[0][pos:pos + 700] = 0.0      # > one 400-sample window: at least one digitally silent frame (ln 0 = -inf)
+            sigs[1][pos // 8:pos // 8 + 500] = 0.0
+        with np.errstate(all="ignore"):
+            refs = [O.mfcc_pipeline(x, cfg, w, fb, dct) for x in sigs]
+        got, _ = _run_plan(api, tables, sigs, variant=0)
+        for u in range(len(sigs)):
+            fin = np.isfinite(refs[u])
+            assert (np.isfinite(got[u]) == fin).all(), (order, cmvn, k, u, int((np.isfinite(got[u]) != fin).sum()))
+            if fin.any() and not (cmvn and fin.all(axis=1).sum() < 8):
+                assert np.abs(got[u][fin] - refs[u][fin]).max() <= 1e-4 * max(1.0, float(np.abs(refs[u][fin]).max())), (order, cmvn, k, u)
