@@ -497,7 +497,7 @@ def main():
                    "backend": (dist.get_backend() if world > 1 else None), "kernel_ms_per_rank": per_rank_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "mfcc_stream512_kernel<13,2,1,3,6,2,3,0,0> (+ its second kernel <...,1>: no chunk flagged, exits on one load)" if args.variant in (0, 3) else "mfcc fused pass", "kernel_ms": ms_kernel,
+                     "kernel": "mfcc_stream512_kernel<13,2,1,3,6,2,3,0,0> + mfcc_stream_scan_kernel + the third kernel <...,1> (no chunk flagged: exits on one load); kernel_ms spans all three" if args.variant in (0, 3) else "mfcc fused pass", "kernel_ms": ms_kernel,
                      "kernel_ms_stat": "median of the timed launches (hipEvents on the launch stream)",
                      "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame},
         "roofline_flop": flop_roof,

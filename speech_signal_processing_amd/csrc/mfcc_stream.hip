@@ -66,7 +66,7 @@ int build_stream_tables(ssp_mfcc_plan* p) {
 
 // ------------------------------------------------------------------------------------------------ the scan between the two
 // mfcc_stream_scan_kernel — the SECOND kernel of a launch: which chunks did the first kernel get wrong?  It reads the answer off the rows
-// the first kernel stored, a wave per chunk, and writes redo_flags[chunk] (+ the "any" word the third kernel asks first).
+// the first kernel stored and sets redo_flags[chunk] (+ the "any" word the third kernel asks first).
 //
 // What the first kernel's arithmetic guarantees (mfcc_stream512_kernel, WALK = 0).  A frame's cepstra are finite or non-finite TOGETHER
 // (each is a sum over the same log-mel row; a non-finite term times any weight, zero included, is non-finite; finite rows of O(10) cannot
@@ -85,45 +85,42 @@ int build_stream_tables(ssp_mfcc_plan* p) {
 // first cepstrum of the same two rows of a transposed step, of every emitted row of a chained one (it has no product that would spread a
 // leaked NaN sample's frame).  Rows that are non-finite in the reference too are flagged as well; the third kernel reproduces them.
 // Cost: one 4-byte load per 8 to 16 rows (1 / 40 of the lines the first kernel wrote with deltas; 0.06 ms at configs[1]).
-__global__ __launch_bounds__(256) void mfcc_stream_scan_kernel(MfccArgs a, StreamArgs sa) {
-    const int lane = threadIdx.x & 63;
-    const int cidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+// One THREAD per (chunk, look): `per_chunk` looks per chunk (enough for the longest chunk of the table; a look past a chunk's last
+// step does nothing), each three dependent loads deep — chunk record, frame offset, the row's word — and millions of them in flight.
+// (A wave per chunk with lanes over its looks took 0.09 ms at configs[1], this takes 0.02.)  The flags were zeroed by the first launch;
+// a look that finds a non-finite word sets its chunk's flag and the "any" word (plain stores of 1: whoever comes last writes the same).
+__global__ __launch_bounds__(256) void mfcc_stream_scan_kernel(MfccArgs a, StreamArgs sa, int per_chunk) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cidx = (int)(i / per_chunk), k = (int)(i - (int64_t)cidx * per_chunk);
     if (cidx >= sa.n_chunks) return;
     const MfccChunk ch = a.chunks[cidx];
     const int64_t f0 = a.frame_off[ch.utt];
     const int dord = a.delta_order, Dd = a.d_out, t0 = ch.t0, n = ch.n;
-    const float* __restrict__ out = a.out + (size_t)f0 * Dd;
-    auto bad_at = [&](int F, int col) -> bool {
-        const float v = out[(size_t)F * Dd + col];
-        return !(__builtin_fabsf(v) < INFINITY);  // NaN or +-inf
-    };
-    bool bad = false;
     // the step geometry of the first kernel: ta = first computed frame (no halo without deltas), step b emits rows
     // [ta + 16 b - 4, ta + 16 b + 12) of the chunk's; a step whose window lies strictly inside the utterance takes the transposed form
-    const int T = (int)(a.frame_off[ch.utt + 1] - f0);
     const int ta = dord > 0 ? max(t0 - 4 - ch.pad, 0) : t0;
     const int n_steps = (t0 + n - ta + 4 + 15) >> 4;
+    int F = -1, col = 0;
     if (dord > 0) {
-        for (int i = lane; i < 2 * n_steps; i += 64) {
-            const int rb = ta + 16 * (i >> 1);
-            const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
-            if (lo < hi) bad |= bad_at((i & 1) ? hi - 1 : lo, 13 * dord);
-        }
+        const int rb = ta + 16 * (k >> 1);
+        const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
+        if ((k >> 1) < n_steps && lo < hi) F = (k & 1) ? hi - 1 : lo;
+        col = 13 * dord;
     } else {
         // without deltas: the selection product of a transposed step spreads over its 16 rows (two rows tell), a chained step stores the
         // ring's rows as they are (every row is looked at)
-        for (int i = lane; i < 16 * n_steps; i += 64) {
-            const int rb = ta + 16 * (i >> 4), k = i & 15;
-            const bool spread = sa.tstep != 0 && rb - 8 >= 1 && rb + 16 <= T - 2;
-            const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
-            const int F = spread ? (k == 0 ? lo : (k == 1 ? hi - 1 : -1)) : rb - 4 + k;
-            if (F >= lo && F < hi) bad |= bad_at(F, 0);
-        }
+        const int T = (int)(a.frame_off[ch.utt + 1] - f0);
+        const int rb = ta + 16 * (k >> 4), r = k & 15;
+        const bool spread = sa.tstep != 0 && rb - 8 >= 1 && rb + 16 <= T - 2;
+        const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
+        const int Fc = spread ? (r == 0 ? lo : (r == 1 ? hi - 1 : -1)) : rb - 4 + r;
+        if ((k >> 4) < n_steps && Fc >= lo && Fc < hi) F = Fc;
     }
-    const bool any = __builtin_amdgcn_ballot_w64(bad) != 0;
-    if (lane == 0) {
-        sa.redo_flags[cidx] = any ? 1 : 0;
-        if (any) sa.work_counter[1] = 1;  // (any writer)
+    if (F < 0) return;
+    const float v = a.out[((size_t)f0 + (size_t)F) * Dd + col];
+    if (!(__builtin_fabsf(v) < INFINITY)) {  // NaN or +-inf
+        sa.redo_flags[cidx] = 1;
+        sa.work_counter[1] = 1;
     }
 }
 
@@ -138,7 +135,12 @@ int launch_mfcc_stream(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks, hip
     sa.work_counter = p->f_counter.as<int32_t>();
     sa.redo_flags = sa.work_counter + 16;
     sa.tstep = (args.cmvn == 0 && !(p->fast.melv >= 4 && p->fast.mel_ns > 2)) ? 1 : 0;  // (mfcc_stream512_kernel: TSTEP)
-    hipLaunchKernelGGL(mfcc_stream_scan_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, stream, args, sa);
+    // looks per chunk: two per step with deltas, sixteen without; steps of the longest chunk the table may hold (+ halo and pad)
+    const int max_steps = (p->cache_chunk_frames + 16 + 4 + 15) >> 4;
+    const int per_chunk = (args.delta_order > 0 ? 2 : 16) * max_steps;
+    const int64_t looks = (int64_t)n_chunks * per_chunk;
+    if ((looks + 255) / 256 > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc(stream): too many chunks for the scan kernel's grid");
+    hipLaunchKernelGGL(mfcc_stream_scan_kernel, dim3((unsigned)((looks + 255) / 256)), dim3(256), 0, stream, args, sa, per_chunk);
     SSP_HIP(hipGetLastError());
     // ... and the third: those chunks once more, term by term (every workgroup reads the "any" word and leaves when it is zero)
     return launch_mfcc_stream_walk(args, p, n_chunks, stream);

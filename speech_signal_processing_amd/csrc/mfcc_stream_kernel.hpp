@@ -1001,8 +1001,8 @@ int launch_mfcc_stream_impl(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks
     sa.table_bytes = 0;
     sa.n_chunks = n_chunks;
     if (!dry_run) {
-        // one buffer: a 64-byte head ([0] next chunk to claim, [1] a chunk was flagged: zeroed by the first launch) + one flag per chunk
-        // (written by the scan kernel)
+        // one buffer: a 64-byte head ([0] next chunk to claim, [1] a chunk was flagged) + one flag per chunk, all zeroed by the first
+        // launch; the scan kernel sets what it finds
         SSP_TRY(p->f_counter.reserve(64 + (size_t)std::max(n_chunks, 1) * sizeof(int32_t)));
         sa.work_counter = p->f_counter.as<int32_t>();
         sa.redo_flags = sa.work_counter + 16;
@@ -1033,7 +1033,7 @@ int launch_mfcc_stream_impl(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks
         int per_cu = 0;                                                                                                 \
         SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * wg_waves, lds));                        \
         const int grid = std::min((n_chunks + wg_waves - 1) / wg_waves, std::max(1, per_cu) * p->ctx->num_cu);          \
-        if (!WALK) SSP_HIP(hipMemsetAsync(sa.work_counter, 0, 64, stream));                                             \
+        if (!WALK) SSP_HIP(hipMemsetAsync(sa.work_counter, 0, 64 + (size_t)n_chunks * 4, stream)); /* counters + flags */    \
         if (getenv("SSP_DEBUG")) fprintf(stderr, "[ssp] mfcc stream%s: grid %d (%d per CU), lds %zu\n", WALK ? " (second kernel)" : "", grid, per_cu, lds); \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * wg_waves), lds, stream, args, f, sa);                             \
         launched = true;                                                                                                \
@@ -1046,7 +1046,7 @@ int launch_mfcc_stream_impl(const MfccArgs& args, ssp_mfcc_plan* p, int n_chunks
         int per_cu = 0;                                                                                                   \
         SSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * wg_waves, lds));                          \
         const int grid = std::min((n_chunks + wg_waves - 1) / wg_waves, std::max(1, per_cu) * p->ctx->num_cu);            \
-        if (!WALK) SSP_HIP(hipMemsetAsync(sa.work_counter, 0, 64, stream));                                               \
+        if (!WALK) SSP_HIP(hipMemsetAsync(sa.work_counter, 0, 64 + (size_t)n_chunks * 4, stream));                            \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * wg_waves), lds, stream, args, f, sa);                               \
         launched = true;                                                                                                  \
     }

@@ -30,8 +30,8 @@ if have("kernel_stats.csv"):
     open(os.path.join(P, "%s_kernel_stats.md" % R), "w").write(md)
 
 # ---- per-stage listings
-DOM = {"mfcc": ("mfcc_stream512_kernel", "roofline"), "ref26": ("mfcc_stream512_kernel", "mfcc_ref26_cmvn"), "inrepo": ("mfcc_stream512_kernel", "mfcc_inrepo"),
-       "librosa": ("mfcc_stream2048_kernel", "mfcc_librosa"), "gmm": ("gmm_loglik", "gmm"), "cosine": ("cosine_", "cosine"), "plp": ("mfcc_stream512_kernel", "plp")}
+DOM = {"mfcc": ("mfcc_stream", "roofline"), "ref26": ("mfcc_stream", "mfcc_ref26_cmvn"), "inrepo": ("mfcc_stream", "mfcc_inrepo"),
+       "librosa": ("mfcc_stream2048_kernel", "mfcc_librosa"), "gmm": ("gmm_loglik", "gmm"), "cosine": ("cosine_", "cosine"), "plp": ("mfcc_stream", "plp")}
 for st, (kern, key) in DOM.items():
     tr = "stage_%s_kernel_trace.csv" % st
     if not have(tr):
