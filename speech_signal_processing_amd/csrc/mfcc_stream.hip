@@ -81,10 +81,10 @@ int build_stream_tables(ssp_mfcc_plan* p) {
 //   * scaling (CM): a non-finite entry makes its column's mean — and with it the column of the whole utterance — NaN.
 // A row is wrong in the first kernel's output only if it is non-finite there (finite rows were formed from finite operands by the same
 // sums as ever), so: delta_order >= 1 — the first column of the HIGHEST-order block (its product sees everything the lower ones saw: the
-// chained delta-delta contracts over both delta tiles) of the first and the last emitted row of every step; delta_order 0 — the
-// first cepstrum of the same two rows of a transposed step, of every emitted row of a chained one (it has no product that would spread a
-// leaked NaN sample's frame).  Rows that are non-finite in the reference too are flagged as well; the third kernel reproduces them.
-// Cost: one 4-byte load per 8 to 16 rows (1 / 40 of the lines the first kernel wrote with deltas; 0.06 ms at configs[1]).
+// chained delta-delta contracts over both delta tiles) of one emitted row of a transposed step, of the first and the last emitted row
+// of a chained one; delta_order 0 — the first cepstrum of one row of a transposed step, of every emitted row of a chained one (it has no
+// product that would spread a leaked NaN sample's frame).  Rows that are non-finite in the reference too are flagged as well; the
+// third kernel reproduces them.  Cost: one 32-byte sector per 16 rows and a few more at the utterance ends.
 // One THREAD per (chunk, look): `per_chunk` looks per chunk (enough for the longest chunk of the table; a look past a chunk's last
 // step does nothing), each three dependent loads deep — chunk record, frame offset, the row's word — and millions of them in flight.
 // (A wave per chunk with lanes over its looks took 0.09 ms at configs[1], this takes 0.02.)  The flags were zeroed by the first launch;
@@ -100,20 +100,22 @@ __global__ __launch_bounds__(256) void mfcc_stream_scan_kernel(MfccArgs a, Strea
     // [ta + 16 b - 4, ta + 16 b + 12) of the chunk's; a step whose window lies strictly inside the utterance takes the transposed form
     const int ta = dord > 0 ? max(t0 - 4 - ch.pad, 0) : t0;
     const int n_steps = (t0 + n - ta + 4 + 15) >> 4;
+    const int T = (int)(a.frame_off[ch.utt + 1] - f0);
     int F = -1, col = 0;
     if (dord > 0) {
+        // a transposed step pollutes every row it emits: ONE look; a chained step's two delta tiles: its first and its last emitted row
         const int rb = ta + 16 * (k >> 1);
+        const bool spread = sa.tstep != 0 && rb - 8 >= 1 && rb + 16 <= T - 2;
         const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
-        if ((k >> 1) < n_steps && lo < hi) F = (k & 1) ? hi - 1 : lo;
+        if ((k >> 1) < n_steps && lo < hi && !(spread && (k & 1))) F = (k & 1) ? hi - 1 : lo;
         col = 13 * dord;
     } else {
-        // without deltas: the selection product of a transposed step spreads over its 16 rows (two rows tell), a chained step stores the
+        // without deltas: the selection product of a transposed step spreads over its 16 rows (one row tells), a chained step stores the
         // ring's rows as they are (every row is looked at)
-        const int T = (int)(a.frame_off[ch.utt + 1] - f0);
         const int rb = ta + 16 * (k >> 4), r = k & 15;
         const bool spread = sa.tstep != 0 && rb - 8 >= 1 && rb + 16 <= T - 2;
         const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
-        const int Fc = spread ? (r == 0 ? lo : (r == 1 ? hi - 1 : -1)) : rb - 4 + r;
+        const int Fc = spread ? (r == 0 ? lo : -1) : rb - 4 + r;
         if ((k >> 4) < n_steps && Fc >= lo && Fc < hi) F = Fc;
     }
     if (F < 0) return;
