@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
                 // (a zero weight of the PADDING silences whatever the sample holds — rows run past the window's last tap into the samples behind
                 //  the frame, in windows shorter than 32 (NZ - 1) + 1 taps more rows than one: the legacy product, cplx.hpp, on every row of
                 //  this fallback kernel: one instruction per row more than the packed product.  The wave-stream kernel takes the plain
-                //  product and sends the chunks a leak shows up in to its second kernel.)
+                //  product; its scan kernel finds the chunks a leak shows up in and its third kernel redoes them.)
                 z[n1] = wmul_edge(y, wreg[n1 < NZ ? n1 : 0]);
             } else {
                 z[n1] = v2f{0.f, 0.f};
