@@ -856,7 +856,7 @@ int ssp_centroids(ssp_ctx* ctx, const float* X, const int32_t* labels, int64_t N
     SSP_TRY(rc);
     const int32_t* dL = (const int32_t*)sl.in(ctx, labels, (size_t)N * sizeof(int32_t), where, &rc);
     SSP_TRY(rc);
-    float* dO = (float*)so.out(out, (size_t)S * d * sizeof(float), where, &rc);
+    float* dO = (float*)so.out(ctx, out, (size_t)S * d * sizeof(float), where, &rc);
     SSP_TRY(rc);
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
@@ -922,11 +922,11 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
     SSP_TRY(rc);
     const float* dC = (const float*)sc.in(ctx, C, (size_t)S * d * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    float* dD = (float*)sd.out(dist_out, (size_t)N * S * sizeof(float), where, &rc);
+    float* dD = (float*)sd.out(ctx, dist_out, (size_t)N * S * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    int32_t* dA = (int32_t*)sa.out(argmin_out, (size_t)N * sizeof(int32_t), where, &rc);
+    int32_t* dA = (int32_t*)sa.out(ctx, argmin_out, (size_t)N * sizeof(int32_t), where, &rc);
     SSP_TRY(rc);
-    float* dM = (float*)sm.out(min_out, (size_t)N * sizeof(float), where, &rc);
+    float* dM = (float*)sm.out(ctx, min_out, (size_t)N * sizeof(float), where, &rc);
     SSP_TRY(rc);
     // (scratch lives on the ctx, grow-only: no allocation and no implicit synchronisation per call; calls on one ctx are stream-ordered)
     DevBuf &inc = ctx->cos_inc, &img = ctx->cos_img;

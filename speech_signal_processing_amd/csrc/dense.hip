@@ -202,7 +202,7 @@ extern "C" int ssp_dense_forward(ssp_ctx* ctx, const float* X, int64_t N, int32_
     SSP_TRY(rc);
     const float* dB = (const float*)sb.in(ctx, bias, (size_t)units * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    float* dY = (float*)sy.out(Y, (size_t)N * units * sizeof(float), where, &rc);
+    float* dY = (float*)sy.out(ctx, Y, (size_t)N * units * sizeof(float), where, &rc);
     SSP_TRY(rc);
     if (d_in <= 256 && !getenv("SSP_DENSE_NO_REG")) {  // samples held in registers, weight tiles streamed (cosine.hip): the network's hidden layers
         Timer tr;

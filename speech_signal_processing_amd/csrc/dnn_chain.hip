@@ -254,7 +254,7 @@ int ssp_dnn_forward(ssp_dnn* dnn, const float* X, int64_t N, float* Y, int where
     int rc;
     const float* dX = (const float*)sx.in(ctx, X, (size_t)N * dnn->dims[0] * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    float* dY = (float*)sy.out(Y, (size_t)N * dnn->dims[(size_t)L] * sizeof(float), where, &rc);
+    float* dY = (float*)sy.out(ctx, Y, (size_t)N * dnn->dims[(size_t)L] * sizeof(float), where, &rc);
     SSP_TRY(rc);
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, s));

@@ -257,7 +257,7 @@ extern "C" int ssp_dtw_distances(ssp_ctx* ctx, const float* xq, const ssp_segmen
     SSP_TRY(rc);
     const float* dt = (const float*)st.in(ctx, xt, (size_t)rows_t * dim * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    float* dout = (float*)so.out(dist_out, (size_t)n_pairs * sizeof(float), where, &rc);
+    float* dout = (float*)so.out(ctx, dist_out, (size_t)n_pairs * sizeof(float), where, &rc);
     SSP_TRY(rc);
     // column block per lane: the smallest of {4, 8, (12,) 16, (20, 24,) 32} that covers the longest template in one super-block, else 32
     const int need = (int)((max_c + 63) / 64);

@@ -225,7 +225,7 @@ int ssp_enframe(ssp_ctx* ctx, const float* samples, int64_t n, int32_t frame_siz
     SSP_TRY(rc);
     const float* d_w = (const float*)sw.in(ctx, window, (size_t)frame_size * sizeof(float), SSP_HOST, &rc);
     SSP_TRY(rc);
-    float* d_out = (float*)sout.out(frames_out, out_bytes, where, &rc);
+    float* d_out = (float*)sout.out(ctx, frames_out, out_bytes, where, &rc);
     SSP_TRY(rc);
     const int grid = (int)std::min<int64_t>(ceil_div<int64_t>((int64_t)frame_size * n_frames, 256), (int64_t)ctx->num_cu * 8);
     Timer tm;
@@ -257,7 +257,7 @@ int ssp_cepstrum(ssp_ctx* ctx, const float* X, int64_t n_rows, int32_t n_bins, c
     SSP_TRY(rc);
     const float* dD = (const float*)sd.in(ctx, dct, (size_t)n_ceps * n_filt * sizeof(float), SSP_HOST, &rc);
     SSP_TRY(rc);
-    float* dO = (float*)so.out(out, (size_t)n_rows * n_ceps * sizeof(float), where, &rc);
+    float* dO = (float*)so.out(ctx, out, (size_t)n_rows * n_ceps * sizeof(float), where, &rc);
     SSP_TRY(rc);
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
@@ -286,7 +286,7 @@ int ssp_delta(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, i
     int rc;
     const float* d_in = (const float*)sin.in(ctx, feats, bytes, where, &rc);
     SSP_TRY(rc);
-    float* d_out = (float*)sout.out(out, bytes, where, &rc);
+    float* d_out = (float*)sout.out(ctx, out, bytes, where, &rc);
     SSP_TRY(rc);
     int den = 0;
     for (int i = 1; i <= N; ++i) den += 2 * i * i;
@@ -322,7 +322,7 @@ int ssp_cmvn(ssp_ctx* ctx, const float* feats, const ssp_segments* frame_seg, in
     int rc;
     const float* d_in = (const float*)sin.in(ctx, feats, bytes, where, &rc);
     SSP_TRY(rc);
-    float* d_out = (float*)sout.out(out, bytes, where, &rc);
+    float* d_out = (float*)sout.out(ctx, out, bytes, where, &rc);
     SSP_TRY(rc);
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));
@@ -363,7 +363,7 @@ extern "C" int ssp_spectrum_abs(ssp_ctx* ctx, const float* reim, int64_t n_rows,
     int rc;
     const float* dI = (const float*)si.in(ctx, reim, (size_t)n * 2 * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    float* dO = (float*)so.out(out, (size_t)n * sizeof(float), where, &rc);
+    float* dO = (float*)so.out(ctx, out, (size_t)n * sizeof(float), where, &rc);
     SSP_TRY(rc);
     Timer tm;
     SSP_TRY(tm.start(kernel_ms != nullptr, ctx->stream));

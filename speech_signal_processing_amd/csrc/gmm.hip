@@ -1122,14 +1122,14 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     const float* d_feats = (const float*)sin.in(ctx, feats, (size_t)F * gmm->D * sizeof(float), where, &rc);
     SSP_TRY(rc);
     const size_t ll_bytes = (size_t)M * (size_t)std::max<int64_t>(F, 1) * sizeof(float);
-    float* d_sc = (float*)ssc.out(scores_out, (size_t)n_utt * M * sizeof(float), where, &rc);
+    float* d_sc = (float*)ssc.out(ctx, scores_out, (size_t)n_utt * M * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    int32_t* d_am = (int32_t*)sam.out(argmax_out, (size_t)n_utt * sizeof(int32_t), where, &rc);
+    int32_t* d_am = (int32_t*)sam.out(ctx, argmax_out, (size_t)n_utt * sizeof(int32_t), where, &rc);
     SSP_TRY(rc);
     Timer tm;
     if (loglik_out) {
         // the caller wants score_samples: the whole [M x F] matrix in one pass, per-utterance means from it
-        float* d_ll = (float*)sll.out(loglik_out, ll_bytes, where, &rc);
+        float* d_ll = (float*)sll.out(ctx, loglik_out, ll_bytes, where, &rc);
         SSP_TRY(rc);
         SSP_TRY(tm.start(kernel_ms != nullptr, s));
         GmmArgs a{};

@@ -513,7 +513,7 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     const size_t out_bytes = (size_t)(frame_seg->host.back()) * plan->d_out * sizeof(float);
     const float* d_samples = (const float*)sin.in(plan->ctx, samples, (size_t)n_samp_total * sizeof(float), where, &rc);
     SSP_TRY(rc);
-    float* d_out = (float*)sout.out(feats_out, out_bytes, where, &rc);
+    float* d_out = (float*)sout.out(plan->ctx, feats_out, out_bytes, where, &rc);
     SSP_TRY(rc);
 
     MfccArgs a = plan->args;

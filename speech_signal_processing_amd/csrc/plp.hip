@@ -219,7 +219,7 @@ extern "C" int ssp_plp_post(ssp_ctx* ctx, const float* logspec, const ssp_segmen
     int rc;
     const float* d_x = (const float*)sin.in(ctx, logspec, in_bytes, where, &rc);
     SSP_TRY(rc);
-    float* d_out = (float*)sout.out(ceps_out, out_bytes, where, &rc);
+    float* d_out = (float*)sout.out(ctx, ceps_out, out_bytes, where, &rc);
     SSP_TRY(rc);
     const float* d_in = d_x;
     Timer tm;
