@@ -10,7 +10,9 @@
  *   - every function returns SSP_OK (0) or a negative ssp_status; ssp_last_error() returns a
  *     thread-local message for the last failure on the calling thread.  Nothing aborts.
  *   - `where` = SSP_HOST (0): bulk arrays are host pointers, the library stages them through
- *     device scratch;  SSP_DEVICE (1): bulk arrays are device pointers on the ctx's device.
+ *     device scratch the ctx keeps between calls (up to 8 buffers of at most 64 MiB; larger
+ *     operands get a buffer of their own for the call);  SSP_DEVICE (1): bulk arrays are
+ *     device pointers on the ctx's device.
  *   - segment offsets (per-utterance sample / frame offsets) are small host-side metadata:
  *     they are always HOST int64 arrays and are uploaded once into an ssp_segments handle.
  *   - one ssp_ctx = one HIP device + one stream.  A ctx is not thread-safe; distinct ctxs are.
