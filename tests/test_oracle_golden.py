@@ -74,6 +74,34 @@ def test_scale_matches_sklearn(golden):
     np.testing.assert_allclose(O.scale(g["scale_one_in"]), g["scale_one_out"], rtol=0, atol=1e-12)
 
 
+def test_scale_constant_columns_match_the_installed_sklearn():
+    """A constant column whose float64 mean is an ulp off the constant (an all-silent utterance of a dialect with a log floor: every
+    frame the same; c0 = -50.59...): the library's SECOND re-centring (sk:preprocessing/_data.py:279-292) makes it zeros, a restatement
+    without it returns -1 / +1 — tools/fuzz_mfcc_batch.py found the kernels (zeros) and the oracle apart there.  scikit-learn is part
+    of the image on both sides, so the restatement is compared with the library itself, on that case and on seeded random ones."""
+    import warnings
+    preprocessing = pytest.importorskip("sklearn.preprocessing")
+    rng = np.random.default_rng(5)
+    c0 = float(-np.sqrt(40.0) * 8.0)   # DCT-II ortho term 0 of forty log10(1e-8)
+    cases = [np.tile(np.array([[c0, 0.0, 1e-3, -7.25]]), (13, 1)),
+             np.tile(rng.standard_normal((1, 39)) * 40.0, (29, 1)),
+             np.hstack([np.full((17, 1), 1.0 / 3.0), rng.standard_normal((17, 3)), np.full((17, 1), -50.59644256269407)]),
+             rng.standard_normal((298, 26)) * 5.0 + 3.0,
+             (rng.standard_normal((50, 13)) * 1e-9) + 1e3]
+    hit = False
+    for X in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = preprocessing.scale(X.copy())
+        got = O.scale(X)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+        const = (X == X[:1]).all(axis=0)
+        if const.any():
+            assert np.abs(ref[:, const]).max() == 0.0
+            hit = hit or bool(np.nanstd(X, axis=0)[const].max() > 0)
+    assert hit   # (at least one constant column whose computed standard deviation is NOT zero: the case the second re-centring is for)
+
+
 def test_scale_nan_rows_match_sklearn(golden):
     """NaN rows (digital silence through a dialect without a log floor, GMM_UBM.py:89-93): statistics over the other entries, NaN kept;
     +-inf raises like the library (tests/golden/make_golden_nan.py)."""

@@ -1,0 +1,113 @@
+"""Randomised MACHINE-FILLING batches through the wave-stream MFCC kernels (auto mode) against the generic kernel on the same device
+arrays and, for a sample of utterances (every one that got a silent stretch or a NaN sample among them), against the float64 oracle.
+tools/fuzz_mfcc.py covers the dialect / hop / length space with a handful of utterances per case; this one covers what only a large
+ragged batch exercises: the chunk table (cuts, tail split, halos), the claim loop over thousands of chunks per wave, the scan kernel's
+looks over cut chunks and the third kernel's walk of a few flagged chunks among many clean ones.  Run on the GPU box:
+    python tools/fuzz_mfcc_batch.py [seed] [cases]"""
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+import speech_signal_processing_amd as pkg
+from speech_signal_processing_amd import api
+from oracle import ref_cpu as O
+
+ctx = api.default_context()
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+rng = np.random.default_rng(seed)
+gen_t = torch.Generator(device="cuda").manual_seed(seed)
+worst_pair = worst_ref = 0.0
+only = int(os.environ.get("FUZZ_ONLY", "-1"))   # replay one case of a seed (the generators are advanced through the others)
+
+
+def dump(tag, **arrays):   # what a failure needs to be looked at off the box
+    os.makedirs("gpurun_out", exist_ok=True)
+    np.savez_compressed("gpurun_out/fuzz_batch_fail_%d_%s.npz" % (seed, tag), **arrays)
+
+
+t_start = time.time()
+for case in range(n_cases):
+    dialect = rng.choice(["sidekit", "sidekit", "inrepo"])
+    order, cmvn = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+    if dialect == "sidekit":
+        tables = pkg.preset_sidekit(fs=16000, delta_order=order, cmvn=cmvn)
+        cfg, w, fb, dct = O.sidekit_tables(delta_order=order, cmvn=cmvn)
+    else:
+        fs, step = int(rng.choice([8000, 16000])), int(rng.choice([160, 256]))
+        tables = pkg.preset_inrepo(fs, 512, step, delta_order=order, cmvn=cmvn)
+        cfg, w, fb, dct = O.inrepo_tables(fs, 512, step)
+        cfg["delta_order"], cfg["cmvn"] = order, cmvn
+    n_utt = int(rng.integers(3000, 30000))
+    kind = rng.random(n_utt)
+    lens = np.where(kind < 0.05, rng.integers(1, 900, n_utt),                      # shorter than a few frames / than one
+           np.where(kind < 0.93, rng.integers(4000, 60000, n_utt),                 # ordinary
+           np.where(kind < 0.995, rng.integers(60000, 200000, n_utt), rng.integers(200000, 900000, n_utt))))   # long: cut into chunks
+    if rng.random() < 0.3:
+        lens[:] = int(rng.integers(8000, 60000))                                   # all equal: the even split of the headline case
+    if cmvn:
+        lens = np.maximum(lens, 2000)
+    lens = [int(v) for v in lens]
+    total = int(np.sum(lens))
+    x = 0.3 * torch.randn(total, device="cuda", generator=gen_t)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    junk = []
+    for u in rng.choice(n_utt, int(rng.integers(0, 12)), replace=False):   # digital silence: ln 0 in the dialects without a floor
+        if lens[u] > 1200:
+            a0 = int(rng.integers(0, lens[u] - 400))
+            x[offs[u] + a0: offs[u] + min(a0 + int(rng.integers(400, 6000)), lens[u])] = 0.0
+            junk.append(int(u))
+    for u in rng.choice(n_utt, int(rng.integers(0, 6)), replace=False):
+        if lens[u] > 0:
+            x[offs[u] + int(rng.integers(0, lens[u]))] = float("nan")
+            junk.append(int(u))
+    if only >= 0 and case != only:
+        rng.choice(n_utt, 6, replace=False)   # (the draw of the oracle's sample below)
+        continue
+    plan = api.MfccPlan(ctx, tables)
+    seg = api.Segments.from_lengths(ctx, lens)
+    fseg = plan.frame_segments(seg)
+    auto = plan.run(x, seg, fseg, variant=0)
+    gen = plan.run(x, seg, fseg, variant=1)
+    torch.cuda.synchronize()
+    fo = torch.as_tensor(np.asarray(fseg.offsets), device="cuda")
+    n_fr = fo[1:] - fo[:-1]
+    uid = torch.repeat_interleave(torch.arange(n_utt, device="cuda"), n_fr)
+    fa, fg = torch.isfinite(auto), torch.isfinite(gen)
+    if not torch.equal(fa, fg):
+        rows = torch.nonzero((fa != fg).any(dim=1)).flatten()
+        raise AssertionError((case, dialect, order, cmvn, "finite pattern differs from the generic kernel's", "utterances",
+                              torch.unique(uid[rows])[:8].tolist(), "rows", rows[:8].tolist(), "junk in", sorted(junk)[:12]))
+    mag = torch.where(fg, gen.abs(), torch.zeros_like(gen)).amax(dim=1)
+    umax = torch.zeros(n_utt, device="cuda").scatter_reduce(0, uid, mag, "amax").clamp_min(1.0)
+    diff = torch.where(fg, (auto - gen).abs(), torch.zeros_like(gen)).amax(dim=1) / umax[uid]
+    if cmvn:  # (utterances left with a handful of finite rows: the scaling amplifies float32 rounding without bound — pattern only)
+        few = torch.zeros(n_utt, device="cuda").scatter_add(0, uid, fg.all(dim=1).float()) < 8
+        diff = torch.where(few[uid], torch.zeros_like(diff), diff)
+    e = float(diff.max()) if diff.numel() else 0.0
+    worst_pair = max(worst_pair, e)
+    assert e <= 2e-4, (case, dialect, order, cmvn, "stream vs generic", e, "utterance", int(uid[int(diff.argmax())]))
+    # the oracle on a sample: every utterance with junk, the longest, the shortest, a few at random
+    pick = set(junk) | {int(np.argmax(lens)), int(np.argmin(lens))} | {int(u) for u in rng.choice(n_utt, 6, replace=False)}
+    pick = [u for u in pick if lens[u] <= 400000][:40]
+    for u in pick:
+        s = x[offs[u]: offs[u + 1]].cpu().numpy()
+        with np.errstate(all='ignore'):
+            ref = O.mfcc_pipeline(s, cfg, w, fb, dct)
+        g = auto[int(fo[u]): int(fo[u + 1])].cpu().numpy()
+        assert g.shape == ref.shape, (case, u, g.shape, ref.shape)
+        if ref.size == 0:
+            continue
+        fin = np.isfinite(ref)
+        assert (np.isfinite(g) == fin).all(), (case, dialect, order, cmvn, u, lens[u], "finite pattern vs oracle",
+                                               np.unique(np.nonzero(np.isfinite(g) != fin)[0])[:10].tolist())
+        if not fin.any() or (cmvn and fin.sum(axis=0).min() < 8):
+            continue
+        err = np.abs(g[fin] - ref[fin]).max() / max(1.0, np.abs(ref[fin]).max())
+        worst_ref = max(worst_ref, err)
+        if err > 1e-4:
+            dump("%d_%d" % (case, u), samples=s, got=g, ref=ref, generic=gen[int(fo[u]): int(fo[u + 1])].cpu().numpy(),
+                 what=np.array([str(dialect), str(order), str(cmvn), str(cfg.get("hop", "")), str(cfg.get("sample_rate", ""))]))
+        assert err <= 1e-4, (case, dialect, order, cmvn, u, lens[u], "vs oracle", err)
+    print("case %d: %s order %d cmvn %d, %d utterances, %.1f M samples, %d with junk: stream-vs-generic %.2e" %
+          (case, dialect, order, cmvn, n_utt, total / 1e6, len(set(junk)), e), flush=True)
+    del x, auto, gen
+print("fuzz_batch OK: %d cases, worst stream-vs-generic %.2e, worst vs oracle %.2e, %.1f s" % (n_cases, worst_pair, worst_ref, time.time() - t_start))
