@@ -16,6 +16,7 @@ n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rng = np.random.default_rng(seed)
 gen_t = torch.Generator(device="cuda").manual_seed(seed)
 worst_pair = worst_ref = 0.0
+DIALECTS = os.environ.get("FUZZ_DIALECTS", "sidekit,sidekit,inrepo,librosa,plp").split(",")
 only = int(os.environ.get("FUZZ_ONLY", "-1"))   # replay one case of a seed (the generators are advanced through the others)
 
 
@@ -26,9 +27,20 @@ def dump(tag, **arrays):   # what a failure needs to be looked at off the box
 
 t_start = time.time()
 for case in range(n_cases):
-    dialect = rng.choice(["sidekit", "sidekit", "inrepo"])
+    dialect = rng.choice(DIALECTS)
     order, cmvn = int(rng.integers(0, 3)), int(rng.integers(0, 2))
-    if dialect == "sidekit":
+    min_len = 1
+    if dialect == "librosa":   # the 2048-point stream kernel: utterance maxima by buffer atomics from every lane, clamp in a second pass
+        order = cmvn = 0
+        fs = int(rng.choice([8000, 16000]))
+        tables = pkg.preset_librosa(fs, 13)
+        cfg, w, fb, dct = O.librosa_tables(fs, 13)
+        min_len = 1025
+    elif dialect == "plp":     # the dense-band instance
+        order = cmvn = 0
+        tables = pkg.preset_sidekit_plp()
+        cfg, w, fb, dct = O.sidekit_plp_tables()
+    elif dialect == "sidekit":
         tables = pkg.preset_sidekit(fs=16000, delta_order=order, cmvn=cmvn)
         cfg, w, fb, dct = O.sidekit_tables(delta_order=order, cmvn=cmvn)
     else:
@@ -45,6 +57,7 @@ for case in range(n_cases):
         lens[:] = int(rng.integers(8000, 60000))                                   # all equal: the even split of the headline case
     if cmvn:
         lens = np.maximum(lens, 2000)
+    lens = np.maximum(lens, min_len)
     lens = [int(v) for v in lens]
     total = int(np.sum(lens))
     x = 0.3 * torch.randn(total, device="cuda", generator=gen_t)
