@@ -2122,3 +2122,33 @@ def test_nonfinite_positions_sweep_against_chunk_and_step_borders(ssp, order, cm
             assert (np.isfinite(got[u]) == fin).all(), (order, cmvn, k, u, int((np.isfinite(got[u]) != fin).sum()))
             if fin.any() and not (cmvn and fin.all(axis=1).sum() < 8):
                 assert np.abs(got[u][fin] - refs[u][fin]).max() <= 1e-4 * max(1.0, float(np.abs(refs[u][fin]).max())), (order, cmvn, k, u)
+
+
+def test_host_pointer_calls_reuse_the_contexts_staging_buffers():
+    """SSP_HOST calls stage through buffers the context keeps (common.hpp StagePool: eight grow-only slots, 64 MiB cap each, an operand
+    above the cap gets its own buffer for the call).  A sequence that walks every branch — growing sizes, an operand above the cap, more
+    staged operands in one call than the previous ones used, then small again, two contexts side by side — must give what the oracle
+    gives (GMM_UBM.py:53-69, d_vector.py:315-319) whichever slot a call lands in."""
+    from oracle import ref_cpu as O
+    from speech_signal_processing_amd import api
+    rng = np.random.default_rng(77)
+    ctxs = [api.default_context(), api.Context(0)]
+    sizes = [5, 298, 40000, 1400000, 298, 3, 200000, 1400001, 17]        # x 13 floats: 1.4 M rows = 73 MB, above the cap
+    for i, T in enumerate(sizes):
+        ctx = ctxs[i % 2]
+        f = rng.standard_normal((T, 13)).astype(np.float32)
+        seg = api.Segments.from_lengths(ctx, [T // 3, T - T // 3])
+        got = np.asarray(api.delta_features(ctx, f, seg, 2))
+        ref = np.concatenate([O.delta(f[: T // 3]), O.delta(f[T // 3:])]) if T // 3 else O.delta(f)
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (i, T)
+        got = np.asarray(api.cmvn_features(ctx, f, seg))
+        ref = np.concatenate([O.scale(f[: T // 3].astype(np.float64)), O.scale(f[T // 3:].astype(np.float64))]) if T // 3 else O.scale(f.astype(np.float64))
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (i, T)
+        # five staged operands in one call (X, C in; distances, arg-min, minimum out), sizes that differ from the ones above
+        N, S, d = int(rng.integers(1, 3000)), int(rng.integers(1, 300)), int(rng.choice([13, 64, 256]))
+        X, Cn = rng.standard_normal((N, d)).astype(np.float32), rng.standard_normal((S, d)).astype(np.float32)
+        r = api.cosine_identify(ctx, X, Cn, dist=True)
+        refd = O.cosine_matrix(X, Cn)
+        assert np.abs(np.asarray(r["dist"]) - refd).max() < 2e-5, (i, N, S, d)
+        assert np.abs(np.asarray(r["min"]) - refd.min(1)).max() < 2e-5, (i, N, S, d)
+    ctxs[1].close()
