@@ -2152,3 +2152,35 @@ def test_host_pointer_calls_reuse_the_contexts_staging_buffers():
         assert np.abs(np.asarray(r["dist"]) - refd).max() < 2e-5, (i, N, S, d)
         assert np.abs(np.asarray(r["min"]) - refd.min(1)).max() < 2e-5, (i, N, S, d)
     ctxs[1].close()
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("equal", [True, False])
+def test_scaling_instances_at_every_width(order, equal):
+    """preprocessing.scale inside the stream kernel (GMM_UBM.py:93) at 13 / 26 / 39 columns: the scaling pass reads its column sums off
+    the stored rows with 64 // columns lane groups sharing the rows (4 / 2 / 1) — the 13-column case merges four groups, which a
+    machine-filling batch of equal lengths was the first to exercise (tools/fuzz_mfcc_batch.py, round 5).  Stream kernel against the
+    generic kernel on every row, against the oracle on a few utterances."""
+    import torch
+    import speech_signal_processing_amd as pkg
+    from speech_signal_processing_amd import api
+    from oracle import ref_cpu as O
+    ctx = api.default_context()
+    rng = np.random.default_rng(40 + order)
+    n_utt = 6000
+    lens = np.full(n_utt, 42284) if equal else rng.integers(2000, 80000, n_utt)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    g = torch.Generator(device="cuda").manual_seed(order)
+    x = 0.3 * torch.randn(int(offs[-1]), device="cuda", generator=g)
+    plan = api.MfccPlan(ctx, pkg.preset_sidekit(fs=16000, delta_order=order, cmvn=1))
+    seg = api.Segments.from_lengths(ctx, [int(v) for v in lens])
+    fseg = plan.frame_segments(seg)
+    auto = plan.run(x, seg, fseg, variant=0)
+    gen = plan.run(x, seg, fseg, variant=1)
+    assert auto.shape[1] == 13 * (order + 1)
+    assert float((auto - gen).abs().max()) <= 2e-4 * max(1.0, float(gen.abs().max()))
+    cfg, w, fb, dct = O.sidekit_tables(delta_order=order, cmvn=1)
+    fo = np.asarray(fseg.offsets)
+    for u in (0, 1, n_utt // 2, n_utt - 1):
+        ref = O.mfcc_pipeline(x[offs[u]: offs[u + 1]].cpu().numpy(), cfg, w, fb, dct)
+        assert_feat_close(auto[int(fo[u]): int(fo[u + 1])].cpu().numpy(), ref, what="scaled %d-d, utterance %d" % (13 * (order + 1), u))

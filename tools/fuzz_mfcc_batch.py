@@ -97,6 +97,12 @@ for case in range(n_cases):
         diff = torch.where(few[uid], torch.zeros_like(diff), diff)
     e = float(diff.max()) if diff.numel() else 0.0
     worst_pair = max(worst_pair, e)
+    if e > 2e-4:
+        ub = int(uid[int(diff.argmax())])
+        badu = torch.unique(uid[diff > 2e-4])
+        dump("%d_pair_%d" % (case, ub), samples=x[offs[ub]: offs[ub + 1]].cpu().numpy(), got=auto[int(fo[ub]): int(fo[ub + 1])].cpu().numpy(),
+             generic=gen[int(fo[ub]): int(fo[ub + 1])].cpu().numpy(), bad_utts=badu.cpu().numpy(), lens=np.asarray(lens),
+             what=np.array([str(dialect), str(order), str(cmvn)]))
     assert e <= 2e-4, (case, dialect, order, cmvn, "stream vs generic", e, "utterance", int(uid[int(diff.argmax())]))
     # the oracle on a sample: every utterance with junk, the longest, the shortest, a few at random
     pick = set(junk) | {int(np.argmax(lens)), int(np.argmin(lens))} | {int(u) for u in rng.choice(n_utt, 6, replace=False)}
