@@ -72,8 +72,8 @@ int build_stream_tables(ssp_mfcc_plan* p) {
 // (each is a sum over the same log-mel row; a non-finite term times any weight, zero included, is non-finite; finite rows of O(10) cannot
 // overflow), and a matrix product spreads a non-finite operand over every element it contributes to with ANY weight, zero included:
 //   * transposed step (interior steps of the non-scaling instances): the delta product contracts over all 24 frames of the step's window
-//     and the selection product (delta_order 0) over exactly the 16 frames it emits — one non-finite frame in reach makes the delta
-//     columns (delta_order 0: the cepstra) of EVERY emitted row of the step non-finite;
+//     — one non-finite frame in reach makes the delta columns of EVERY emitted row of the step non-finite; the cepstra leave straight
+//     from the ring (a row is wrong only if its own frame is);
 //   * chained step (utterance ends; every step of the scaling instances): cepstra leave straight from the ring (a row is wrong only if
 //     its own frame is), delta tile 0 = emitted rows up to rb + 9 contracts over frames rb - 8 .. rb + 11, tile 1 = rows rb + 10,
 //     rb + 11 over rb + 8 .. rb + 15, delta-delta over both tiles — so the delta columns of the FIRST and the LAST emitted row of a step
@@ -82,8 +82,7 @@ int build_stream_tables(ssp_mfcc_plan* p) {
 // A row is wrong in the first kernel's output only if it is non-finite there (finite rows were formed from finite operands by the same
 // sums as ever), so: delta_order >= 1 — the first column of the HIGHEST-order block (its product sees everything the lower ones saw: the
 // chained delta-delta contracts over both delta tiles) of one emitted row of a transposed step, of the first and the last emitted row
-// of a chained one; delta_order 0 — the first cepstrum of one row of a transposed step, of every emitted row of a chained one (it has no
-// product that would spread a leaked NaN sample's frame).  Rows that are non-finite in the reference too are flagged as well; the
+// of a chained one; delta_order 0 — the first cepstrum of every emitted row (no product that would spread a leaked NaN sample's frame).  Rows that are non-finite in the reference too are flagged as well; the
 // third kernel reproduces them.  Cost: one 32-byte sector per 16 rows and a few more at the utterance ends.
 // One THREAD per (chunk, look): `per_chunk` looks per chunk (enough for the longest chunk of the table; a look past a chunk's last
 // step does nothing), each three dependent loads deep — chunk record, frame offset, the row's word — and millions of them in flight.
@@ -110,12 +109,10 @@ __global__ __launch_bounds__(256) void mfcc_stream_scan_kernel(MfccArgs a, Strea
         if ((k >> 1) < n_steps && lo < hi && !(spread && (k & 1))) F = (k & 1) ? hi - 1 : lo;
         col = 13 * dord;
     } else {
-        // without deltas: the selection product of a transposed step spreads over its 16 rows (one row tells), a chained step stores the
-        // ring's rows as they are (every row is looked at)
+        // without deltas both step forms store the ring's rows as they are: every row is looked at
         const int rb = ta + 16 * (k >> 4), r = k & 15;
-        const bool spread = sa.tstep != 0 && rb - 8 >= 1 && rb + 16 <= T - 2;
         const int lo = max(rb - 4, t0), hi = min(rb + 12, t0 + n);
-        const int Fc = spread ? (r == 0 ? lo : -1) : rb - 4 + r;
+        const int Fc = rb - 4 + r;
         if ((k >> 4) < n_steps && Fc >= lo && Fc < hi) F = Fc;
     }
     if (F < 0) return;

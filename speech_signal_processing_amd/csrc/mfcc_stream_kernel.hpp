@@ -616,9 +616,12 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.x), ro, row4 + blk * (nc * 4), 0, 0);
             };
             {
-                v4f c = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 1; s < 5; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[s], (ef + (float)(4 * s)) == 0.f ? 1.f : 0.f, c, 0, 0, 0);
+                // the cepstra of this lane's frame need no product (until round 5 they took four with a unit matrix): four consecutive
+                // cepstra of one frame are 16 contiguous bytes of its ring row.  (A non-finite frame therefore stays in its own row of this
+                // block; what the scan kernel looks at is the delta block, or every row when there are no deltas.)
+                int slot = (rb + 20) % RING_FRAMES + j;  // (rb - 4 + j) mod 24
+                slot = slot >= RING_FRAMES ? slot - RING_FRAMES : slot;
+                const v4f c = *reinterpret_cast<const v4f*>(ring + slot * RING_ROW + g * 16);
                 store(c, 0);
             }
             if (dord >= 1) {
