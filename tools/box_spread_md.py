@@ -49,7 +49,8 @@ if os.path.exists("profiles/r05_box_spread_final.jsonl"):
         boxes2[-1][1][r["lib"]] = r
     out += ["", "## The final library of round 5 (three kernels per launch, DESIGN.md 4.1) against the same round-3 kernels", "",
             "The table above was taken with the mid-round library, whose first kernel sat in the slow one of its two speed states (DESIGN.md 4.1a).",
-            "Same procedure on further fresh boxes with the library as shipped:", "",
+            "Same procedure on further fresh boxes with the three-kernel library (taken before the last change of the round, the cepstra block",
+            "of the transposed step read straight from the ring: the shipped library is another 0.6 % faster, profiles/r05_ab_regression.txt 9):", "",
             "| box (card) | lib | kernel ms | sustained ms | sclk MHz | power W | junction C | copy GB/s | fma TFLOP/s | at 2 GHz, ms |", "|---|---|---|---|---|---|---|---|---|---|"]
     for i, (card, libs) in enumerate(boxes2, len(boxes) + 1):
         for lib in ("-", "r3"):
