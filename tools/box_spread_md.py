@@ -4,7 +4,7 @@ rows = [json.loads(l) for l in open(sys.argv[1] if len(sys.argv) > 1 else "profi
 boxes = []
 for r in rows:
     key = (r["card"], r["time"][:5])
-    if not boxes or boxes[-1][0] != r["card"]:
+    if not boxes or boxes[-1][0] != r["card"] or r["lib"] in boxes[-1][1]:
         boxes.append((r["card"], {}))
     boxes[-1][1][r["lib"]] = r
 out = ["# Round 5: what a gpurun box is worth (verdict r4, task 2)", "",
@@ -38,33 +38,40 @@ if both:
             "chains are in family) and the faster LIBRARY runs at the lower clock on every box (it keeps more of the chip busy per cycle).  The CYCLES of a pass",
             "hold to 3 % over all boxes: `value_normalised` = the headline at a nominal 2.0 GHz takes the raw 10 % spread to 3 %.  The FMA / copy figures",
             "(137 - 143 TFLOP/s, 5.5 - 5.8 TB/s) do not track the pass — the FMA chains alone do not reach the cap's clock regime — and serve to spot a sick box."]
-# the FINAL library of the round (three-kernel launch: the first kernel in its fast state), same procedure, other boxes
+# later libraries of the round, same procedure, other boxes
 import os
-if os.path.exists("profiles/r05_box_spread_final.jsonl"):
-    rows2 = [json.loads(l) for l in open("profiles/r05_box_spread_final.jsonl")]
+n_prev = len(boxes)
+for path, title, intro, name in (
+        ("profiles/r05_box_spread_final.jsonl", "The three-kernel library (DESIGN.md 4.1) against the same round-3 kernels",
+         ["The table above was taken with the mid-round library, whose first kernel sat in the slow one of its two speed states (DESIGN.md 4.1a).",
+          "Same procedure on further fresh boxes with the three-kernel library (taken before the last change of the round, the cepstra block",
+          "of the transposed step read straight from the ring: profiles/r05_ab_regression.txt 9):"], "three-kernel"),
+        ("profiles/r05_box_spread_shipped.jsonl", "The library as shipped (three kernels + ring-copy step) against the same round-3 kernels",
+         ["Same procedure, the tree at the end of the round:"], "shipped")):
+    if not os.path.exists(path):
+        continue
+    rows2 = [json.loads(l) for l in open(path)]
     boxes2 = []
     for r in rows2:
-        if not boxes2 or boxes2[-1][0] != r["card"]:
+        if not boxes2 or boxes2[-1][0] != r["card"] or r["lib"] in boxes2[-1][1]:   # (a row of a library already present = the next box)
             boxes2.append((r["card"], {}))
         boxes2[-1][1][r["lib"]] = r
-    out += ["", "## The final library of round 5 (three kernels per launch, DESIGN.md 4.1) against the same round-3 kernels", "",
-            "The table above was taken with the mid-round library, whose first kernel sat in the slow one of its two speed states (DESIGN.md 4.1a).",
-            "Same procedure on further fresh boxes with the three-kernel library (taken before the last change of the round, the cepstra block",
-            "of the transposed step read straight from the ring: the shipped library is another 0.6 % faster, profiles/r05_ab_regression.txt 9):", "",
+    out += ["", "## " + title, ""] + intro + ["",
             "| box (card) | lib | kernel ms | sustained ms | sclk MHz | power W | junction C | copy GB/s | fma TFLOP/s | at 2 GHz, ms |", "|---|---|---|---|---|---|---|---|---|---|"]
-    for i, (card, libs) in enumerate(boxes2, len(boxes) + 1):
+    for i, (card, libs) in enumerate(boxes2, n_prev + 1):
         for lib in ("-", "r3"):
             if lib in libs:
                 r = libs[lib]
-                out.append("| %d (%s) | %s | %.3f | %.3f | %s | %s | %s | %s | %s | %s |" % (i, card[5:], "round 5 final" if lib == "-" else "round 3", r["kernel_ms"], r["sustained_ms"], f(r["sclk_mhz"], 0),
+                out.append("| %d (%s) | %s | %.3f | %.3f | %s | %s | %s | %s | %s | %s |" % (i, card[5:], "round 5 " + name if lib == "-" else "round 3", r["kernel_ms"], r["sustained_ms"], f(r["sclk_mhz"], 0),
                                                                                        f(r["power_w"], 0), f(r["junction_c"]), f(r["copy_gbs"], 0), f(r["fma_tflops"]), f(r["kernel_ms"] * r["sclk_mhz"] / 2000.0, 3)))
+    n_prev += len(boxes2)
     v = [b[1]["-"]["kernel_ms"] for b in boxes2 if "-" in b[1]]
     n = [b[1]["-"]["kernel_ms"] * b[1]["-"]["sclk_mhz"] / 2000.0 for b in boxes2 if "-" in b[1]]
     both2 = [b[1]["-"]["kernel_ms"] / b[1]["r3"]["kernel_ms"] for b in boxes2 if "-" in b[1] and "r3" in b[1]]
     if len(v) > 1:
-        out += ["", "final library over %d boxes: kernel (all three kernels of a launch) %.3f - %.3f ms (spread %.1f %% of the median %.3f); at 2 GHz %.3f - %.3f ms (spread %.1f %%)." % (
-            len(v), min(v), max(v), 100 * (max(v) - min(v)) / statistics.median(v), statistics.median(v), min(n), max(n), 100 * (max(n) - min(n)) / statistics.median(n))]
+        out += ["", "%s library over %d boxes: kernel (all three kernels of a launch) %.3f - %.3f ms (spread %.1f %% of the median %.3f); at 2 GHz %.3f - %.3f ms (spread %.1f %%)." % (
+            name, len(v), min(v), max(v), 100 * (max(v) - min(v)) / statistics.median(v), statistics.median(v), min(n), max(n), 100 * (max(n) - min(n)) / statistics.median(n))]
     if both2:
-        out += ["Final / round 3 on the same box: %s (median %.3f)." % (", ".join("%.3f" % x for x in both2), statistics.median(both2))]
+        out += ["%s / round 3 on the same box: %s (median %.3f)." % (name, ", ".join("%.3f" % x for x in both2), statistics.median(both2))]
 open("profiles/r05_box_spread.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out[-12:]))
