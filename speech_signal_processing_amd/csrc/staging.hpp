@@ -1,0 +1,98 @@
+// Host-side staging of SSP_HOST calls (included twice by common.hpp: part 1 before ssp_ctx — the pool it holds —, part 2 behind it — the
+// per-operand helper).  No device code here: the file is deliberately NOT part of bench.py's kernel-source hash.
+#if SSP_STAGING_PART == 1
+#include <mutex>
+namespace ssp {
+// Staging buffers of SSP_HOST calls, kept by the ctx between calls: the reference's callers loop over utterances in Python, and a
+// hipMalloc + hipFree pair per staged operand costs up to 0.7 ms each once the allocator has no small block at hand (GMM_UBM.delta
+// took 1.4 ms a call in such a state, 0.06 ms with the buffers kept).  A slot is taken for the life of one Staged; all work of a
+// ctx is ordered on its one stream, so the next call may overwrite a slot without a host wait.  Buffers above KEEP_MAX are not kept.
+struct StagePool {
+    static constexpr int SLOTS = 8;
+    static constexpr size_t KEEP_MAX = (size_t)64 << 20;
+    DevBuf slot[SLOTS];
+    bool busy[SLOTS] = {};
+    std::mutex mu;  // (a ctx is not thread-safe, but before the pool two host-pointer calls on one ctx never shared a staging buffer: keep it so)
+    void give_back(int i) {
+        std::lock_guard<std::mutex> g(mu);
+        busy[i] = false;
+    }
+    // a free slot of at least n bytes: the smallest that fits, else the smallest free one grown to n; -1 = none free or n too large
+    int take(size_t n, int* rc) {
+        *rc = SSP_OK;
+        if (n > KEEP_MAX) return -1;
+        std::lock_guard<std::mutex> g(mu);
+        int fit = -1, spare = -1;
+        for (int i = 0; i < SLOTS; ++i) {
+            if (busy[i]) continue;
+            if (slot[i].p && slot[i].bytes >= n && (fit < 0 || slot[i].bytes < slot[fit].bytes)) fit = i;
+            if (spare < 0 || slot[i].bytes < slot[spare].bytes) spare = i;
+        }
+        if (fit < 0) {
+            if (spare < 0) return -1;
+            size_t want = n < 4096 ? 4096 : n + n / 4;  // headroom: utterance lengths vary from call to call
+            if (want > KEEP_MAX) want = KEEP_MAX;
+            *rc = slot[spare].alloc(want);
+            if (*rc != SSP_OK) return -1;
+            fit = spare;
+        }
+        busy[fit] = true;
+        return fit;
+    }
+};
+}  // namespace ssp
+#elif SSP_STAGING_PART == 2
+namespace ssp {
+// Staging helper for SSP_HOST calls: device copy of a host input / device scratch for an output.
+struct Staged {
+    DevBuf own;  // operands too large for the ctx's pool (or when all its slots are taken)
+    const ssp_ctx* pool = nullptr;
+    int slot = -1;
+    void* p = nullptr;
+    Staged() = default;
+    Staged(const Staged&) = delete;
+    Staged& operator=(const Staged&) = delete;
+    ~Staged() {
+        if (slot >= 0) pool->stage.give_back(slot);
+    }
+    int get(const ssp_ctx* ctx, size_t bytes) {
+        int rc;
+        if (slot >= 0) ctx->stage.give_back(slot);
+        slot = ctx->stage.take(bytes, &rc);
+        if (rc != SSP_OK) return rc;
+        if (slot >= 0) {
+            pool = ctx;
+            p = ctx->stage.slot[slot].p;
+            return SSP_OK;
+        }
+        rc = own.alloc(bytes);
+        p = own.p;
+        return rc;
+    }
+    const void* in(const ssp_ctx* ctx, const void* host, size_t bytes, int where, int* rc) {
+        *rc = SSP_OK;
+        if (where == SSP_DEVICE || host == nullptr) return host;
+        *rc = get(ctx, bytes);
+        if (*rc != SSP_OK) return nullptr;
+        hipError_t e = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            set_error("hipMemcpyAsync H2D failed: %s", hipGetErrorString(e));
+            *rc = SSP_ERR_HIP;
+            return nullptr;
+        }
+        return p;
+    }
+    void* out(const ssp_ctx* ctx, void* host, size_t bytes, int where, int* rc) {
+        *rc = SSP_OK;
+        if (where == SSP_DEVICE || host == nullptr) return host;
+        *rc = get(ctx, bytes);
+        return *rc == SSP_OK ? p : nullptr;
+    }
+    int back(const ssp_ctx* ctx, void* host, size_t bytes, int where) {
+        if (where == SSP_DEVICE || host == nullptr) return SSP_OK;
+        SSP_HIP(hipMemcpyAsync(host, p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return SSP_OK;
+    }
+};
+}  // namespace ssp
+#endif
