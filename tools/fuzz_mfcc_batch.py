@@ -3,7 +3,9 @@ arrays and, for a sample of utterances (every one that got a silent stretch or a
 tools/fuzz_mfcc.py covers the dialect / hop / length space with a handful of utterances per case; this one covers what only a large
 ragged batch exercises: the chunk table (cuts, tail split, halos), the claim loop over thousands of chunks per wave, the scan kernel's
 looks over cut chunks and the third kernel's walk of a few flagged chunks among many clean ones.  Run on the GPU box:
-    python tools/fuzz_mfcc_batch.py [seed] [cases]"""
+    python tools/fuzz_mfcc_batch.py [seed] [cases]
+(env: FUZZ_DIALECTS=sidekit,inrepo,librosa,plp  FUZZ_JUNK_FRAC=0.5 — that share of the utterances with silence / NaN samples: the third
+kernel under load —  FUZZ_ONLY=<case> — replay one case of a seed)"""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import speech_signal_processing_amd as pkg
@@ -17,6 +19,7 @@ rng = np.random.default_rng(seed)
 gen_t = torch.Generator(device="cuda").manual_seed(seed)
 worst_pair = worst_ref = 0.0
 DIALECTS = os.environ.get("FUZZ_DIALECTS", "sidekit,sidekit,inrepo,librosa,plp").split(",")
+JUNK_FRAC = float(os.environ.get("FUZZ_JUNK_FRAC", "0"))
 only = int(os.environ.get("FUZZ_ONLY", "-1"))   # replay one case of a seed (the generators are advanced through the others)
 
 
@@ -63,12 +66,15 @@ for case in range(n_cases):
     x = 0.3 * torch.randn(total, device="cuda", generator=gen_t)
     offs = np.concatenate([[0], np.cumsum(lens)])
     junk = []
-    for u in rng.choice(n_utt, int(rng.integers(0, 12)), replace=False):   # digital silence: ln 0 in the dialects without a floor
+    n_sil, n_nan = int(rng.integers(0, 12)), int(rng.integers(0, 6))
+    if JUNK_FRAC > 0:   # stress of the third kernel: a large share of the chunks flagged and walked again
+        n_sil, n_nan = int(JUNK_FRAC * n_utt), int(0.1 * JUNK_FRAC * n_utt)
+    for u in rng.choice(n_utt, n_sil, replace=False):   # digital silence: ln 0 in the dialects without a floor
         if lens[u] > 1200:
             a0 = int(rng.integers(0, lens[u] - 400))
             x[offs[u] + a0: offs[u] + min(a0 + int(rng.integers(400, 6000)), lens[u])] = 0.0
             junk.append(int(u))
-    for u in rng.choice(n_utt, int(rng.integers(0, 6)), replace=False):
+    for u in rng.choice(n_utt, n_nan, replace=False):
         if lens[u] > 0:
             x[offs[u] + int(rng.integers(0, lens[u]))] = float("nan")
             junk.append(int(u))
@@ -106,7 +112,7 @@ for case in range(n_cases):
     assert e <= 2e-4, (case, dialect, order, cmvn, "stream vs generic", e, "utterance", int(uid[int(diff.argmax())]))
     # the oracle on a sample: every utterance with junk, the longest, the shortest, a few at random
     pick = set(junk) | {int(np.argmax(lens)), int(np.argmin(lens))} | {int(u) for u in rng.choice(n_utt, 6, replace=False)}
-    pick = [u for u in pick if lens[u] <= 400000][:40]
+    pick = [u for u in sorted(pick) if lens[u] <= 400000][:40]
     for u in pick:
         s = x[offs[u]: offs[u + 1]].cpu().numpy()
         with np.errstate(all='ignore'):
