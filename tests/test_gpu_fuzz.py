@@ -18,3 +18,13 @@ def test_fuzz(script, seed, cases, monkeypatch, capsys):
     monkeypatch.setattr(sys, "argv", [script, str(seed), str(cases)])
     runpy.run_path(os.path.join(ROOT, "tools", script), run_name="__main__")
     assert "OK" in capsys.readouterr().out
+
+
+def test_fuzz_walk_kernel_under_load(monkeypatch, capsys):
+    """Half of a machine-filling batch's utterances hold a silent stretch (a tenth of those a NaN sample too): the scan kernel flags and
+    the WALK instance walks again thousands of chunks per launch — the claim-by-ballot loop under load, not a handful of chunks."""
+    monkeypatch.setenv("FUZZ_JUNK_FRAC", "0.5")
+    monkeypatch.setenv("FUZZ_DIALECTS", "sidekit,sidekit,inrepo")
+    monkeypatch.setattr(sys, "argv", ["fuzz_mfcc_batch.py", "105", "6"])
+    runpy.run_path(os.path.join(ROOT, "tools", "fuzz_mfcc_batch.py"), run_name="__main__")
+    assert "OK" in capsys.readouterr().out
