@@ -78,7 +78,7 @@ def cpu_baseline_mfcc(n_utt, n_samp, fs, budget_s=15.0):
     return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d utterances x %d samples, oracle.ref_cpu.mfcc_pipeline (numpy float64 restatement of the "
                       "sidekit-dialect MFCC + delta + delta-delta path), 1 thread, %.1f s" % (utts, n_samp, dt),
-            "host_cores": os.cpu_count()}
+            "host_cores": os.cpu_count(), "blas_threads": 1 if threadpool_limits is not None else None}
 
 
 def cpu_baseline_mfcc_loop(n_samp, fs, budget_s=6.0):
@@ -224,7 +224,143 @@ def kernel_source_sha256(names=("mfcc_stream_kernel.hpp", "mfcc_stream.hip", "cp
     return h.hexdigest()
 
 
-# ---------------------------------------------------------------------------------------------- box state (`env` in the bench line)
+# ---------------------------------------------------------------------------------------------- the line the driver parses
+LINE_LIMIT = 4096            # the LAST stdout line stays under this; everything else goes to the detail file (round 5's 22.8 KB line did not parse)
+LIMITER_MFCC = "valu-issue at the power-capped clock (VALU busy 78 %, traffic = 1.01 x algorithmic: profiles/mfcc_valu_lds_pmc.json); frac stays priced on HBM"
+
+
+def _sig(x, n=6):
+    """floats to n significant digits (bytes of the line); non-finite floats become null: the line is strict JSON"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (n, x))
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    return x
+
+
+def clean_json(o, n=None):
+    """a JSON-safe copy: numpy scalars to Python's, NaN / inf to null (json.dumps(allow_nan=False) passes), floats rounded if n is given"""
+    if isinstance(o, dict):
+        return {str(k): clean_json(v, n) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [clean_json(v, n) for v in o]
+    if isinstance(o, np.ndarray):
+        return clean_json(o.tolist(), n)
+    if isinstance(o, (float, np.floating)):
+        return _sig(o, n if n else 17)
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.bool_,)):
+        return bool(o)
+    return o
+
+
+def _pick(d, *keys):
+    return {k: _sig(d[k]) for k in keys if isinstance(d, dict) and k in d}
+
+
+def _stage_summary(s):
+    """one small object per stage: value / unit / kernel_ms / frac (+ the stage's own few scalars); the full stage is in the detail file"""
+    if not isinstance(s, dict):
+        return None
+    rf = s.get("roofline") or s.get("front_roofline") or {}
+    out = _pick(s, "value", "unit")
+    ms = rf.get("kernel_ms", s.get("kernel_ms"))
+    if ms is not None:
+        out["kernel_ms"] = _sig(ms, 5)
+    if "frac" in rf:
+        out["frac"] = _sig(rf["frac"], 4)
+        out["bound"] = rf.get("bound")
+    if "mfma_busy" in rf:
+        out["mfma_busy"] = _sig(rf["mfma_busy"], 4)
+    return out
+
+
+def compact_line(res, detail_path=None):
+    """The ONE line the driver parses (<= LINE_LIMIT bytes, strict JSON): the contract's keys, `roofline`, `cpu_baseline`, `value_normalised`,
+    `build`, and one small summary per other stage.  `res` is the full result (what bench_detail.json holds)."""
+    line = _pick(res, "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {"metric": "MFCC frames/s (fused 39-d pass: framing, pre-emphasis, window, rFFT, mel, log, DCT, delta, delta-delta)", **line}
+    c = res.get("config", {})
+    line["config"] = _pick(c, "utterances_per_gpu", "frames_per_gpu", "d_out", "parallelism", "world_size_observed", "backend")
+    line["config"] = {"workload": str(c.get("workload", ""))[:120], **line["config"]}
+    if "kernel_ms_per_rank" in c:
+        line["config"]["kernel_ms_per_rank"] = [_sig(v, 5) for v in c["kernel_ms_per_rank"]]
+    r = res.get("roofline", {})
+    line["roofline"] = _pick(r, "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch", "bytes_per_frame")
+    line["roofline"]["kernel"] = str(r.get("kernel", ""))[:100]
+    if "limiter" in r:
+        line["roofline"]["limiter"] = r["limiter"]
+    f = res.get("roofline_flop") or {}
+    if "frac" in f:
+        line["roofline"]["valu_fp32_frac"] = _sig(f["frac"], 4)
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind", "host_cores", "blas_threads", "skipped")
+        if "sample" in cb:
+            line["cpu_baseline"]["sample"] = str(cb["sample"])[:150]
+    cp = res.get("cpu_baseline_parallel")
+    if isinstance(cp, dict):
+        line["cpu_baseline_parallel"] = _pick(cp, "value", "unit", "cores", "kind", "host_cores", "usable_cores", "blas_threads_per_worker", "value_16_workers", "error")
+    if "value_normalised" in res:
+        line["value_normalised"] = _pick(res["value_normalised"], "value", "ms_per_step")
+    env = res.get("env") or {}
+    su = env.get("sustained_mfcc") or {}
+    if su:
+        line["env"] = {"sclk_mhz": _sig((su.get("sclk_mhz") or {}).get("mean"), 4), "power_w": _sig((su.get("power_w") or {}).get("mean"), 4)}
+    if isinstance(res.get("build"), dict):
+        line["build"] = _pick(res["build"], "build_mode", "lib_bytes")
+    # ---- the other stages: a summary each (never part of `value`)
+    for k in ("mfcc_ref26_cmvn", "mfcc_librosa", "mfcc_host_fed", "gmm", "gmm_bf16x3", "gmm_bf16x3_proven_band", "gmm_auto", "cosine", "cosine_bf16x3",
+              "cosine_bf16_cascade", "cosine_auto", "gmm_em", "dvector_dnn", "dvector_pipeline", "dtw", "plp"):
+        if k in res:
+            line[k] = _stage_summary(res[k])
+    if "gmm" in res:   # the one collective of the path: what the N-rank runs are checked on
+        line["gmm"].update(_pick(res["gmm"], "gathered_rows", "record_bytes", "ms_per_step"))
+    if "mfcc_host_fed" in res:
+        line["mfcc_host_fed"].update(_pick(res["mfcc_host_fed"], "h2d_gbs", "frac_of_pcie_bound", "value_i16", "frac_of_pcie_bound_i16"))
+    for k in ("gmm_auto", "cosine_auto"):
+        if k in res:
+            line[k].update(_pick(res[k], "worst_ratio_to_best_fixed", "mismatches_vs_fp32"))
+    if "mfcc_inrepo" in res:
+        line["mfcc_inrepo"] = {t: _stage_summary(v) for t, v in res["mfcc_inrepo"].items() if t in ("16k", "8k")}
+    c3 = res.get("gmm_cfg3_shape")
+    if isinstance(c3, dict):
+        line["gmm_cfg3_shape"] = {t: _pick(c3[t], "value", "kernel_ms") for t in ("f32", "bf16x3") if t in c3}
+        if "bf16x3_full_share" in c3:
+            line["gmm_cfg3_shape"]["full_share"] = _pick(c3["bf16x3_full_share"], "value", "measured_s", "utterances_per_gpu", "argmax_mismatches_vs_fp32_sample")
+    line["detail"] = detail_path
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:   # never lose the contract's keys to the extras: drop summaries from the back until it fits
+        for k in [k for k in list(line)[::-1] if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                                             "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline",
+                                                             "value_normalised", "build", "detail")]:
+            del line[k]
+            text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    return text
+
+
+def write_detail(res, path):
+    """the full result (every stage's dict, env windows, close-call tables, prose) as strict JSON; returns the path written (or None)"""
+    for p in (path, os.path.join("/tmp", "bench_detail.json")):
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(p)), exist_ok=True)
+            with open(p, "w") as f:
+                json.dump(clean_json(res), f, allow_nan=False)
+            return p
+        except OSError:
+            continue
+    return None
+
+
+# ---------------------------------------------------------------------------------------------- box state (`env` in the detail file)
 CLOSE_GMM_OFFSETS = (1.0, 0.1, 0.01)   # speaker-mean offsets (x std) of the close-call rows; 0.3 = the headline rows
 CLOSE_COS_NOISE = (3.0, 4.0, 10.0)       # embedding noise of the close-call rows; 0.7 = the headline rows
 NOMINAL_SCLK_MHZ = 2000       # value_normalised: the headline at this engine clock (what the boxes of the pool grant on the power cap: 1.85 - 2.05 GHz)
@@ -234,13 +370,14 @@ SYSFS_FILES = {"sclk_hz": "freq1_input", "mclk_hz": "freq2_input", "power_uw": "
 
 def env_sampler_main():
     """Child process of bench.py (started BEFORE the parent touches the GPU; this process never does): reads the card's hwmon files
-    in sysfs as fast as they answer and, when told to quit, prints every sample as JSON.  stdin lines: `card <pci bus address>` picks
+    in sysfs every ~5 ms and, when told to quit, prints every sample as JSON.  stdin lines: `card <pci bus address>` picks
     the card (until then nothing is read), `quit` ends."""
     import glob
     import select
-    files, samples, card = {}, [], None
+    files, samples, card, stride, tick = {}, [], None, 1, 0
     while True:
-        r, _, _ = select.select([sys.stdin], [], [], 0.0 if files else 0.05)
+        # ~5 ms between reads: a tight loop would hold a core and query the SMU continuously while the headline is measured
+        r, _, _ = select.select([sys.stdin], [], [], 0.005 if files else 0.05)
         if r:
             line = sys.stdin.readline()
             if not line or line.strip() == "quit":
@@ -261,7 +398,11 @@ def env_sampler_main():
                         row[k] = int(fh.read().strip())
                 except (OSError, ValueError):
                     pass
-            samples.append(row)
+            tick += 1
+            if tick % stride == 0:
+                samples.append(row)
+            if len(samples) >= 20000:   # bounded: keep every second sample and halve the rate from here on
+                samples, stride = samples[::2], stride * 2
     print(json.dumps({"card": card, "files": sorted(files), "samples": samples}))
 
 
@@ -331,6 +472,9 @@ def main():
     ap.add_argument("--no-gmm4-full", dest="gmm4_full", action="store_false", help="skip the measured full per-GPU share of configs[3] (150000 utterances, bf16x3 path, ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gmm-precision", type=int, default=0, help="0 exact-fp32 MFMA (parity path) | 1 bf16x3 split MFMA")
+    ap.add_argument("--detail", default=os.environ.get("SSP_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json")),
+                    help="where the full result goes (every stage's dict, env windows, close-call tables); the last stdout line is the compact summary")
+    ap.add_argument("--full-line", action="store_true", help="print the FULL result as the last stdout line (tools/ab*.sh, stage_ms.sh read stage internals from it); the driver's run never sets this")
     ap.add_argument("--env-sampler", action="store_true", help="(internal) run as the sysfs sampler child")
     ap.add_argument("--no-env", action="store_true", help="no sysfs sampler child, no calibration kernels")
     ap.add_argument("--sustain-s", type=float, default=1.5, help="seconds the MFCC kernel is repeated behind the timed region while the sampler reads clocks / power (the timed region itself is ~0.2 s: too short for the governor to show its steady state)")
@@ -489,15 +633,15 @@ def main():
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: %d x %.0f s synthetic 16 kHz utterances per GPU, 39-dim MFCC (+delta+delta-delta), "
-                               "win 400 / hop 160 / nfft 512, 24 mel filters" % (n_utt, args.seconds),
+        "config": {"workload": "configs[1]: %d x %.0f s synthetic 16 kHz utterances per GPU, 39-d MFCC (+delta+delta-delta), 400/160/512, 24 mel" % (n_utt, args.seconds),
                    "utterances_per_gpu": n_utt, "frames_per_gpu": n_frames, "d_out": plan.d_out,
                    "kernel_variant": args.variant, "parallelism": "utterance-sharded x%d" % world,
                    "world_size_observed": (dist.get_world_size() if world > 1 else 1),
                    "backend": (dist.get_backend() if world > 1 else None), "kernel_ms_per_rank": per_rank_ms},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # `bound` names the roofline `peak` / `frac` are priced on (the MFCC pass -> HBM); `limiter` names what actually binds
+        "roofline": {"bound": "hbm", "limiter": LIMITER_MFCC if args.variant in (0, 3) else None, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "mfcc_stream512_kernel<13,2,1,3,6,2,3,0,0> + mfcc_stream_scan_kernel + the third kernel <...,1> (no chunk flagged: exits on one load); kernel_ms spans all three" if args.variant in (0, 3) else "mfcc fused pass", "kernel_ms": ms_kernel,
+                     "kernel": "mfcc_stream512_kernel<13,2,1,3,6,2,3,0,0> (+ scan + walk kernels; kernel_ms spans all three)" if args.variant in (0, 3) else "mfcc fused pass", "kernel_ms": ms_kernel,
                      "kernel_ms_stat": "median of the timed launches (hipEvents on the launch stream)",
                      "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_frame": bytes_per_frame},
         "roofline_flop": flop_roof,
@@ -1014,10 +1158,11 @@ def main():
         result["cpu_baseline"] = cpu_baseline_mfcc(20000, n_samp, fs)
         if "mfcc_inrepo" in result:
             result["mfcc_inrepo"]["cpu_baseline_reference_loop"] = cpu_baseline_mfcc_loop(n_samp, fs)
-        try:  # best-effort CPU figure: the same oracle in 16 worker processes (a child process: no fork from this GPU process)
+        try:  # SURVEY.md 8(d)(ii) best-effort CPU figure: the same oracle in min(usable cores, 128) worker processes, 1 BLAS thread each
+            # (a child process: no fork from this GPU process; the tool states host / usable cores, the cgroup quota and the 16-worker figure)
             import subprocess
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_parallel_baseline.py"), "16", "8"],
-                                 capture_output=True, text=True, timeout=120)
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_parallel_baseline.py"), "auto", "8"],
+                                 capture_output=True, text=True, timeout=180)
             result["cpu_baseline_parallel"] = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # pragma: no cover
             result["cpu_baseline_parallel"] = {"error": repr(e)}
@@ -1044,7 +1189,13 @@ def main():
     except Exception:
         result["build"] = None
     if rank == 0:
-        print(json.dumps(result))
+        # the full result goes to the detail file; stdout carries exactly ONE line, the compact one (compact_line)
+        detail = write_detail(result, args.detail)
+        sys.stdout.flush()
+        if args.full_line:
+            print(json.dumps(clean_json(result), allow_nan=False), flush=True)
+        else:
+            print(compact_line(result, os.path.relpath(detail, ROOT) if detail and detail.startswith(ROOT) else detail), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

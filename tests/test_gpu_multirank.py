@@ -27,6 +27,7 @@ def test_bench_two_ranks_hip_scorer():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert line == out.stdout.strip().splitlines()[-1] and len(line.encode()) < 4096      # the compact line IS the last line
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["config"]["world_size_observed"] == 2
     assert r["config"]["backend"] == ("nccl" if two_gpus else "gloo")
@@ -53,7 +54,9 @@ def test_bench_four_ranks_rehearsal_ragged_gather():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    assert len(lines[0].encode()) < 4096
     r = json.loads(lines[0])
+    assert os.path.exists(os.path.join(ROOT, r["detail"])) or os.path.exists(r["detail"])   # the full result behind the line
     assert r["n_gpus"] == n and r["config"]["world_size_observed"] == n and len(r["config"]["kernel_ms_per_rank"]) == n
     assert r["gmm"]["gathered_rows"] == n * 300 and r["gmm"]["record_bytes"] == 12
     assert r["scaling"] == "weak" and r["value"] > 0

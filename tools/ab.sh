@@ -7,7 +7,7 @@ for r in $(seq $rounds); do
   for spec in "$@"; do
     v=${spec%%:*}; kv=0; [[ "$spec" == *:* ]] && kv=${spec##*:}
     if [ "$v" = "-" ]; then unset SSP_LIB_PATH; else export SSP_LIB_PATH=$PWD/tools/scratch/variants/$v.so; fi
-    ms=$(python bench.py --steps ${STEPS:-15} --warmup 3 --stages mfcc --no-cpu-baseline --no-env --variant $kv 2>/dev/null | tail -1 | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.read())['roofline']['kernel_ms'])")
+    ms=$(python bench.py --full-line --steps ${STEPS:-15} --warmup 3 --stages mfcc --no-cpu-baseline --no-env --variant $kv 2>/dev/null | tail -1 | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.read())['roofline']['kernel_ms'])")
     acc[$spec]="${acc[$spec]} $ms"
   done
 done

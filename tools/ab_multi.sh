@@ -9,7 +9,7 @@ mkdir -p "$(dirname $out)"
 for r in $(seq $rounds); do
   for v in "$@"; do
     if [ "$v" = "-" ]; then unset SSP_LIB_PATH; else export SSP_LIB_PATH=$PWD/tools/scratch/variants/$v.so; fi
-    python bench.py --steps ${STEPS:-10} --warmup 2 --stages $stages --no-cpu-baseline --no-env 2>/dev/null | tail -1 | python -c "
+    python bench.py --full-line --steps ${STEPS:-10} --warmup 2 --stages $stages --no-cpu-baseline --no-env 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
 paths = {'mfcc': 'roofline.kernel_ms', 'ref26': 'mfcc_ref26_cmvn.roofline.kernel_ms', 'inrepo16k': 'mfcc_inrepo.16k.roofline.kernel_ms',

@@ -6,7 +6,7 @@ declare -A acc
 for r in $(seq $rounds); do
   for v in "$@"; do
     if [ "$v" = "-" ]; then unset SSP_LIB_PATH; else export SSP_LIB_PATH=$PWD/tools/scratch/variants/$v.so; fi
-    ms=$(python bench.py --steps ${STEPS:-5} --warmup 1 --stages $stage --no-cpu-baseline --no-env ${BENCH_ARGS:-} 2>/dev/null | tail -1 | python -c "
+    ms=$(python bench.py --full-line --steps ${STEPS:-5} --warmup 1 --stages $stage --no-cpu-baseline --no-env ${BENCH_ARGS:-} 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 for k in '$path'.split('.'): d=d[k]

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 [ $# -eq 0 ] && set -- -
 for v in "$@"; do
   if [ "$v" = "-" ]; then unset SSP_LIB_PATH; else export SSP_LIB_PATH=$PWD/tools/scratch/variants/$v.so; fi
-  python bench.py --stages mfcc --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+  python bench.py --full-line --stages mfcc --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json, sys, socket, time
 d = json.loads(sys.stdin.read())
 e = d.get('env', {})

@@ -9,7 +9,7 @@ out=gpurun_out/clock_$stage.txt
 : > $out
 rocm-smi --showclocks --showpower --showmaxpower >> $out 2>&1
 echo "=== idle above; running stage $stage x $steps ===" >> $out
-SSP_BENCH_STAGE_REPS=${3:-3} python3 bench.py --steps $steps --warmup 3 --stages $stage --no-cpu-baseline > gpurun_out/clock_$stage.line 2> gpurun_out/clock_$stage.err &
+SSP_BENCH_STAGE_REPS=${3:-3} python3 bench.py --full-line --steps $steps --warmup 3 --stages $stage --no-cpu-baseline > gpurun_out/clock_$stage.line 2> gpurun_out/clock_$stage.err &
 pid=$!
 while kill -0 $pid 2>/dev/null; do
     date +%s.%N >> $out

@@ -1,4 +1,5 @@
-"""Markdown rows of README.md's results table from a bench line:  python tools/readme_table.py profiles/r03_bench_line.json"""
+"""Markdown rows of README.md's results table from a bench DETAIL file (bench.py --detail; until round 5 the line itself carried everything):
+    python tools/readme_table.py profiles/r06_bench_detail.json"""
 import json, sys
 d = json.load(open(sys.argv[1]))
 g = lambda *k: (lambda v: v)(__import__("functools").reduce(lambda a, b: a[b], k, d))

@@ -3,7 +3,7 @@
 stages=$1; shift
 for v in "$@"; do
   if [ "$v" = "-" ]; then unset SSP_LIB_PATH; else export SSP_LIB_PATH=$PWD/tools/scratch/variants/$v.so; fi
-  python bench.py --steps 5 --warmup 2 --stages $stages --no-cpu-baseline --no-gmm4-full 2>/dev/null | tail -1 | python -c "
+  python bench.py --full-line --steps 5 --warmup 2 --stages $stages --no-cpu-baseline --no-gmm4-full 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read())
 out={'mfcc': round(d['roofline']['kernel_ms'],3)}
 for k in ('mfcc_ref26_cmvn','mfcc_librosa'):

@@ -17,12 +17,13 @@ def have(n):
     return os.path.exists(os.path.join(S, n))
 
 
-if have("bench_line.json"):
-    shutil.copy(os.path.join(S, "bench_line.json"), os.path.join(P, "%s_bench_line.json" % R))
+for n in ("bench_line.json", "bench_detail.json"):   # the compact line the driver parses + the full result behind it
+    if have(n):
+        shutil.copy(os.path.join(S, n), os.path.join(P, "%s_%s" % (R, n)))
 if have("kernel_stats.csv"):
     shutil.copy(os.path.join(S, "kernel_stats.csv"), os.path.join(P, "%s_kernel_stats.csv" % R))
     md = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stats_md.py"), os.path.join(S, "kernel_stats.csv"),
-                         "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline   (MI355X, %s, tree %s)" % (R, git)],
+                         "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-env   (MI355X, %s, tree %s)" % (R, git)],
                         capture_output=True, text=True).stdout
     md = "\n".join(l for l in md.splitlines() if "at::native" not in l) + "\n"
     md += "\n(torch's own elementwise / reduction kernels that build the synthetic inputs are left out of this table; they are in the csv.\n" \
@@ -40,8 +41,8 @@ for st, (kern, key) in DOM.items():
     by = collections.OrderedDict()
     for r in rows:
         by.setdefault(r["Kernel_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    line = json.load(open(os.path.join(S, "stage_%s_bench_line.json" % st)))
-    shutil.copy(os.path.join(S, "stage_%s_bench_line.json" % st), os.path.join(P, "%s_stage_%s_bench_line.json" % (R, st)))
+    line = json.load(open(os.path.join(S, "stage_%s_bench_detail.json" % st)))   # the full result of the stage's run
+    shutil.copy(os.path.join(S, "stage_%s_bench_detail.json" % st), os.path.join(P, "%s_stage_%s_bench_detail.json" % (R, st)))
     shutil.copy(os.path.join(S, "stage_%s_kernel_stats.csv" % st), os.path.join(P, "%s_stage_%s_kernel_stats.csv" % (R, st)))
     out = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 --stages %s --no-cpu-baseline   (MI355X, %s, tree %s)" % (st, R, git), "",
            "Every launch of the stage's dominant kernel(s), in launch order (ms, rocprofv3 kernel trace).  The set-up launch and the warm-up launches come first;",
@@ -102,7 +103,7 @@ def pmc(prefix, kern, also=""):
 
 a = pmc("512", "mfcc_stream512", ", 0>(")  # (the first kernel of the launch: <..., WALK = 0>; the second exits on one load)
 if a:
-    line = json.load(open(os.path.join(S, "stage_mfcc_bench_line.json"))) if have("stage_mfcc_bench_line.json") else None
+    line = json.load(open(os.path.join(S, "stage_mfcc_bench_detail.json"))) if have("stage_mfcc_bench_detail.json") else None
     algo = 23848800000
     g = lambda k: a[k]["mean_per_launch"] if k in a else None
     rd = 2.0 * g("FETCH_SIZE") * 1024 if g("FETCH_SIZE") is not None else None
