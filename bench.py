@@ -467,7 +467,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="0 auto | 1 generic kernel | 2 fused workgroup kernel | 3 fused wave-stream kernel (| 4: the 2048-point one, librosa stage only)")
     ap.add_argument("--ref26-variant", type=int, default=0, help="kernel variant of the 26-d + CMVN stage (as --variant)")
     ap.add_argument("--inrepo-variant", type=int, default=0, help="kernel variant of the in-repo MFCC stage (as --variant)")
-    ap.add_argument("--stages", default="mfcc,ref26,inrepo,librosa,gmm,gmm4,cosine,closecalls,em,dnn,dvec,dtw,plp")
+    ap.add_argument("--stages", default="mfcc,ref26,hostfed,inrepo,librosa,gmm,gmm4,cosine,closecalls,em,dnn,dvec,dtw,plp")
+    ap.add_argument("--hostfed-utts", type=int, default=25000, help="utterances of the host-fed stage's pinned batch (25000 x 3 s = 4.8 GB in, 1.16 GB out)")
     ap.add_argument("--gmm4-utts", type=int, default=12000, help="utterances per GPU of the configs[3]-shaped sample (full: 150000 per GPU; SURVEY.md 8(d) asks for >= 12000)")
     ap.add_argument("--no-gmm4-full", dest="gmm4_full", action="store_false", help="skip the measured full per-GPU share of configs[3] (150000 utterances, bf16x3 path, ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -677,6 +678,69 @@ def main():
                          "kernel": "mfcc_stream512_kernel<..., CM = 1> (the wave that walked an utterance sums its columns and rescales its own rows through L2; batches with multi-chunk utterances take cmvn_kernel instead)",
                          "kernel_ms": r_ms, "algorithmic_bytes_per_launch": r_bytes, "bytes_per_frame": tables.cfg.hop * 4 + rplan.d_out * 4}}
         del rplan, rfeat
+
+    # ------------------------------------------------------------------ the host-fed path: what the reference-shaped callers use (GMM_UBM.py:24-50 reads
+    # wav files into host arrays, :86-93 feeds them to the extractor).  A configs[1]-shaped batch in PINNED host memory through
+    # ssp_mfcc_run(SSP_HOST): sliced copy-in / compute / copy-back pipeline inside the library; wall clock, next to what PCIe gives this box.
+    if "hostfed" in stages and rank == 0:
+        n_h = min(n_utt, args.hostfed_utts)
+        hseg = api.Segments.from_lengths(ctx, np.full(n_h, n_samp, dtype=np.int64))
+        hfseg = plan.frame_segments(hseg)
+        pin_in = torch.empty(n_h * n_samp, dtype=torch.float32, pin_memory=True)
+        pin_in.copy_(flat[:n_h * n_samp])
+        pin_out = torch.empty((hfseg.total, plan.d_out), dtype=torch.float32, pin_memory=True)
+        dev_tmp = torch.empty(n_h * n_samp, dtype=torch.float32, device=device)
+        dev_out = torch.empty((hfseg.total, plan.d_out), dtype=torch.float32, device=device)
+        torch.cuda.synchronize()
+
+        def gbs(dst, src, reps=3):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dst.copy_(src, non_blocking=True)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return src.numel() * src.element_size() / float(np.median(ts)) / 1e9
+        h2d = gbs(dev_tmp, pin_in)
+        plan.run(dev_tmp, hseg, hfseg, out=dev_out, variant=args.variant)        # the device-pointer result of the same batch
+        d2h = gbs(pin_out, dev_out)
+        torch.cuda.synchronize()
+        in_np, out_np = pin_in.numpy(), pin_out.numpy()
+
+        def wall(src):
+            ts = []
+            plan.run(src, hseg, hfseg, out=out_np, variant=args.variant)
+            for _ in range(3):
+                t0 = time.perf_counter()
+                plan.run(src, hseg, hfseg, out=out_np, variant=args.variant)     # (a host-pointer call returns when the features are in `out`)
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts))
+        out_np[:] = 0
+        w32 = wall(in_np)
+        same32 = bool(torch.equal(torch.from_numpy(out_np).to(device), dev_out))
+        in_b, out_b = n_h * n_samp * 4, int(hfseg.total) * plan.d_out * 4
+        bound32 = max(in_b / (h2d * 1e9), out_b / (d2h * 1e9))                   # PCIe is full duplex: the longer direction bounds the pipeline
+        # int16 PCM (utils/tools.py:45-47): half the bytes in; the device widens
+        a16 = (audio[:n_h] * 20000.0).to(torch.int16).view(-1)
+        pin16 = torch.empty(n_h * n_samp, dtype=torch.int16, pin_memory=True)
+        pin16.copy_(a16)
+        plan.run(a16.float(), hseg, hfseg, out=dev_out, variant=args.variant)
+        torch.cuda.synchronize()
+        out_np[:] = 0
+        w16 = wall(pin16.numpy())
+        same16 = bool(torch.equal(torch.from_numpy(out_np).to(device), dev_out))
+        bound16 = max(in_b / 2 / (h2d * 1e9), out_b / (d2h * 1e9))
+        result["mfcc_host_fed"] = {
+            "metric": "MFCC frames/s, host-fed: a configs[1]-shaped batch in pinned host memory through ssp_mfcc_run(SSP_HOST) — sliced pipeline "
+                      "(copy-in | compute | copy-back on three streams), wall clock of the call; never part of `value`",
+            "value": hfseg.total / w32, "unit": "frames/s", "utterances": n_h, "wall_ms": w32 * 1e3, "dtype": "f32",
+            "h2d_gbs": h2d, "d2h_gbs": d2h, "pcie_bound_ms": bound32 * 1e3, "frac_of_pcie_bound": bound32 / w32,
+            "bits_equal_device_path": same32, "slice_mb": int(os.environ.get("SSP_HOST_SLICE_MB", "64")),
+            "value_i16": hfseg.total / w16, "wall_ms_i16": w16 * 1e3, "pcie_bound_ms_i16": bound16 * 1e3, "frac_of_pcie_bound_i16": bound16 / w16,
+            "bits_equal_device_path_i16": same16, "i16_over_f32": w32 / w16,
+            "bound": "PCIe: max(input bytes / measured pinned H2D rate, feature bytes / measured D2H rate) of this box, this run"}
+        del pin_in, pin_out, dev_tmp, dev_out, pin16, a16, in_np, out_np
 
     # ------------------------------------------------------------------ the reference-pinned dialect: in-repo MFCC (utils/processing.py:19-144)
     if "inrepo" in stages:

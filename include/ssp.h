@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SSP_ABI_VERSION 3 /* 3: ssp_cosine_identify2 (precision), ssp_mfcc_plan_set_flags; 2: ssp_comm_* / ssp_allgather / ssp_allreduce_sum; ssp_gmm_score precision = 1 re-scores close calls in fp32 (host sync) */
+#define SSP_ABI_VERSION 4 /* 4: ssp_mfcc_run_i16, sliced host-fed ssp_mfcc_run, ssp_calibrate, precision = auto (ssp_gmm_score 4, ssp_cosine_identify2 3); 3: ssp_cosine_identify2 (precision), ssp_mfcc_plan_set_flags; 2: ssp_comm_* / ssp_allgather / ssp_allreduce_sum; ssp_gmm_score precision = 1 re-scores close calls in fp32 (host sync) */
 
 typedef enum {
     SSP_OK = 0,
@@ -152,6 +152,19 @@ int ssp_mfcc_frame_segments(ssp_mfcc_plan* plan, const ssp_segments* sample_seg,
  * answers SSP_ERR_UNSUPPORTED when the cfg is not covered; auto picks 3, then 2 (n_fft == 512), 4 (n_fft == 2048), then 1. */
 int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
                  const float* samples, float* feats_out, int where, int variant, float* kernel_ms);
+/* Host-fed batches (where = SSP_HOST — what the reference-shaped callers hand over: GMM_UBM.py:24-50 reads the wav files into host
+ * arrays, :86-93 loops over them).  Up to two slices (SSP_HOST_SLICE_MB, default 64 MiB of fp32 samples) a batch is staged whole; larger
+ * ones run as a pipeline over runs of whole utterances: slice i + 1 copies in while slice i computes and slice i - 1's features copy
+ * back (three streams, a ring of three slots kept on the ctx).  Pinned host memory (hipHostMalloc / torch pin_memory) makes the copies
+ * asynchronous and full rate; pageable memory works at the runtime's staging rate.  kernel_ms then spans the pipeline on the ctx stream.
+ *
+ * ssp_mfcc_run_i16: the same pass on int16 PCM — what utils.tools.read (utils/tools.py:45-47, scipy.io.wavfile) returns and the
+ * reference's extractors receive (GMM_UBM.py:86-93, d_vector.py:80-98).  Samples are taken at their integer value (no 1/32768: sidekit's
+ * mfcc computes on the integers as they are); half the bytes cross PCIe and a widening kernel on the device feeds the same MFCC
+ * kernels (bit-identical to ssp_mfcc_run on the float32 of the same integers).  where = SSP_DEVICE: int16 device array, widened
+ * slice by slice through the same ring. */
+int ssp_mfcc_run_i16(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
+                     const int16_t* samples, float* feats_out, int where, int variant, float* kernel_ms);
 
 /* ---- stand-alone framing and cepstrum steps of the in-repo dialect (kept for API parity; ssp_mfcc_run fuses them) ---- */
 /* utils.processing.enframe (utils/processing.py:19-38): frame i = x[i*step : i*step+frame_size], zero padded tail, times

@@ -52,12 +52,11 @@ def extract_feature(x, y, is_train=False, feature_type='MFCC', fs=16000, delta_o
             train_data[lab] = np.vstack((train_data[lab], f)) if lab in train_data else f
         return train_data, feature, y
     plan = _feature_plan(feature_type, int(fs), int(delta_order))
-    sig = [np.asarray(s, dtype=np.float32).reshape(-1) for s in x]
-    seg = api.Segments.from_lengths(plan.ctx, [s.shape[0] for s in sig])
+    flat, lens = api.flatten_signals(x)   # (int16 PCM — what load_data reads, GMM_UBM.py:24-50 — goes to the device as int16)
+    seg = api.Segments.from_lengths(plan.ctx, lens)
     fseg = plan.frame_segments(seg)
-    flat = np.concatenate(sig) if sig else np.zeros(0, dtype=np.float32)
     feats = np.asarray(plan.run(flat, seg, fseg), dtype=np.float64)
-    feature = [feats[fseg.offsets[i]:fseg.offsets[i + 1]] for i in range(len(sig))]
+    feature = [feats[fseg.offsets[i]:fseg.offsets[i + 1]] for i in range(len(lens))]
     if not is_train:
         return feature, y
     train_data = {}

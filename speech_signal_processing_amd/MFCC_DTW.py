@@ -37,12 +37,12 @@ def _MFCC(raw_signal):
 
 def MFCC_lib_batch(signals, n_mfcc=13):
     """MFCC_lib over a list of signals in one kernel launch."""
-    sig = [np.ascontiguousarray(np.asarray(x).astype("float32").reshape(-1)) for x in signals]
+    flat, lens = api.flatten_signals(signals)   # (int16 wav data stays int16 up to the device; the float32 of MFCC_DTW.py:29 is taken there)
     plan = _librosa_plan(int(n_mfcc))
-    seg = api.Segments.from_lengths(plan.ctx, [x.shape[0] for x in sig])
+    seg = api.Segments.from_lengths(plan.ctx, lens)
     fseg = plan.frame_segments(seg)
-    feats = np.asarray(plan.run(np.concatenate(sig) if sig else np.zeros(0, np.float32), seg, fseg))
-    return [feats[fseg.offsets[i]:fseg.offsets[i + 1]].flatten() for i in range(len(sig))]
+    feats = np.asarray(plan.run(flat, seg, fseg))
+    return [feats[fseg.offsets[i]:fseg.offsets[i + 1]].flatten() for i in range(len(lens))]
 
 
 def _extract_all(signals, mfcc_extract):

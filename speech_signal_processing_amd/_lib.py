@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("SSP_LIB_PATH") or os.path.join(HERE, "libsspgpu.so") 
 
 SSP_OK, SSP_ERR_INVALID, SSP_ERR_UNSUPPORTED, SSP_ERR_HIP, SSP_ERR_NOMEM, SSP_ERR_NODEVICE = 0, -1, -2, -3, -4, -5
 HOST, DEVICE = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "ssp_mfcc_out_dim": (C.c_int, [C.POINTER(ssp_mfcc_cfg), C.POINTER(C.c_int32)]),
     "ssp_mfcc_frame_segments": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "ssp_mfcc_run": (C.c_int, [_P, _P, _P, _F32P, _F32P, C.c_int, C.c_int, _MSP]),
+    "ssp_mfcc_run_i16": (C.c_int, [_P, _P, _P, _F32P, _F32P, C.c_int, C.c_int, _MSP]),
     "ssp_enframe": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, C.c_int32, _F32P, _F32P, C.c_int, _MSP]),
     "ssp_cepstrum": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, C.c_int32, _F32P, C.c_int32, C.c_int32, C.c_int32,
                                C.c_float, _F32P, C.c_int, _MSP]),
@@ -105,12 +106,15 @@ def load():
     # makes the dynamic loader resolve libsspgpu.so's NEEDED libamdhip64.so.7 (same SONAME) to torch's copy.
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    # the ABI first: an older or variant library (SSP_LIB_PATH) gets the rebuild message, not a bare AttributeError on a newer symbol
+    lib.ssp_abi_version.restype = C.c_int
+    lib.ssp_abi_version.argtypes = []
+    if lib.ssp_abi_version() != ABI_VERSION:
+        raise ImportError("libsspgpu.so ABI version %d != %d (rebuild: python -m speech_signal_processing_amd.build)" % (lib.ssp_abi_version(), ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.ssp_abi_version() != ABI_VERSION:
-        raise ImportError("libsspgpu.so ABI version %d != %d (rebuild: python -m speech_signal_processing_amd.build)" % (lib.ssp_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -35,6 +35,20 @@ def _as_f32(x, name):
     return a, a.ctypes.data, _lib.HOST
 
 
+def _as_samples(x, name):
+    """-> (array kept alive, raw address, where, is_int16): int16 PCM (what utils.tools.read / scipy.io.wavfile return) stays int16 —
+    half the bytes cross PCIe and the device widens (ssp_mfcc_run_i16); everything else goes as float32"""
+    if _is_torch(x):
+        import torch
+        if x.is_cuda and x.dtype == torch.int16:
+            x = x.contiguous()
+            return x, x.data_ptr(), _lib.DEVICE, True
+    elif isinstance(x, np.ndarray) and x.dtype == np.int16:
+        a = np.ascontiguousarray(x)
+        return a, a.ctypes.data, _lib.HOST, True
+    return _as_f32(x, name) + (False,)
+
+
 class Context:
     """One HIP device + one stream (ssp_ctx).  stream=None: the library owns a stream; an int is a borrowed
     hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; 0 = the HIP default stream)."""
@@ -248,11 +262,12 @@ class MfccPlan:
 
     def run(self, samples, sample_seg: Segments, frame_seg: Optional[Segments] = None, out=None, variant: int = 0,
             timing: bool = False):
-        """samples: float32[total samples] (numpy -> host path, torch cuda -> device path).
-        Returns feats (total_frames, d_out) [and kernel milliseconds when timing=True]."""
+        """samples: float32[total samples] or int16 PCM (numpy -> host path, torch cuda -> device path).  Large host batches run as a
+        copy / compute / copy-back pipeline inside the library (include/ssp.h, ssp_mfcc_run); pinned arrays (`pinned_empty`) get the
+        full PCIe rate.  Returns feats (total_frames, d_out) [and kernel milliseconds when timing=True]."""
         if frame_seg is None:
             frame_seg = self.frame_segments(sample_seg)
-        keep, ptr, where = _as_f32(samples, "samples")
+        keep, ptr, where, is_i16 = _as_samples(samples, "samples")
         if keep.ndim != 1 and not (keep.ndim == 2 and keep.shape[0] * keep.shape[1] == sample_seg.total):
             raise ValueError("samples must be a flat array of all utterances' samples")
         if int(np.prod(keep.shape)) < sample_seg.total:
@@ -264,8 +279,8 @@ class MfccPlan:
             raise ValueError("out must be a contiguous float32 array of the same kind as samples")
         ms = C.c_float(0.0)
         with self.ctx._ordered(where):
-            _lib.check(self._lib.ssp_mfcc_run(self._h, sample_seg._h, frame_seg._h, ptr, optr, where, int(variant),
-                                               C.byref(ms) if timing else None))
+            fn = self._lib.ssp_mfcc_run_i16 if is_i16 else self._lib.ssp_mfcc_run
+            _lib.check(fn(self._h, sample_seg._h, frame_seg._h, ptr, optr, where, int(variant), C.byref(ms) if timing else None))
         return (out, ms.value) if timing else out
 
     def close(self):
@@ -278,6 +293,25 @@ class MfccPlan:
             self.close()
         except Exception:
             pass
+
+
+def flatten_signals(signals):
+    """a list of 1-D utterances -> (one flat array, their lengths).  When every utterance is int16 PCM (utils.tools.read /
+    scipy.io.wavfile, utils/tools.py:45-47) the flat array stays int16: no widening pass on the host, half the bytes over PCIe, the
+    device widens (ssp_mfcc_run_i16).  Anything else is converted to float32 as before."""
+    sig = [np.asarray(s).reshape(-1) for s in signals]
+    if sig and all(s.dtype == np.int16 for s in sig):
+        return (sig[0] if len(sig) == 1 else np.concatenate(sig)), [s.shape[0] for s in sig]
+    sig = [np.asarray(s, dtype=np.float32) for s in sig]
+    return (np.concatenate(sig) if sig else np.zeros(0, dtype=np.float32)), [s.shape[0] for s in sig]
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """a numpy array over page-locked host memory (torch's pinned allocator = hipHostMalloc): host-fed calls copy from / to such arrays
+    asynchronously and at the full PCIe rate; the array keeps its tensor alive"""
+    import torch
+    t = torch.empty(tuple(np.atleast_1d(shape)), dtype=getattr(torch, np.dtype(dtype).name), pin_memory=True)
+    return t.numpy()   # (the array's base keeps the pinned storage alive)
 
 
 def enframe(ctx: Context, samples, frame_size: int, step: int, window):

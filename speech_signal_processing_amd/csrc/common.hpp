@@ -142,6 +142,7 @@ struct ssp_ctx {
     // cosine scorer's scratch, kept between calls (the reference calls it in a loop): packed centroid images, the lists of close calls, counts
     ssp::DevBuf cos_img16, cos_img, cos_list1, cos_list2, cos_count, cos_inc;
     mutable ssp::StagePool stage;  // staging buffers of SSP_HOST calls
+    ssp::HostPipe* pipe = nullptr;  // slots / streams of the sliced host-fed MFCC path (staging.hpp; made on first use)
 };
 
 struct ssp_segments {

@@ -192,6 +192,12 @@ int ssp_ctx_destroy(ssp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     ssp::sync_quietly(ctx->stream);
     (void)ssp_comm_destroy(ctx);
+    if (ctx->pipe) {
+        ssp::sync_quietly(ctx->pipe->h2d);
+        ssp::sync_quietly(ctx->pipe->d2h);
+        delete ctx->pipe;
+        ctx->pipe = nullptr;
+    }
     for (hipEvent_t& ev : ctx->order_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);

@@ -128,6 +128,8 @@ struct ssp_mfcc_plan {
     size_t cache_lds = 0;
     int cache_waves = 4;  // waves per workgroup of the generic kernel
     int32_t cache_n_chunks = 0;
+    std::vector<int32_t> cache_chunk_first;  // [n_utt + 1] first chunk of every utterance (chunks are laid out in utterance order): a
+                                             // range of utterances is a range of chunks (the sliced host-fed path launches such ranges)
     ssp::DevBuf chunks;
     ssp::MfccArgs args{};
     // fused n_fft == 512 kernel

@@ -677,7 +677,10 @@ __global__ __launch_bounds__(64 * FAST_WAVES, SSP_FAST_OCC) void mfcc_fused512_k
 
 // ------------------------------------------------------------------------------------------------ host side
 bool mfcc_fast_supported(const ssp_mfcc_cfg& c) {
-    return c.n_fft == 512 && c.hop >= 2 && c.hop <= 256 && (c.hop & 1) == 0 && c.n_filt <= 64 && c.n_ceps <= 64 &&
+    // floor_mode 2 (max(eps, .), numpy.maximum) stays with the generic kernel: fast_log / stream_log floor through fmaxf, which turns a NaN
+    // mel sum (a NaN sample in the frame, or behind it in the stream kernel's padded rows) into log(eps) — finite and wrong, invisible
+    // to the scan kernel; numpy.maximum keeps the NaN.  (No shipped 512-point preset uses that floor; librosa's is the 2048-point kernel's.)
+    return c.n_fft == 512 && c.floor_mode != 2 && c.hop >= 2 && c.hop <= 256 && (c.hop & 1) == 0 && c.n_filt <= 64 && c.n_ceps <= 64 &&
            c.frame_mode != 2 && c.top_db < 0.f && (c.delta_order == 0 || c.delta_N <= 4);
 }
 

@@ -214,9 +214,11 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
         if (fseg->n >= 4 * waves) tail_from = fseg->n - waves;  // (measured: halves beat thirds / quarters, one wave-set beats two)
     }
 #endif
+    p->cache_chunk_first.assign((size_t)fseg->n + 1, 0);
     for (int64_t u = 0; u < fseg->n; ++u) {
         const int64_t T = fseg->host[u + 1] - fseg->host[u];
         if (T > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: utterance %lld has too many frames", (long long)u);
+        p->cache_chunk_first[(size_t)u] = (int32_t)std::min<size_t>(chunks.size(), (size_t)INT32_MAX);
         int64_t chu = ch;
         if (u >= tail_from && T >= 64) chu = std::min<int64_t>(ch, ((T + 1) / 2 + 15) / 16 * 16);
         // wave-stream kernel: a cut chunk starts 16 frames early (pad = 12 on top of the 4-frame halo) and then reproduces the uncut
@@ -228,6 +230,7 @@ static int build_work(ssp_mfcc_plan* p, const ssp_segments* sseg, const ssp_segm
             chunks.push_back(MfccChunk{(int32_t)u, (int32_t)t0, (int32_t)std::min<int64_t>(chu, T - t0), t0 > 0 ? pad : 0});
     }
     if (chunks.size() > (size_t)INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: too many chunks");
+    p->cache_chunk_first[(size_t)fseg->n] = (int32_t)chunks.size();
     SSP_TRY(upload(p->chunks, chunks, p->ctx->stream));
     SSP_HIP(hipStreamSynchronize(p->ctx->stream));  // `chunks` (host) dies at return
     p->fast_max_samples = sseg->max_len();
@@ -448,19 +451,41 @@ int ssp_mfcc_frame_segments(ssp_mfcc_plan* plan, const ssp_segments* sample_seg,
     return segments_make(plan->ctx, fo.data(), sample_seg->n, frame_seg_out);
 }
 
-int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
-                 const float* samples, float* feats_out, int where, int variant, float* kernel_ms) {
-    ssp::TraceRange trace_("ssp_mfcc_run");
-    if (!plan || !sample_seg || !frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: null handle");
-    SSP_TRY(use_ctx(plan->ctx));
-    if (sample_seg->n != frame_seg->n) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: sample/frame segment counts differ");
-    if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: where");
-    if (variant < 0 || variant > 4) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: variant");
-    const int64_t total_frames = frame_seg->total();
-    const int64_t n_samp_total = sample_seg->host.back();
-    if (kernel_ms) *kernel_ms = 0.f;
-    if (total_frames == 0) return SSP_OK;
-    if (!samples || !feats_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: null data pointer");
+// ---- the run: checks + work table (run_prepare), launches over a range of utterances (run_launch), and the three ways data gets there
+}  // extern "C"
+
+namespace ssp {
+
+// int16 PCM (what utils/tools.py:45-47 / scipy.io.wavfile hand the reference's extractors) -> the float32 the kernels read: the value
+// itself, no scaling (sidekit's mfcc takes the integers as they are).  8 samples per thread: one 16-byte read, two 16-byte writes.
+__global__ __launch_bounds__(256) void widen_i16_kernel(const int16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n && ((reinterpret_cast<uintptr_t>(in + i) & 15) == 0)) {
+        const int4 v = *reinterpret_cast<const int4*>(in + i);
+        const int w[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[2 * k] = (float)(int16_t)(w[k] & 0xffff);
+            f[2 * k + 1] = (float)(int16_t)(w[k] >> 16);
+        }
+        *reinterpret_cast<float4*>(out + i) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(out + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+        for (int64_t k = i; k < n && k < i + 8; ++k) out[k] = (float)in[k];
+    }
+}
+
+static int launch_widen_i16(const int16_t* in, float* out, int64_t n, hipStream_t s) {
+    if (n <= 0) return SSP_OK;
+    const int64_t blocks = (n + 2047) / 2048;
+    if (blocks > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: too many int16 samples for one widening launch");
+    hipLaunchKernelGGL(widen_i16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
+}
+
+static int run_prepare(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg, int variant) {
     if (plan->checked_sseg != sample_seg->serial || plan->checked_fseg != frame_seg->serial) {
         // frame segments must follow the plan's framing rule (checked once per segment pair: segments are immutable, and the loop
         // is 0.2 ms of host time at 100k utterances)
@@ -505,21 +530,24 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
         SSP_TRY(brc);
         plan->cache_request = variant;
     }
-    v = plan->cache_variant;
+    return SSP_OK;
+}
 
-    hipStream_t s = plan->ctx->stream;
-    Staged sin, sout;
-    int rc;
-    const size_t out_bytes = (size_t)(frame_seg->host.back()) * plan->d_out * sizeof(float);
-    const float* d_samples = (const float*)sin.in(plan->ctx, samples, (size_t)n_samp_total * sizeof(float), where, &rc);
-    SSP_TRY(rc);
-    float* d_out = (float*)sout.out(plan->ctx, feats_out, out_bytes, where, &rc);
-    SSP_TRY(rc);
-
+// the cached work table's launches for utterances [u0, u1) (the whole batch: 0, n).  `d_samples` / `d_out` are addressed with the
+// batch's ABSOLUTE offsets (sample_off[u], frame_off[u] . d_out): a caller that holds only a slice passes pointers biased by the
+// slice's first offsets — the kernels never touch an address outside [u0, u1)'s samples and rows.
+static int run_launch(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg, const float* d_samples, float* d_out,
+                      int64_t u0, int64_t u1, hipStream_t s) {
+    const int v = plan->cache_variant;
+    const bool all = u0 == 0 && u1 == frame_seg->n;
+    const int c0 = plan->cache_chunk_first[(size_t)u0], n_chunks = plan->cache_chunk_first[(size_t)u1] - c0;
+    if (n_chunks <= 0) return SSP_OK;
+    const int64_t total_frames = frame_seg->total();
     MfccArgs a = plan->args;
     if (plan->cache_split_cmvn) a.cmvn = 0;  // utterances longer than one workgroup's chunk: normalised by the CMVN kernel below
     a.lm_out = nullptr;
     if (plan->cache_split_topdb && (v == 1 || v == 4)) {  // two-pass top_db: log-mel rows to a scratch, clamp + DCT in a second kernel
+        if (!all) SSP_FAIL(SSP_ERR_UNSUPPORTED, "mfcc: the two-pass top_db path runs on whole batches");
         SSP_TRY(plan->lm_scratch.reserve((size_t)total_frames * plan->cfg.n_filt * sizeof(float)));
         a.lm_out = plan->lm_scratch.as<float>();
         SSP_TRY(plan->umax_scratch.reserve((size_t)frame_seg->n * sizeof(float)));
@@ -531,26 +559,210 @@ int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_
     a.sample_off = sample_seg->dev.as<int64_t>();
     a.frame_off = frame_seg->dev.as<int64_t>();
     a.out = d_out;
-    a.chunks = plan->chunks.as<MfccChunk>();
-    Timer tm;
-    SSP_TRY(tm.start(kernel_ms != nullptr, s));
+    a.chunks = plan->chunks.as<MfccChunk>() + c0;
     if (v == 4)
-        SSP_TRY(launch_mfcc_s2k(a, plan, plan->cache_n_chunks, s));
+        SSP_TRY(launch_mfcc_s2k(a, plan, n_chunks, s));
     else if (v == 3)
-        SSP_TRY(launch_mfcc_stream(a, plan, plan->cache_n_chunks, s));
+        SSP_TRY(launch_mfcc_stream(a, plan, n_chunks, s));
     else if (v == 2)
-        SSP_TRY(launch_mfcc_fast(a, plan, plan->cache_n_chunks, plan->cache_chunk_frames, s));
+        SSP_TRY(launch_mfcc_fast(a, plan, n_chunks, plan->cache_chunk_frames, s));
     else
-        SSP_TRY(launch_mfcc_generic(a, plan->cache_n_chunks, plan->cache_lds, plan->cache_waves, plan->ctx->num_cu, s));
+        SSP_TRY(launch_mfcc_generic(a, n_chunks, plan->cache_lds, plan->cache_waves, plan->ctx->num_cu, s));
     if (a.lm_out && !(v == 4 && plan->cache_s2k_fused))
-        SSP_TRY(launch_topdb_dct(a.lm_out, frame_seg->dev.as<int64_t>(), frame_seg->n, a.chunks, plan->cache_n_chunks, a.utt_max,
+        SSP_TRY(launch_topdb_dct(a.lm_out, frame_seg->dev.as<int64_t>(), frame_seg->n, a.chunks, n_chunks, a.utt_max,
                                  plan->cfg.n_filt, plan->cfg.n_ceps, plan->dct.as<float>(),
                                  plan->cfg.top_db >= 0.f ? plan->cfg.top_db : INFINITY /* no clamp: max - inf */, d_out, s));
-    if (plan->cache_split_cmvn) SSP_TRY(launch_cmvn(d_out, d_out, frame_seg->dev.as<int64_t>(), frame_seg->n, plan->d_out, frame_seg->max_len(), s));
+    if (plan->cache_split_cmvn)  // (offsets stay absolute: the table pointer moves to utterance u0, the data pointer does not)
+        SSP_TRY(launch_cmvn(d_out, d_out, frame_seg->dev.as<int64_t>() + u0, u1 - u0, plan->d_out, frame_seg->max_len(), s));
+    return SSP_OK;
+}
+
+// Large host-fed batches (and int16 input from either side): the batch goes through the ctx's ring of slice-sized slots — slice i + 1
+// copies in while slice i computes and slice i - 1's features copy back (HostPipe, staging.hpp).  Slices are runs of whole utterances of
+// about `slice_bytes` of fp32 samples (an utterance longer than that is a slice of its own).  host_in / host_out: where the operand
+// lives (int16 device input with device output only widens through the ring; nothing is copied).
+static int run_sliced(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg, const void* samples, int stype,
+                      float* feats_out, bool host, size_t slice_bytes, float* kernel_ms) {
+    ssp_ctx* ctx = plan->ctx;
+    hipStream_t cs = ctx->stream;
+    if (!ctx->pipe) {
+        ctx->pipe = new (std::nothrow) HostPipe;
+        if (!ctx->pipe) SSP_FAIL(SSP_ERR_NOMEM, "mfcc: host alloc (pipeline)");
+    }
+    HostPipe& hp = *ctx->pipe;
+    SSP_TRY(hp.init());
+    const int64_t n = frame_seg->n, D = plan->d_out;
+    const std::vector<int64_t>&so = sample_seg->host, &fo = frame_seg->host;
+    // slices: [cut[i], cut[i + 1]) utterances
+    std::vector<int64_t> cut{0};
+    size_t max_in = 0, max_out = 0;
+    {
+        const int64_t per = (int64_t)(slice_bytes / sizeof(float));
+        int64_t u = 0;
+        while (u < n) {
+            int64_t e = u + 1;
+            while (e < n && so[e + 1] - so[u] <= per) ++e;
+            max_in = std::max(max_in, (size_t)(so[e] - so[u]));
+            max_out = std::max(max_out, (size_t)(fo[e] - fo[u]) * (size_t)D);
+            cut.push_back(e);
+            u = e;
+        }
+    }
+    const int n_slices = (int)cut.size() - 1;
+    // (a slot that has to grow may still be read by work of an earlier call on the other streams: everything is drained first)
+    bool grow = false;
+    for (int k = 0; k < HostPipe::RING; ++k)
+        grow = grow || hp.in[k].bytes < max_in * 4 + 4096 || (host && hp.out[k].bytes < max_out * 4 + 16) || (stype == 1 && host && hp.raw[k].bytes < max_in * 2 + 64);
+    if (grow) {
+        SSP_HIP(hipStreamSynchronize(cs));
+        SSP_HIP(hipStreamSynchronize(hp.h2d));
+        SSP_HIP(hipStreamSynchronize(hp.d2h));
+        for (int k = 0; k < HostPipe::RING; ++k) {
+            SSP_TRY(hp.in[k].reserve(max_in * 4 + 4096));
+            if (host) SSP_TRY(hp.out[k].reserve(max_out * 4 + 16));
+            if (stype == 1 && host) SSP_TRY(hp.raw[k].reserve(max_in * 2 + 64));
+        }
+    }
+    if (plan->cache_variant == 3)   // (the launcher's grow-only counter / flag buffer: sized for the whole table now, not by a later, larger slice)
+        SSP_TRY(plan->f_counter.reserve(64 + (size_t)std::max(plan->cache_n_chunks, 1) * sizeof(int32_t)));
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, cs));
+    // the copy streams start behind whatever the ctx stream holds (the slots' last readers of an earlier call included)
+    SSP_HIP(hipEventRecord(hp.computed[0], cs));
+    SSP_HIP(hipStreamWaitEvent(hp.h2d, hp.computed[0], 0));
+    SSP_HIP(hipStreamWaitEvent(hp.d2h, hp.computed[0], 0));
+    const size_t esz = stype == 1 ? sizeof(int16_t) : sizeof(float);
+    // SSP_HOST_TRACE=1 (diagnostic): per slice, when its copy-in, its kernels and its copy-back ended (ms from the call's start, stderr)
+    const bool trace = getenv("SSP_HOST_TRACE") != nullptr;
+    std::vector<hipEvent_t> tev;
+    hipEvent_t t_start = nullptr;
+    if (trace) {
+        tev.resize((size_t)n_slices * 3, nullptr);
+        for (hipEvent_t& e : tev) SSP_HIP(hipEventCreate(&e));
+        SSP_HIP(hipEventCreate(&t_start));
+        SSP_HIP(hipEventRecord(t_start, cs));
+    }
+    for (int i = 0; i < n_slices; ++i) {
+        const int k = i % HostPipe::RING;
+        const int64_t u0 = cut[(size_t)i], u1 = cut[(size_t)i + 1];
+        const int64_t s0 = so[(size_t)u0], ns = so[(size_t)u1] - s0, f0 = fo[(size_t)u0], nf = fo[(size_t)u1] - f0;
+        const char* src = static_cast<const char*>(samples) + (size_t)(s0 - so[0]) * esz;   // (the caller's array starts at the first utterance's first sample)
+        float* d_in = hp.in[k].as<float>();
+        if (host) {
+            // slot k's last reader was slice i - RING.  The HOST waits for it (it runs at most RING slices ahead, and the call is synchronous
+            // anyway): a device-side hipStreamWaitEvent on the copy stream made every copy-in start only when the previous slice's
+            // copy-back had ended (measured per slice with SSP_HOST_TRACE: 1.70 ms a slice instead of 1.20) — the two directions serialised
+            if (i >= HostPipe::RING) SSP_HIP(hipEventSynchronize(hp.computed[k]));
+            SSP_HIP(hipMemcpyAsync(stype == 1 ? hp.raw[k].p : (void*)d_in, src, (size_t)ns * esz, hipMemcpyHostToDevice, hp.h2d));
+            SSP_HIP(hipEventRecord(hp.in_ready[k], hp.h2d));
+            if (trace) SSP_HIP(hipEventRecord(tev[(size_t)i * 3], hp.h2d));
+            SSP_HIP(hipStreamWaitEvent(cs, hp.in_ready[k], 0));
+            if (i >= HostPipe::RING) SSP_HIP(hipEventSynchronize(hp.out_done[k]));              // ... and its features have left the out slot
+            if (stype == 1) SSP_TRY(launch_widen_i16(hp.raw[k].as<int16_t>(), d_in, ns, cs));
+        } else {
+            SSP_TRY(launch_widen_i16(reinterpret_cast<const int16_t*>(src), d_in, ns, cs));   // (in-order on cs: slot k's last reader is long done)
+        }
+        float* d_o = host ? hp.out[k].as<float>() - (size_t)(f0 - fo[0]) * (size_t)D : feats_out;
+        // pointers biased by the slice's first offsets: the kernels address with the batch's absolute offsets (run_launch)
+        SSP_TRY(run_launch(plan, sample_seg, frame_seg, d_in - (size_t)(s0 - so[0]), d_o, u0, u1, cs));
+        if (host) {
+            SSP_HIP(hipEventRecord(hp.computed[k], cs));
+            if (trace) SSP_HIP(hipEventRecord(tev[(size_t)i * 3 + 1], cs));
+            SSP_HIP(hipStreamWaitEvent(hp.d2h, hp.computed[k], 0));
+            SSP_HIP(hipMemcpyAsync(feats_out + (size_t)(f0 - fo[0]) * (size_t)D, hp.out[k].p, (size_t)nf * (size_t)D * sizeof(float), hipMemcpyDeviceToHost, hp.d2h));
+            SSP_HIP(hipEventRecord(hp.out_done[k], hp.d2h));
+            if (trace) SSP_HIP(hipEventRecord(tev[(size_t)i * 3 + 2], hp.d2h));
+        }
+    }
+    if (host) {   // the ctx stream ends behind the last copy-back (one stream to wait on, for this call and for whoever comes next)
+        SSP_HIP(hipStreamWaitEvent(cs, hp.out_done[(n_slices - 1) % HostPipe::RING], 0));
+    }
+    SSP_TRY(tm.stop(cs, kernel_ms));
+    if (host) SSP_HIP(hipStreamSynchronize(cs));
+    if (trace) {
+        if (host) {
+            fprintf(stderr, "[ssp host pipeline] %d slices of <= %zu MiB (fp32); ms from start: copy-in done | kernels done | copy-back done\n", n_slices, slice_bytes >> 20);
+            for (int i = 0; i < n_slices; ++i) {
+                float a = 0.f, b = 0.f, c = 0.f;
+                (void)hipEventElapsedTime(&a, t_start, tev[(size_t)i * 3]);
+                (void)hipEventElapsedTime(&b, t_start, tev[(size_t)i * 3 + 1]);
+                (void)hipEventElapsedTime(&c, t_start, tev[(size_t)i * 3 + 2]);
+                fprintf(stderr, "[ssp host pipeline] slice %3d: %8.3f %8.3f %8.3f\n", i, a, b, c);
+            }
+        }
+        for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(t_start);
+    }
+    return SSP_OK;
+}
+
+static size_t host_slice_bytes() {
+    size_t mb = 64;  // ~1.2 ms of PCIe per slice: long against a launch's host cost, short against the batch (fill + drain = two slices)
+    if (const char* e = getenv("SSP_HOST_SLICE_MB")) mb = (size_t)std::max(1, atoi(e));
+    return mb << 20;
+}
+
+static int mfcc_run_any(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg, const void* samples, int stype,
+                        float* feats_out, int where, int variant, float* kernel_ms) {
+    if (!plan || !sample_seg || !frame_seg) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: null handle");
+    SSP_TRY(use_ctx(plan->ctx));
+    if (sample_seg->n != frame_seg->n) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: sample/frame segment counts differ");
+    if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: where");
+    if (variant < 0 || variant > 4) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: variant");
+    const int64_t total_frames = frame_seg->total();
+    const int64_t n_samp_total = sample_seg->host.back();
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (total_frames == 0) return SSP_OK;
+    if (!samples || !feats_out) SSP_FAIL(SSP_ERR_INVALID, "ssp_mfcc_run: null data pointer");
+    SSP_TRY(run_prepare(plan, sample_seg, frame_seg, variant));
+    const int v = plan->cache_variant;
+    hipStream_t s = plan->ctx->stream;
+    const size_t out_bytes = (size_t)(frame_seg->host.back()) * plan->d_out * sizeof(float);
+    const size_t slice = host_slice_bytes();
+    const bool two_pass = plan->cache_split_topdb && (v == 1 || v == 4);   // (needs the whole batch's rows in one scratch)
+    const bool big = (size_t)n_samp_total * sizeof(float) >= 2 * slice && frame_seg->n >= 2 && sample_seg->host.front() == 0 && frame_seg->host.front() == 0;
+    if (!two_pass && ((where == SSP_HOST && big) || (stype == 1 && where == SSP_DEVICE && sample_seg->host.front() == 0 && frame_seg->host.front() == 0)))
+        return run_sliced(plan, sample_seg, frame_seg, samples, stype, feats_out, where == SSP_HOST, slice, kernel_ms);
+
+    // one piece: the operands as they are (device pointers), or staged whole through the ctx's pool (host pointers)
+    Staged sin, sout, sraw;
+    int rc;
+    const float* d_samples;
+    if (stype == 1) {
+        const int16_t* d_raw = (const int16_t*)sraw.in(plan->ctx, samples, (size_t)n_samp_total * sizeof(int16_t), where, &rc);
+        SSP_TRY(rc);
+        SSP_TRY(sin.get(plan->ctx, (size_t)n_samp_total * sizeof(float) + 16));
+        SSP_TRY(launch_widen_i16(d_raw, (float*)sin.p, n_samp_total, s));
+        d_samples = (const float*)sin.p;
+    } else {
+        d_samples = (const float*)sin.in(plan->ctx, samples, (size_t)n_samp_total * sizeof(float), where, &rc);
+        SSP_TRY(rc);
+    }
+    float* d_out = (float*)sout.out(plan->ctx, feats_out, out_bytes, where, &rc);
+    SSP_TRY(rc);
+    Timer tm;
+    SSP_TRY(tm.start(kernel_ms != nullptr, s));
+    SSP_TRY(run_launch(plan, sample_seg, frame_seg, d_samples, d_out, 0, frame_seg->n, s));
     SSP_TRY(tm.stop(s, kernel_ms));
     SSP_TRY(sout.back(plan->ctx, feats_out, out_bytes, where));
-    if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(s));
+    if (where == SSP_HOST || stype == 1) SSP_HIP(hipStreamSynchronize(s));   // (the staging slots are given back at return)
     return SSP_OK;
+}
+
+}  // namespace ssp
+
+extern "C" {
+
+int ssp_mfcc_run(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
+                 const float* samples, float* feats_out, int where, int variant, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_mfcc_run");
+    return mfcc_run_any(plan, sample_seg, frame_seg, samples, 0, feats_out, where, variant, kernel_ms);
+}
+
+int ssp_mfcc_run_i16(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg,
+                     const int16_t* samples, float* feats_out, int where, int variant, float* kernel_ms) {
+    ssp::TraceRange trace_("ssp_mfcc_run_i16");
+    return mfcc_run_any(plan, sample_seg, frame_seg, samples, 1, feats_out, where, variant, kernel_ms);
 }
 
 }  // extern "C"

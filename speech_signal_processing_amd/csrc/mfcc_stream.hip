@@ -9,7 +9,9 @@ namespace ssp {
 bool mfcc_stream_dense(const ssp_mfcc_plan* p) {
     const ssp_mfcc_cfg& c = p->cfg;
     return mfcc_fast_supported(c) && p->fast_ready && !getenv("SSP_MFCC_NO_STREAM") && p->fast.melv == 0 && p->args.dct_identity &&
-           c.n_filt <= 24 && c.delta_order == 0 && c.win_len <= 416 && c.spec_power == 2 && c.preemph_mode != 0;
+           c.n_filt <= 24 && c.delta_order == 0 && c.win_len > 384 && c.win_len <= 416 && c.spec_power == 2 && c.preemph_mode != 0;
+    // (win_len > 384: this instance takes the legacy window product on the LAST 32-sample row only and has no scan / walk kernels behind
+    //  it; a shorter window has several padded rows through which a NaN sample behind a frame would reach it — those plans take the fused kernel)
 }
 
 bool mfcc_stream_supported(const ssp_mfcc_plan* p) {

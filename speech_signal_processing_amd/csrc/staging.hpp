@@ -40,6 +40,35 @@ struct StagePool {
         return fit;
     }
 };
+// Pipeline of large SSP_HOST MFCC batches (mfcc_plan.hip, mfcc_run_host_sliced): the batch goes through RING slots of slice size — slice
+// i + 1 is copied in (own stream) while slice i computes (the ctx stream) and slice i - 1's features are copied back (third stream).
+// The slots, streams and events live on the ctx, are made on first use and kept (grow-only); ssp_ctx_destroy frees them.
+struct HostPipe {
+    static constexpr int RING = 3;
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    DevBuf in[RING], raw[RING], out[RING];          // fp32 samples | int16 samples as copied in (widened into `in`) | features
+    hipEvent_t in_ready[RING] = {}, computed[RING] = {}, out_done[RING] = {};
+    int init() {
+        if (h2d) return SSP_OK;
+        SSP_HIP(hipStreamCreateWithFlags(&h2d, hipStreamNonBlocking));
+        SSP_HIP(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking));
+        for (int i = 0; i < RING; ++i) {
+            SSP_HIP(hipEventCreateWithFlags(&in_ready[i], hipEventDisableTiming));
+            SSP_HIP(hipEventCreateWithFlags(&computed[i], hipEventDisableTiming));
+            SSP_HIP(hipEventCreateWithFlags(&out_done[i], hipEventDisableTiming));
+        }
+        return SSP_OK;
+    }
+    ~HostPipe() {
+        for (int i = 0; i < RING; ++i) {
+            if (in_ready[i]) (void)hipEventDestroy(in_ready[i]);
+            if (computed[i]) (void)hipEventDestroy(computed[i]);
+            if (out_done[i]) (void)hipEventDestroy(out_done[i]);
+        }
+        if (h2d) (void)hipStreamDestroy(h2d);
+        if (d2h) (void)hipStreamDestroy(d2h);
+    }
+};
 }  // namespace ssp
 #elif SSP_STAGING_PART == 2
 namespace ssp {
@@ -58,8 +87,7 @@ struct Staged {
     int get(const ssp_ctx* ctx, size_t bytes) {
         int rc;
         if (slot >= 0) ctx->stage.give_back(slot);
-        slot = ctx->stage.take(bytes, &rc);
-        if (rc != SSP_OK) return rc;
+        slot = ctx->stage.take(bytes, &rc);  // (a slot that could not grow is no error: the operand gets a buffer of its own for the call)
         if (slot >= 0) {
             pool = ctx;
             p = ctx->stage.slot[slot].p;

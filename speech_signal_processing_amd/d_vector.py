@@ -208,7 +208,7 @@ class Data_gen:
         sr = self.sample_rate
         chunks, labels = [], []
         for xi, yi in zip(x, y):
-            xi = np.asarray(xi, dtype=np.float32).reshape(-1)
+            xi = np.asarray(xi).reshape(-1)   # (int16 PCM stays int16: api.flatten_signals below)
             for j in range(xi.shape[0] // sr):
                 chunks.append(xi[j * sr:(j + 1) * sr])
                 labels.append(yi)
@@ -216,7 +216,7 @@ class Data_gen:
             return [], []
         seg = api.Segments.from_lengths(plan.ctx, [sr] * len(chunks))
         fseg = plan.frame_segments(seg)
-        feats = plan.run(np.concatenate(chunks), seg, fseg)
+        feats = plan.run(api.flatten_signals(chunks)[0], seg, fseg)
         if feature_type == 'PLP':
             feats = api.plp_post(plan.ctx, feats, fseg, sr / 2.0)
         feats = np.asarray(feats, dtype=np.float64)

@@ -24,18 +24,17 @@ def _plp_plan(fs, nwin, shift, prefac):
 def mfcc(input_sig, fs=16000, nwin=0.025, shift=0.01, nceps=13, prefac=0.97):
     """sidekit mfcc at the reference's call sites (GMM_UBM.py:89, d_vector.py:91): [cepstra (T, nceps), None, None, None]."""
     plan = _mfcc_plan(int(fs), float(nwin), float(shift), int(nceps), float(prefac))
-    x = np.asarray(input_sig, dtype=np.float32).reshape(-1)
-    seg = api.Segments.from_lengths(plan.ctx, [x.shape[0]])
+    x, lens = api.flatten_signals([input_sig])
+    seg = api.Segments.from_lengths(plan.ctx, lens)
     return [np.asarray(plan.run(x, seg), dtype=np.float64), None, None, None]
 
 
 def plp_batch(signals, fs=16000, nwin=0.025, shift=0.01, plp_order=13, prefac=0.97, rasta=True):
     """PLP cepstra of a list of utterances in two launches: -> (feats (sum T_i, plp_order) float32 array, frame Segments)."""
     plan = _plp_plan(int(fs), float(nwin), float(shift), float(prefac))
-    sig = [np.asarray(s, dtype=np.float32).reshape(-1) for s in signals]
-    seg = api.Segments.from_lengths(plan.ctx, [s.shape[0] for s in sig])
+    flat, lens = api.flatten_signals(signals)
+    seg = api.Segments.from_lengths(plan.ctx, lens)
     fseg = plan.frame_segments(seg)
-    flat = np.concatenate(sig) if sig else np.zeros(0, dtype=np.float32)
     logspec = plan.run(flat, seg, fseg)
     return api.plp_post(plan.ctx, logspec, fseg, fs / 2.0, plp_order, rasta), fseg
 

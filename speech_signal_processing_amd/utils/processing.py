@@ -77,11 +77,11 @@ def _mfcc_any_size(x, fs, L, step):
 def MFCC(raw_signal, fs=8000, frameSize=512, step=256):
     """utils/processing.py:110-144 — (frames, 13) float64 MFCC matrix of one utterance, computed on the GPU (the fused
     kernel for power-of-two frame sizes, a DFT-matrix product on the matrix cores for any other size)."""
-    x = np.ascontiguousarray(np.asarray(raw_signal).reshape(-1), dtype=np.float32)
     L = int(frameSize)
     if L < 64 or L > 2048 or (L & (L - 1)):  # (the fused plans cover power-of-two frames up to 2048, ssp_mfcc_plan_create)
-        return _mfcc_any_size(x, int(fs), L, int(step))
+        return _mfcc_any_size(np.ascontiguousarray(np.asarray(raw_signal).reshape(-1), dtype=np.float32), int(fs), L, int(step))
     plan = _plan(int(fs), int(frameSize), int(step), 13, False)
+    x, _ = api.flatten_signals([raw_signal])   # (int16 PCM — utils/tools.py:45-47 — is widened on the device)
     seg = api.Segments.from_lengths(plan.ctx, [x.shape[0]])
     feats = plan.run(x, seg)
     return np.asarray(feats, dtype=np.float64)
@@ -94,8 +94,8 @@ def MFCC_batch(signals, fs=8000, frameSize=512, step=256):
     if L < 64 or L > 2048 or (L & (L - 1)):  # (the fused plans cover power-of-two frames up to 2048, ssp_mfcc_plan_create)
         return [_mfcc_any_size(s, int(fs), L, int(step)) for s in sig]
     plan = _plan(int(fs), int(frameSize), int(step), 13, False)
-    seg = api.Segments.from_lengths(plan.ctx, [s.shape[0] for s in sig])
+    flat, lens = api.flatten_signals(signals)   # (int16 PCM goes to the device as it is)
+    seg = api.Segments.from_lengths(plan.ctx, lens)
     fseg = plan.frame_segments(seg)
-    flat = np.concatenate(sig) if sig else np.zeros(0, dtype=np.float32)
     feats = np.asarray(plan.run(flat, seg, fseg), dtype=np.float64)
     return [feats[fseg.offsets[i]:fseg.offsets[i + 1]] for i in range(len(sig))]

@@ -2184,3 +2184,93 @@ def test_scaling_instances_at_every_width(order, equal):
     for u in (0, 1, n_utt // 2, n_utt - 1):
         ref = O.mfcc_pipeline(x[offs[u]: offs[u + 1]].cpu().numpy(), cfg, w, fb, dct)
         assert_feat_close(auto[int(fo[u]): int(fo[u + 1])].cpu().numpy(), ref, what="scaled %d-d, utterance %d" % (13 * (order + 1), u))
+
+
+# ----------------------------------------------------------------------------------------- int16 PCM input and the sliced host-fed path
+def test_int16_pcm_matches_reference_golden_and_the_float_path(golden, ssp):
+    """utils.tools.read (utils/tools.py:45-47) hands the extractors int16 PCM; ssp_mfcc_run_i16 takes it as it is (half the PCIe bytes)
+    and widens on the device.  The reference's own output on its int16 signal is the bar (tests/golden/mfcc_inrepo.npz, made by
+    utils.processing.MFCC on `x_int16`), and the float32 path on the same integers must give the same BITS — host and device pointers."""
+    import torch
+    pkg, api = ssp
+    from speech_signal_processing_amd.utils import processing as P
+    g = golden("mfcc_inrepo")
+    x = g["x_int16"]
+    assert x.dtype == np.int16
+    for fs, L, st in GEOMS:
+        got = P.MFCC(x, fs=fs, frameSize=L, step=st)                       # int16 in: the i16 entry point
+        assert_feat_close(got, g[f"mfcc_int16_{fs}_{L}_{st}"], what=f"int16 {fs}/{L}/{st}")
+        assert np.array_equal(got, P.MFCC(x.astype(np.float32), fs=fs, frameSize=L, step=st))
+    # batches, every kernel variant, host and device pointers, ragged lengths (odd lengths: the widening kernel's unaligned tails)
+    rng = np.random.default_rng(5)
+    sigs = [(3000 * rng.standard_normal(n)).astype(np.int16) for n in (4001, 16000, 777, 48000, 1023, 9999)]
+    flat16 = np.concatenate(sigs)
+    for tables in (pkg.preset_sidekit(delta_order=2), pkg.preset_sidekit(delta_order=1, cmvn=1), pkg.preset_inrepo(16000, 512, 256), pkg.preset_librosa(8000, 13)):
+        if tables.cfg.n_fft == 2048:    # (reflect padding needs utterances longer than n_fft / 2)
+            sigs = [s for s in sigs if len(s) > 1024]
+            flat16 = np.concatenate(sigs)
+        ctx = api.default_context()
+        plan = api.MfccPlan(ctx, tables)
+        seg = api.Segments.from_lengths(ctx, [len(s) for s in sigs])
+        fseg = plan.frame_segments(seg)
+        ref = plan.run(flat16.astype(np.float32), seg, fseg)
+        assert np.array_equal(plan.run(flat16, seg, fseg), ref, equal_nan=True)
+        tctx = api.default_context(torch_stream=True)
+        tplan = api.MfccPlan(tctx, tables)
+        tseg = api.Segments.from_lengths(tctx, [len(s) for s in sigs])
+        dev = tplan.run(torch.from_numpy(flat16).cuda(), tseg, tplan.frame_segments(tseg))
+        assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), ref, equal_nan=True)
+
+
+@pytest.mark.parametrize("dialect", ["sidekit39", "ref26_cmvn", "inrepo", "sidekit_long"])
+def test_sliced_host_pipeline_equals_the_device_path(ssp, dialect, monkeypatch):
+    """Host-fed batches above two slices run as a copy / compute / copy-back pipeline over runs of whole utterances (ssp_mfcc_run,
+    SSP_HOST): with 1-MiB slices a 40-MiB ragged batch takes ~40 slices through the three-slot ring.  Bits must equal the one-launch
+    device-pointer path of a reproducible plan (an utterance's bits do not depend on the batch), from pageable and from pinned memory,
+    for float32 and for int16 input; an utterance longer than a slice is a slice of its own."""
+    import torch
+    pkg, api = ssp
+    monkeypatch.setenv("SSP_HOST_SLICE_MB", "1")
+    tables = {"sidekit39": lambda: pkg.preset_sidekit(delta_order=2), "ref26_cmvn": lambda: pkg.preset_sidekit(delta_order=1, cmvn=1),
+              "inrepo": lambda: pkg.preset_inrepo(16000, 512, 256), "sidekit_long": lambda: pkg.preset_sidekit(delta_order=2)}[dialect]()
+    rng = np.random.default_rng(11)
+    if dialect == "sidekit_long":
+        lens = [600000, 48000, 1000000, 16000, 300, 48000] * 3           # 1e6 samples = 4 MB > the 1-MiB slice
+    else:
+        lens = [int(v) for v in rng.integers(300, 70000, 300)]
+    sigs16 = [(2000 * rng.standard_normal(n)).astype(np.int16) for n in lens]
+    flat16 = np.concatenate(sigs16)
+    flat = flat16.astype(np.float32)
+    assert flat.nbytes > 2 * (1 << 20)
+    tctx = api.default_context(torch_stream=True)
+    tplan = api.MfccPlan(tctx, tables).set_reproducible()
+    tseg = api.Segments.from_lengths(tctx, lens)
+    ref = tplan.run(torch.from_numpy(flat).cuda(), tseg, tplan.frame_segments(tseg)).cpu().numpy()
+    ctx = api.default_context()
+    plan = api.MfccPlan(ctx, tables).set_reproducible()
+    seg = api.Segments.from_lengths(ctx, lens)
+    fseg = plan.frame_segments(seg)
+    for variant in (0, 1, 2, 3) if dialect != "inrepo" else (0, 3):
+        if variant == 0:
+            want = ref
+        else:
+            want = tplan.run(torch.from_numpy(flat).cuda(), tseg, tplan.frame_segments(tseg), variant=variant).cpu().numpy()
+        got = plan.run(flat, seg, fseg, variant=variant)                              # pageable float32
+        assert np.array_equal(got, want, equal_nan=True), (dialect, variant, "pageable f32")
+        got16 = plan.run(flat16, seg, fseg, variant=variant)                          # pageable int16
+        assert np.array_equal(got16, want, equal_nan=True), (dialect, variant, "pageable i16")
+    pin = api.pinned_empty(flat.shape, np.float32)
+    pin[:] = flat
+    out = api.pinned_empty((fseg.total, plan.d_out), np.float32)
+    out[:] = -7.0
+    got = plan.run(pin, seg, fseg, out=out)
+    assert got is out and np.array_equal(out, ref, equal_nan=True), (dialect, "pinned f32")
+    pin16 = api.pinned_empty(flat16.shape, np.int16)
+    pin16[:] = flat16
+    out[:] = -7.0
+    plan.run(pin16, seg, fseg, out=out)
+    assert np.array_equal(out, ref, equal_nan=True), (dialect, "pinned i16")
+    # twice in a row on one ctx (the ring's events and slots are reused), then a small call through the pool again
+    assert np.array_equal(plan.run(pin, seg, fseg), ref, equal_nan=True)
+    one = plan.run(flat[:lens[0]], api.Segments.from_lengths(ctx, lens[:1]))
+    assert np.array_equal(one, ref[:one.shape[0]], equal_nan=True)

@@ -74,7 +74,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ssp_abi_version() == 3
+    assert lib.ssp_abi_version() == _lib.ABI_VERSION == 4
     assert ctypes.sizeof(_lib.ssp_mfcc_cfg) == 18 * 4
 
 
