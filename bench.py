@@ -881,8 +881,18 @@ def main():
             "argmax_mismatches_vs_fp32_path": int((r0["argmax"] != rp["argmax"]).sum().item()),
             "roofline": {"bound": "mfma", "achieved": flop / (gp_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": flop / (gp_ms * 1e-3) / 1e12 / 2500.0, "traffic": None, "kernel_ms": gp_ms, "algorithmic_flop_per_launch": flop}}
+        # precision "auto" (ssp_gmm_score precision 4): the proven-band guarantee at the cost of the cheaper of the split and the fp32 path —
+        # a pilot on the first 2 % of the utterances prices the re-scoring (timed with the call)
+        ra, ga_ms, ga_elapsed, _ = run_gmm(4)
+        auto_info = scorer.last_auto
+        result["gmm_auto"] = {
+            "metric": "GMM frame-scores/s, precision auto (pilot on 2 % of the utterances, then the proven-band bf16x3 path or the fp32 path)",
+            "value": fscores / ga_elapsed, "unit": "frame-scores/s", "kernel_ms": ga_ms, "dtype": "bf16x3->f32 | f32", **auto_info,
+            "argmax_mismatches_vs_fp32_path": int((r0["argmax"] != ra["argmax"]).sum().item()),
+            "ratio_to_best_fixed": ga_ms / min(g_ms, gp_ms), "fixed_ms": {"fp32": g_ms, "proven_band": gp_ms}}
+        auto_ratios, auto_mism = [ga_ms / min(g_ms, gp_ms)], int((r0["argmax"] != ra["argmax"]).sum().item())
         r = r1
-        del scorer, r, r0, r1, r2, rp
+        del scorer, r, r0, r1, r2, rp, ra
         # ---- the same shape with the speaker models moved closer to the UBM (offset 0.3 std above): what the exact-arg-max guarantee
         # of the split-precision path costs when many utterances are close calls (verdict r4: the rows above are the best case)
         if "closecalls" in stages:
@@ -902,13 +912,27 @@ def main():
                     pt[name] = {"kernel_ms": float(np.mean(ms2)), "utterances_rescored_in_fp32": int(sc.last_rescored),
                                 "fraction_rescored": float(sc.last_rescored) / n_utt, "speedup_vs_fp32": ref["kernel_ms"] / float(np.mean(ms2)),
                                 "argmax_mismatches_vs_fp32_path": int((rr["argmax"] != ref["argmax"]).sum().item())}
+                sc.score(feats, fseg, precision=4)
+                ms2 = []
+                for _ in range(2):
+                    rr = sc.score(feats, fseg, precision=4, timing=True)
+                    ms2.append(rr["kernel_ms"])
+                best = min(pt["fp32_kernel_ms"], pt["proven_band"]["kernel_ms"])
+                pt["auto"] = {"kernel_ms": float(np.mean(ms2)), **sc.last_auto, "ratio_to_best_fixed": float(np.mean(ms2)) / best,
+                              "argmax_mismatches_vs_fp32_path": int((rr["argmax"] != ref["argmax"]).sum().item())}
+                auto_ratios.append(pt["auto"]["ratio_to_best_fixed"])
+                auto_mism += pt["auto"]["argmax_mismatches_vs_fp32_path"]
                 pts.append(pt)
                 del sc, ref, rr
             result["gmm_bf16x3_close_calls"] = {
                 "what": "configs[2] shape, speaker means at `speaker_offset_std` x std from the UBM's (0.3 in the rows above): the share of utterances whose "
                         "top-2 margin falls inside the error band — scored again in fp32 on their candidate models — and what the pass then costs; "
-                        "arg-max equality with the fp32 path is checked on every utterance",
+                        "arg-max equality with the fp32 path is checked on every utterance; `auto` = precision 4 (pilot, then proven band or fp32), "
+                        "`ratio_to_best_fixed` = its time over min(fp32, proven band) at the same point",
                 "points": pts}
+        result["gmm_auto"]["worst_ratio_to_best_fixed"] = float(max(auto_ratios))
+        result["gmm_auto"]["points_checked"] = len(auto_ratios)
+        result["gmm_auto"]["mismatches_vs_fp32"] = auto_mism
 
     # ------------------------------------------------------------------ configs[3] shape: 512-mix UBM + 1251 speaker models, a measured sample
     if "gmm4" in stages:
@@ -1069,6 +1093,19 @@ def main():
                          "kernel": "cosine_bf16x3_kernel<16, 1> (+ <16, 3> and cosine_reg_kernel<32> on the listed rows)", "kernel_ms": cc,
                          "algorithmic_flop_per_launch": flop}}
 
+        # precision "auto" (ssp_cosine_identify2 precision 3): pilot on 2 % of the rows, then the cascade, the bf16x3 sweep or fp32
+        rau = api.cosine_identify(ctx, X, Cn, precision=3)
+        msa = []
+        for _ in range(c_steps):
+            rau = api.cosine_identify(ctx, X, Cn, timing=True, precision=3)
+            msa.append(rau["kernel_ms"])
+        ca = float(np.mean(msa))
+        result["cosine_auto"] = {
+            "metric": "cosine pair-scores/s, precision auto (pilot on 2 % of the rows, then cascade | bf16x3 | fp32), arg-min only", "value": N * S / (ca * 1e-3),
+            "unit": "pair-scores/s", "kernel_ms": ca, "dtype": "bf16 / bf16x3 / f32", **rau["auto"], "argmin_equals_fp32_path": bool((rau["argmin"] == am0).all().item()),
+            "ratio_to_best_fixed": ca / min(c_ms, c16, cc), "fixed_ms": {"fp32": c_ms, "bf16x3": c16, "cascade": cc}}
+        cos_ratios, cos_mism = [ca / min(c_ms, c16, cc)], int((rau["argmin"] != am0).sum().item())
+
         if "closecalls" in stages:
             pts = []
             Zc = torch.randn((N, d), generator=gen, device=device)
@@ -1088,13 +1125,27 @@ def main():
                     if prec == 2:
                         pt[name]["rows_to_bf16x3"] = int(rr["split_rows"])
                         pt[name]["fraction_to_bf16x3"] = float(rr["split_rows"]) / N
+                api.cosine_identify(ctx, Xc, Cn, precision=3)
+                ms2 = []
+                for _ in range(3):
+                    rr = api.cosine_identify(ctx, Xc, Cn, timing=True, precision=3)
+                    ms2.append(rr["kernel_ms"])
+                best = min(pt["fp32_kernel_ms"], pt["bf16x3"]["kernel_ms"], pt["cascade"]["kernel_ms"])
+                pt["auto"] = {"kernel_ms": float(np.mean(ms2)), **rr["auto"], "ratio_to_best_fixed": float(np.mean(ms2)) / best,
+                              "argmin_equals_fp32_path": bool((rr["argmin"] == ref["argmin"]).all().item())}
+                cos_ratios.append(pt["auto"]["ratio_to_best_fixed"])
+                cos_mism += int((rr["argmin"] != ref["argmin"]).sum().item())
                 pts.append(pt)
                 del Xc
             result["cosine_close_calls"] = {
                 "what": "configs[4] shape, embeddings = centroid + `embedding_noise` x N(0, 1) (0.7 in the rows above: no close call at all): rows whose two "
-                        "best cosines lie inside a stage's proven band go to the next stage; arg-min equality with the fp32 path on every row",
+                        "best cosines lie inside a stage's proven band go to the next stage; arg-min equality with the fp32 path on every row; "
+                        "`auto` = precision 3, `ratio_to_best_fixed` = its time over min(fp32, bf16x3, cascade) at the same point",
                 "points": pts}
             del Zc
+        result["cosine_auto"]["worst_ratio_to_best_fixed"] = float(max(cos_ratios))
+        result["cosine_auto"]["points_checked"] = len(cos_ratios)
+        result["cosine_auto"]["mismatches_vs_fp32"] = cos_mism
 
     # ------------------------------------------------------------------ widened stages; reported, not part of `value`
     if "em" in stages:

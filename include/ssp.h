@@ -231,6 +231,14 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
                   float* scores_out, int32_t* argmax_out, int where, int precision, float* kernel_ms);
 /* utterances the last precision = 1 call scored again on the fp32 path (diagnostics) */
 int ssp_gmm_last_rescored(const ssp_gmm* gmm, int32_t* n_out);
+/* precision = 4 (auto; GMM_UBM.py:183-187's arg-max with the fp32 path's result on every utterance, never dearer than the cheaper of the
+ * two ways to get it): precision 1's guarantee scores close calls twice, which costs more than precision 0 once most utterances are
+ * close calls.  A pilot — split-precision pass, band and candidate lists on the first ~2 % of the utterances (>= 256) — prices the
+ * re-scoring (listed frames x candidate models); the call then runs as precision 1 when that predicts less than the fp32 pass, else as
+ * precision 0.  Batches under 1024 utterances and calls that ask for loglik_out run as precision 0.  One extra host wait.
+ * ssp_gmm_last_auto: what the last such call chose (precision_used; -1: none yet) and saw (predicted_cost: of precision 1, in units of
+ * the fp32 pass). */
+int ssp_gmm_last_auto(const ssp_gmm* gmm, int32_t* precision_used, int32_t* pilot_utts, int32_t* pilot_listed, float* predicted_cost);
 
 /* ---- GMM training (EM): the O(frames x K x D) part of one iteration of sklearn GaussianMixture(covariance_type='diag').fit as
  *      the reference trains its speaker models and UBM (GMM_UBM.py:158-170; sklearn mixture/_base.py:_e_step,
@@ -306,6 +314,12 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
  * (these wait for the ctx stream when the counts of a device-pointer call have not been read yet) */
 int ssp_cosine_last_rescored(const ssp_ctx* ctx, int32_t* n_out);
 int ssp_cosine_last_split_rows(const ssp_ctx* ctx, int32_t* n_out);
+/* precision = 3 (auto; d_vector.py:315-319's arg-min with the fp32 path's result on every row, at the cost of the cheapest path): a pilot
+ * runs the bf16 and the bf16x3 sweep over the first ~2 % of the rows (>= 2048) and reads how many each would hand on; from those shares
+ * the call takes the cascade (2), the bf16x3 sweep (1) or — when nearly every row is a close call, or N < 8192, or d > 256, or dist_out
+ * is asked for — the fp32 sweep (0).  One host wait per call (the counts), also with device pointers.  ssp_cosine_last_auto: what the
+ * last such call chose and saw (precision_used -1: no auto call yet). */
+int ssp_cosine_last_auto(const ssp_ctx* ctx, int32_t* precision_used, int32_t* pilot_rows, int32_t* pilot_to_bf16x3, int32_t* pilot_to_fp32);
 
 #ifdef __cplusplus
 }

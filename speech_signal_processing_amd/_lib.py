@@ -85,6 +85,8 @@ SIGNATURES = {
     "ssp_centroids": (C.c_int, [_P, _F32P, _P, C.c_int64, C.c_int32, C.c_int32, _F32P, C.c_int, _MSP]),
     "ssp_cosine_identify": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, C.c_int32, _F32P, _P, _F32P, C.c_int, _MSP]),
     "ssp_cosine_identify2": (C.c_int, [_P, _F32P, C.c_int64, C.c_int32, _F32P, C.c_int32, _F32P, _P, _F32P, C.c_int, C.c_int, _MSP]),
+    "ssp_cosine_last_auto": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ssp_gmm_last_auto": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "ssp_cosine_last_rescored": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "ssp_cosine_last_split_rows": (C.c_int, [_P, C.POINTER(C.c_int32)]),
 }

@@ -465,7 +465,11 @@ class GmmScorer:
         (= GaussianMixture.score), argmax (U,) int32 over speaker models of score - score_ubm.
         precision: 0 exact-fp32 MFMA | 1 bf16x3 split MFMA with the close calls (top-2 margin inside the split-precision error
         BOUND) scored again in fp32, so the arg-max equals precision 0's (``last_rescored`` = how many) | 2 bf16x3 alone | 3 as 1
-        with the calibrated, heuristic band (about 100 times narrower than the bound: far fewer utterances scored twice)."""
+        with the calibrated, heuristic band (about 100 times narrower than the bound: far fewer utterances scored twice) | 4 or
+        "auto": precision 1's guarantee at the cost of the cheaper of 1 and 0 — a pilot on the first ~2 % of the utterances prices the
+        re-scoring; ``last_auto`` says what it chose (include/ssp.h, ssp_gmm_score)."""
+        if precision == "auto":
+            precision = 4
         keep, ptr, where = _as_f32(feats, "feats")
         if keep.ndim != 2 or keep.shape[1] != self.D:
             raise ValueError("feats must be (frames, %d)" % self.D)
@@ -500,6 +504,13 @@ class GmmScorer:
         n = C.c_int32(0)
         _lib.check(self._lib.ssp_gmm_last_rescored(self._h, C.byref(n)))
         return n.value
+
+    @property
+    def last_auto(self) -> dict:
+        """what the last precision = "auto" call chose and what its pilot saw (precision_used -1: no such call yet)"""
+        a, b, c, f = C.c_int32(-1), C.c_int32(0), C.c_int32(0), C.c_float(0.0)
+        _lib.check(self._lib.ssp_gmm_last_auto(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(f)))
+        return {"precision_used": a.value, "pilot_utterances": b.value, "pilot_listed": c.value, "predicted_cost_of_precision_1": f.value}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -674,7 +685,11 @@ def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True
     closer than a proven error bound — the arg-min of the fp32 path on every row, about 3x faster; no distance matrix (dist=False);
     the result then carries "rescored" (rows that went through fp32 again).  precision 2: a bf16 sweep in front (bound 4e-3), its close
     calls to the bf16x3 sweep: same arg-min guarantee, the minimum only within 4e-3 on rows the first sweep decided.
+    precision 3 or "auto": the fp32 path's arg-min at the cost of the cheapest of 2, 1 and 0 — a pilot on the first ~2 % of the rows
+    reads how many each sweep would hand on (one host wait); the result carries "auto" (what it chose and saw).
     ``counts=False`` skips the "rescored" / "split_rows" diagnostics: with CUDA tensors the call then returns without waiting for the GPU."""
+    if precision == "auto":
+        precision = 3
     xk, xp, where = _as_f32(X, "X")
     ck, cp, cwhere = _as_f32(Cn, "C")
     if cwhere != where:
@@ -696,6 +711,10 @@ def cosine_identify(ctx: Context, X, Cn, dist: bool = False, argmin: bool = True
         _lib.check(ctx._lib.ssp_cosine_identify2(ctx._h, xp, N, d, cp, S, p(dm), p(am), p(mv), where, int(precision),
                                                  C.byref(ms) if timing else None))
     res = {}
+    if precision == 3:
+        a, b, c, e = C.c_int32(-1), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _lib.check(ctx._lib.ssp_cosine_last_auto(ctx._h, C.byref(a), C.byref(b), C.byref(c), C.byref(e)))
+        res["auto"] = {"precision_used": a.value, "pilot_rows": b.value, "pilot_to_bf16x3": c.value, "pilot_to_fp32": e.value}
     if precision >= 1 and counts:
         n = C.c_int32(0)
         _lib.check(ctx._lib.ssp_cosine_last_rescored(ctx._h, C.byref(n)))

@@ -138,6 +138,7 @@ struct ssp_ctx {
     hipEvent_t order_ev[2] = {nullptr, nullptr};  // ssp_ctx_wait_stream / ssp_ctx_signal_stream
     mutable int32_t cos_last_rescored = 0;  // rows the last ssp_cosine_identify2(precision >= 1) call scored again in fp32
     mutable int32_t cos_last_split = 0;     // ... rows its precision-2 cascade handed from the bf16 sweep to the bf16x3 sweep
+    mutable int32_t cos_auto_choice = -1, cos_auto_pilot_rows = 0, cos_auto_to_x3 = 0, cos_auto_to_f32 = 0;  // ssp_cosine_identify2(precision = 3): the pilot's verdict
     mutable bool cos_counts_pending = false;  // the two counts still sit in cos_count on the device (a device-pointer call does not wait for them)
     // cosine scorer's scratch, kept between calls (the reference calls it in a loop): packed centroid images, the lists of close calls, counts
     ssp::DevBuf cos_img16, cos_img, cos_list1, cos_list2, cos_count, cos_inc;

@@ -900,15 +900,33 @@ int ssp_cosine_last_split_rows(const ssp_ctx* ctx, int32_t* n_out) {
     return SSP_OK;
 }
 
+static constexpr int64_t COS_AUTO_MIN_ROWS = 8192;   // precision 3: below this a call is launch bound either way
+
+int ssp_cosine_last_auto(const ssp_ctx* ctx, int32_t* precision_used, int32_t* pilot_rows, int32_t* pilot_to_bf16x3, int32_t* pilot_to_fp32) {
+    if (!ctx) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_last_auto: null");
+    if (precision_used) *precision_used = ctx->cos_auto_choice;
+    if (pilot_rows) *pilot_rows = ctx->cos_auto_pilot_rows;
+    if (pilot_to_bf16x3) *pilot_to_bf16x3 = ctx->cos_auto_to_x3;
+    if (pilot_to_fp32) *pilot_to_fp32 = ctx->cos_auto_to_f32;
+    return SSP_OK;
+}
+
 int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, const float* C, int32_t S, float* dist_out,
                          int32_t* argmin_out, float* min_out, int where, int precision, float* kernel_ms) {
     ssp::TraceRange trace_("ssp_cosine_identify");
     SSP_TRY(use_ctx(ctx));
     if (N < 0 || d < 1 || S < 1) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: bad shape N=%lld d=%d S=%d", (long long)N, d, S);
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: where");
-    if (precision < 0 || precision > 2)
-        SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: precision must be 0 (fp32 MFMA), 1 (bf16x3 MFMA + fp32 re-scoring of close calls) or 2 (bf16 sweep, "
-                                  "then bf16x3, then fp32 on the respective close calls)");
+    if (precision < 0 || precision > 3)
+        SSP_FAIL(SSP_ERR_INVALID, "ssp_cosine_identify: precision must be 0 (fp32 MFMA), 1 (bf16x3 MFMA + fp32 re-scoring of close calls), 2 (bf16 sweep, "
+                                  "then bf16x3, then fp32 on the respective close calls) or 3 (auto: 2, 1 or 0, whichever a pilot on the first rows predicts to be fastest)");
+    const bool want_auto = precision == 3;
+    ctx->cos_auto_choice = -1;
+    ctx->cos_auto_pilot_rows = ctx->cos_auto_to_x3 = ctx->cos_auto_to_f32 = 0;
+    if (want_auto && (dist_out || d > 256 || N < COS_AUTO_MIN_ROWS)) {   // the distance matrix / wide embeddings: fp32 only; small calls: launch bound, fp32
+        precision = 0;
+        ctx->cos_auto_choice = 0;
+    }
     if (precision >= 1 && (dist_out || d > 256))
         SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_cosine_identify: precision 1 / 2 give the arg-min / minimum only (dist_out must be NULL) for d <= 256");
     if (kernel_ms) *kernel_ms = 0.f;
@@ -931,6 +949,7 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
     // (scratch lives on the ctx, grow-only: no allocation and no implicit synchronisation per call; calls on one ctx are stream-ordered)
     DevBuf &inc = ctx->cos_inc, &img = ctx->cos_img;
     Timer tm;
+    bool timer_on = false;
     ctx->cos_last_rescored = ctx->cos_last_split = 0;
     ctx->cos_counts_pending = false;
     if (precision >= 1) {
@@ -943,47 +962,80 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
         SSP_TRY(img16.reserve((size_t)n_tiles * nk * 2048));
         SSP_TRY(img.reserve((size_t)n_tiles * nq * 256 * sizeof(float)));
         SSP_TRY(list2.reserve((size_t)N * sizeof(int32_t)));
-        if (precision == 2) SSP_TRY(list1.reserve((size_t)N * sizeof(int32_t)));
+        if (precision >= 2) SSP_TRY(list1.reserve((size_t)N * sizeof(int32_t)));
         SSP_TRY(count.reserve(4 * sizeof(int32_t)));  // [0] rows for the bf16 x 3 sweep (precision 2), [1] rows for fp32, [2] centroid flag
         int32_t* cnt = count.as<int32_t>();
-        Cos16Args c3{dX, img16.as<__bf16>(), dA, dM, list2.as<int32_t>(), cnt + 1, cnt + 2, N, d, S, n_tiles, 2.0f * cos_band(d), nullptr, nullptr};
-        CosRegArgs ra{dX, img.as<float>(), nullptr, 0, nullptr, dA, dM, N, d, S, n_tiles};
-        ra.rows = list2.as<int32_t>();
-        ra.n_dev = cnt + 1;
         SSP_TRY(tm.start(kernel_ms != nullptr, s));
+        timer_on = true;
         SSP_HIP(hipMemsetAsync(count.p, 0, 4 * sizeof(int32_t), s));
         hipLaunchKernelGGL(cos_pack16_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nk, img16.as<__bf16>(), cnt + 2);
         hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>(), 1);
         SSP_HIP(hipGetLastError());
-        if (precision == 2) {
-            Cos16Args c1 = c3;
-            c1.list = list1.as<int32_t>();
-            c1.count = cnt;
-            c1.band2 = 2.0f * cos_band1(d);
-            SSP_TRY(launch_cos16_nk<1>(nk, c1, s));
-            c3.rows = list1.as<int32_t>();
-            c3.n_dev = cnt;
+        if (want_auto) {
+            // ---- precision 3 (auto): the pilot.  Both sweeps over the first ~2 % of the rows, each listing its close calls: the share the
+            // bf16 sweep would hand to the bf16 x 3 sweep (f1) and the share that one would hand to fp32 (f2).  Predicted cost in units of
+            // the fp32 sweep (bench `cosine_close_calls`: bf16 sweep 0.165, bf16 x 3 sweep 0.30; a listed row costs more than its share
+            // of a dense sweep — rows are gathered through the list, 64 to a wave — by ~1.6 x at the densities measured):
+            //   cascade = 0.165 + 1.6 (0.30 f1 + f2) | bf16 x 3 = 0.30 + 1.6 f2 | fp32 = 1.  The smallest wins.  One host wait.
+            int64_t n_p = std::max<int64_t>(2048, N / 50);
+            if (const char* e = getenv("SSP_COS_AUTO_PILOT")) n_p = std::max<int64_t>(1, atoll(e));
+            n_p = std::min(n_p, N);
+            Cos16Args p3{dX, img16.as<__bf16>(), dA, dM, list2.as<int32_t>(), cnt + 1, cnt + 2, n_p, d, S, n_tiles, 2.0f * cos_band(d), nullptr, nullptr};
+            Cos16Args p1 = p3;
+            p1.list = list1.as<int32_t>();
+            p1.count = cnt;
+            p1.band2 = 2.0f * cos_band1(d);
+            SSP_TRY(launch_cos16_nk<1>(nk, p1, s));
+            SSP_TRY(launch_cos16_nk<3>(nk, p3, s));
+            int32_t h[4] = {0, 0, 0, 0};
+            SSP_HIP(hipMemcpyAsync(h, count.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            SSP_HIP(hipStreamSynchronize(s));
+            const float f1 = (float)h[0] / (float)n_p, f2 = (float)h[1] / (float)n_p;
+            const float casc = 0.165f + 1.6f * (0.30f * f1 + f2), x3 = 0.30f + 1.6f * f2;
+            precision = (casc <= x3 && casc < 0.95f) ? 2 : (x3 < 0.95f ? 1 : 0);
+            // (a non-finite centroid makes the sweeps list every row: f1 = f2 = 1 and the fp32 sweep is chosen)
+            ctx->cos_auto_choice = precision;
+            ctx->cos_auto_pilot_rows = (int32_t)n_p;
+            ctx->cos_auto_to_x3 = h[0];
+            ctx->cos_auto_to_f32 = h[1];
+            SSP_HIP(hipMemsetAsync(count.p, 0, 2 * sizeof(int32_t), s));   // (the centroid flag at [2] stays)
         }
-        SSP_TRY(launch_cos16_nk<3>(nk, c3, s));
-        switch (nq) {
-            case 8: SSP_TRY(launch_cos_reg<8>(ra, s)); break;
-            case 16: SSP_TRY(launch_cos_reg<16>(ra, s)); break;
-            case 24: SSP_TRY(launch_cos_reg<24>(ra, s)); break;
-            default: SSP_TRY(launch_cos_reg<32>(ra, s)); break;
+        if (precision >= 1) {
+            Cos16Args c3{dX, img16.as<__bf16>(), dA, dM, list2.as<int32_t>(), cnt + 1, cnt + 2, N, d, S, n_tiles, 2.0f * cos_band(d), nullptr, nullptr};
+            CosRegArgs ra{dX, img.as<float>(), nullptr, 0, nullptr, dA, dM, N, d, S, n_tiles};
+            ra.rows = list2.as<int32_t>();
+            ra.n_dev = cnt + 1;
+            if (precision == 2) {
+                Cos16Args c1 = c3;
+                c1.list = list1.as<int32_t>();
+                c1.count = cnt;
+                c1.band2 = 2.0f * cos_band1(d);
+                SSP_TRY(launch_cos16_nk<1>(nk, c1, s));
+                c3.rows = list1.as<int32_t>();
+                c3.n_dev = cnt;
+            }
+            SSP_TRY(launch_cos16_nk<3>(nk, c3, s));
+            switch (nq) {
+                case 8: SSP_TRY(launch_cos_reg<8>(ra, s)); break;
+                case 16: SSP_TRY(launch_cos_reg<16>(ra, s)); break;
+                case 24: SSP_TRY(launch_cos_reg<24>(ra, s)); break;
+                default: SSP_TRY(launch_cos_reg<32>(ra, s)); break;
+            }
+            SSP_TRY(tm.stop(s, kernel_ms));
+            SSP_TRY(sa.back(ctx, argmin_out, (size_t)N * sizeof(int32_t), where));
+            SSP_TRY(sm.back(ctx, min_out, (size_t)N * sizeof(float), where));
+            ctx->cos_counts_pending = true;  // (ssp_cosine_last_rescored / _split_rows fetch them)
+            if (where == SSP_HOST) SSP_TRY(cos_fetch_counts(ctx));  // (host outputs: the call waits for its copies anyway)
+            return SSP_OK;
         }
-        SSP_TRY(tm.stop(s, kernel_ms));
-        SSP_TRY(sa.back(ctx, argmin_out, (size_t)N * sizeof(int32_t), where));
-        SSP_TRY(sm.back(ctx, min_out, (size_t)N * sizeof(float), where));
-        ctx->cos_counts_pending = true;  // (ssp_cosine_last_rescored / _split_rows fetch them)
-        if (where == SSP_HOST) SSP_TRY(cos_fetch_counts(ctx));  // (host outputs: the call waits for its copies anyway)
-        return SSP_OK;
+        // (the pilot chose the fp32 sweep: it follows, inside the same timed region)
     }
     if (d <= 256) {  // register-resident embeddings, LDS-DMA streamed centroid tiles
         const int nq = d <= 64 ? 8 : (d <= 128 ? 16 : (d <= 192 ? 24 : 32));
         const int n_tiles = (S + 31) / 32;
         SSP_TRY(img.reserve((size_t)n_tiles * nq * 256 * sizeof(float)));
         CosRegArgs ra{dX, img.as<float>(), nullptr, 0, dD, dA, dM, N, d, S, n_tiles};
-        SSP_TRY(tm.start(kernel_ms != nullptr, s));
+        if (!timer_on) SSP_TRY(tm.start(kernel_ms != nullptr, s));
         hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>(), 1);
         SSP_HIP(hipGetLastError());
         switch (nq) {

@@ -805,6 +805,9 @@ struct ssp_gmm {
     std::vector<int32_t> sub_list_host, sub_pb_host;
     std::vector<int64_t> sub_off_host;
     int32_t last_rescored = 0;
+    // precision = 4 (auto): what the pilot of the last such call saw and chose
+    int32_t auto_choice = -1, auto_pilot_utts = 0, auto_pilot_listed = 0;
+    float auto_predicted = 0.f;  // predicted cost of the proven-band split path, in units of the fp32 path's
 };
 
 using namespace ssp;
@@ -1093,6 +1096,81 @@ static int score_fused(ssp_gmm* gmm, const float* d_feats, const int64_t* h_off,
     return SSP_OK;
 }
 
+// ---- precision = 4 (auto): the proven-band split path only when it is the faster one --------------------------------------------------
+// The exact-arg-max guarantee of precision 1 scores every close call a second time in fp32; when most utterances are close calls that
+// costs more than the fp32 path alone (bench `gmm_bf16x3_close_calls`: 164 ms against 121 with every utterance listed).  The pilot runs
+// the split-precision pass, the band and the candidate selection on the first ~2 % of the utterances and prices the re-scoring from what
+// it lists: work = sum over listed utterances of frames x candidate models (every model when the list overflows), relative to
+// frames x models of the pilot.  Predicted cost of precision 1 in units of the fp32 path = SPLIT + RESCORE x work (SPLIT: the bf16x3
+// sweep, ~0.32 of the fp32 sweep at any shape — same tiles, three MFMAs at 8 x the rate, the epilogue shared; RESCORE: a listed frame's
+// workgroup scores the UNION of its utterances' candidate lists, measured ~2 x the sum on bench shapes, 1.05 x when every model is
+// asked for).  fp32 is chosen when the prediction exceeds AUTO_CUTOVER.  Cost of asking: the pilot (2 % of a split pass) + one host wait.
+static constexpr float AUTO_SPLIT = 0.33f, AUTO_RESCORE_LISTS = 2.0f, AUTO_RESCORE_ALL = 1.05f, AUTO_CUTOVER = 0.92f;
+static constexpr int64_t AUTO_MIN_UTTS = 1024;   // below this a call is launch-latency bound either way: fp32 (fewest kernels, no host wait)
+
+static int gmm_auto_choice(ssp_gmm* gmm, const float* d_feats, const ssp_segments* frame_seg, hipStream_t s, int* choice) {
+    const int64_t n_utt = frame_seg->n;
+    const int M = gmm->n_models;
+    gmm->auto_pilot_utts = gmm->auto_pilot_listed = 0;
+    gmm->auto_predicted = 0.f;
+    *choice = 0;
+    if (gmm->nk16 == 0 || n_utt < AUTO_MIN_UTTS) return SSP_OK;       // no split kernels for this D / tiny batch
+    if (gmm->has_ubm + 1 >= M) {                                         // one speaker model: nothing to confuse, the split path needs no re-scoring
+        *choice = 1;
+        return SSP_OK;
+    }
+    int64_t n_p = std::max<int64_t>(256, n_utt / 50);
+    if (const char* e = getenv("SSP_GMM_AUTO_PILOT")) n_p = std::max<int64_t>(1, atoll(e));
+    n_p = std::min(n_p, n_utt);
+    const int64_t* h_off = frame_seg->host.data();
+    const int64_t* d_off = frame_seg->dev.as<int64_t>();
+    SSP_TRY(gmm->margin.reserve((size_t)n_utt * sizeof(float)));
+    SSP_TRY(gmm->sub_scores.reserve((size_t)n_p * M * sizeof(float)));
+    SSP_TRY(gmm->band.reserve((size_t)n_utt * sizeof(float)));
+    SSP_TRY(gmm->flag_list.reserve((size_t)n_utt * sizeof(int32_t)));
+    SSP_TRY(gmm->flag_count.reserve(sizeof(int32_t)));
+    float* sc = gmm->sub_scores.as<float>();
+    // (second buffer set: the batch's cached piece table stays as it is)
+    SSP_TRY(score_fused(gmm, d_feats, h_off, d_off, n_p, 0, /*bf16=*/true, /*sub=*/true, sc, nullptr, gmm->margin.as<float>(), s));
+    const float eps = 3.01f * 0x1p-18f + 8.0f * (float)gmm->D * 0x1p-23f * 1.01f;
+    hipLaunchKernelGGL(gmm_band_kernel, dim3((unsigned)n_p), dim3(256), 0, s, d_feats, d_off, gmm->D, gmm->bound_tab.as<float>(), eps, sc, M,
+                       gmm->band.as<float>());
+    hipLaunchKernelGGL(gmm_flag_kernel, dim3(1), dim3(256), 0, s, gmm->margin.as<float>(), gmm->band.as<float>(), (int)n_p,
+                       gmm->flag_list.as<int32_t>(), gmm->flag_count.as<int32_t>());
+    SSP_HIP(hipGetLastError());
+    int32_t n_flag = 0;
+    SSP_HIP(hipMemcpyAsync(&n_flag, gmm->flag_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SSP_HIP(hipStreamSynchronize(s));
+    double work = 0.0, work_all = 0.0;
+    if (n_flag > 0) {
+        SSP_TRY(gmm->cand.reserve((size_t)n_flag * GMM_CAND * sizeof(int32_t)));
+        hipLaunchKernelGGL(gmm_candidates_kernel, dim3((unsigned)n_flag), dim3(256), 0, s, gmm->flag_list.as<int32_t>(), sc, gmm->band.as<float>(), M,
+                           gmm->has_ubm, gmm->cand.as<int32_t>());
+        SSP_HIP(hipGetLastError());
+        gmm->sub_list_host.resize((size_t)n_flag);
+        gmm->cand_host.resize((size_t)n_flag * GMM_CAND);
+        SSP_HIP(hipMemcpyAsync(gmm->sub_list_host.data(), gmm->flag_list.p, (size_t)n_flag * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SSP_HIP(hipMemcpyAsync(gmm->cand_host.data(), gmm->cand.p, (size_t)n_flag * GMM_CAND * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SSP_HIP(hipStreamSynchronize(s));
+        for (int32_t i = 0; i < n_flag; ++i) {
+            const int32_t u = gmm->sub_list_host[(size_t)i];
+            const double T = (double)(h_off[(size_t)u + 1] - h_off[(size_t)u]);
+            const int32_t c0 = gmm->cand_host[(size_t)i * GMM_CAND];
+            if (c0 < 0) work_all += T * M;
+            else work += T * (double)c0;
+        }
+    }
+    const double total = (double)std::max<int64_t>(h_off[(size_t)n_p] - h_off[0], 1) * M;
+    const float pred = AUTO_SPLIT + (float)((AUTO_RESCORE_LISTS * work + AUTO_RESCORE_ALL * work_all) / total);
+    gmm->auto_pilot_utts = (int32_t)n_p;
+    gmm->auto_pilot_listed = n_flag;
+    gmm->auto_predicted = pred;
+    float cut = AUTO_CUTOVER;
+    if (const char* e = getenv("SSP_GMM_AUTO_CUTOVER")) cut = (float)atof(e);
+    *choice = pred < cut ? 1 : 0;
+    return SSP_OK;
+}
+
 }  // namespace ssp
 
 extern "C" {
@@ -1104,10 +1182,14 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     ssp_ctx* ctx = gmm->ctx;
     SSP_TRY(use_ctx(ctx));
     if (where != SSP_HOST && where != SSP_DEVICE) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: where");
-    if (precision < 0 || precision > 3)
+    if (precision < 0 || precision > 4)
         SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_score: precision must be 0 (fp32 MFMA), 1 (bf16x3 MFMA + fp32 re-scoring inside the proven error bound), "
-                                  "2 (bf16x3 MFMA alone) or 3 (bf16x3 MFMA + fp32 re-scoring inside the calibrated, heuristic band)");
-    if (precision != 0 && gmm->nk16 == 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_score: bf16x3 path covers D <= 64");
+                                  "2 (bf16x3 MFMA alone), 3 (bf16x3 MFMA + fp32 re-scoring inside the calibrated, heuristic band) or 4 (auto: 1 or 0, "
+                                  "whichever a pilot on the first utterances predicts to be faster)");
+    if (precision != 0 && precision != 4 && gmm->nk16 == 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_score: bf16x3 path covers D <= 64");
+    const bool want_auto = precision == 4;
+    if (want_auto) precision = 0;   // (until the pilot has spoken; score_samples requests — loglik_out — stay on the parity path)
+    gmm->auto_choice = -1;
     if (kernel_ms) *kernel_ms = 0.f;
     const int64_t F = frame_seg->host.back();
     const int64_t n_utt = frame_seg->n;
@@ -1116,17 +1198,24 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     if (n_utt > INT32_MAX) SSP_FAIL(SSP_ERR_UNSUPPORTED, "gmm: too many utterances");
     hipStream_t s = ctx->stream;
     const int M = gmm->n_models;
-    const bool bf16 = precision != 0;
     Staged sin, sll, ssc, sam;
     int rc;
     const float* d_feats = (const float*)sin.in(ctx, feats, (size_t)F * gmm->D * sizeof(float), where, &rc);
     SSP_TRY(rc);
+    Timer tm;
+    bool timer_on = false;
+    if (want_auto && !loglik_out && (scores_out || argmax_out)) {
+        SSP_TRY(tm.start(kernel_ms != nullptr, s));   // (the pilot is part of what the call costs)
+        timer_on = true;
+        SSP_TRY(gmm_auto_choice(gmm, d_feats, frame_seg, s, &precision));
+        gmm->auto_choice = precision;
+    }
+    const bool bf16 = precision != 0;
     const size_t ll_bytes = (size_t)M * (size_t)std::max<int64_t>(F, 1) * sizeof(float);
     float* d_sc = (float*)ssc.out(ctx, scores_out, (size_t)n_utt * M * sizeof(float), where, &rc);
     SSP_TRY(rc);
     int32_t* d_am = (int32_t*)sam.out(ctx, argmax_out, (size_t)n_utt * sizeof(int32_t), where, &rc);
     SSP_TRY(rc);
-    Timer tm;
     if (loglik_out) {
         // the caller wants score_samples: the whole [M x F] matrix in one pass, per-utterance means from it
         float* d_ll = (float*)sll.out(ctx, loglik_out, ll_bytes, where, &rc);
@@ -1151,6 +1240,7 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     } else if (scores_out || argmax_out) {
         // fused path: per-utterance sums leave the scoring kernel as piece partials, [M x F] never reaches HBM
         const bool rescore = (precision == 1 || precision == 3) && gmm->has_ubm + 1 < M;  // (one speaker model: nothing to confuse)
+        if (!rescore) gmm->last_rescored = 0;
         float* d_margin = nullptr;
         float* d_sc_work = d_sc;
         if (rescore) {
@@ -1161,7 +1251,7 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
                 d_sc_work = gmm->sub_scores.as<float>();
             }
         }
-        SSP_TRY(tm.start(kernel_ms != nullptr, s));
+        if (!timer_on) SSP_TRY(tm.start(kernel_ms != nullptr, s));
         SSP_TRY(score_fused(gmm, d_feats, frame_seg->host.data(), frame_seg->dev.as<int64_t>(), n_utt, frame_seg->serial, bf16, false,
                             d_sc_work, d_am, d_margin, s));
         if (rescore) {
@@ -1262,6 +1352,16 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     SSP_TRY(ssc.back(ctx, scores_out, (size_t)n_utt * M * sizeof(float), where));
     SSP_TRY(sam.back(ctx, argmax_out, (size_t)n_utt * sizeof(int32_t), where));
     if (where == SSP_HOST) SSP_HIP(hipStreamSynchronize(s));
+    return SSP_OK;
+}
+
+/* precision = 4: what the last such call's pilot saw and chose */
+int ssp_gmm_last_auto(const ssp_gmm* gmm, int32_t* precision_used, int32_t* pilot_utts, int32_t* pilot_listed, float* predicted_cost) {
+    if (!gmm) SSP_FAIL(SSP_ERR_INVALID, "ssp_gmm_last_auto: null");
+    if (precision_used) *precision_used = gmm->auto_choice;
+    if (pilot_utts) *pilot_utts = gmm->auto_pilot_utts;
+    if (pilot_listed) *pilot_listed = gmm->auto_pilot_listed;
+    if (predicted_cost) *predicted_cost = gmm->auto_predicted;
     return SSP_OK;
 }
 

@@ -2274,3 +2274,78 @@ def test_sliced_host_pipeline_equals_the_device_path(ssp, dialect, monkeypatch):
     assert np.array_equal(plan.run(pin, seg, fseg), ref, equal_nan=True)
     one = plan.run(flat[:lens[0]], api.Segments.from_lengths(ctx, lens[:1]))
     assert np.array_equal(one, ref[:one.shape[0]], equal_nan=True)
+
+
+# ----------------------------------------------------------------------------------------- precision "auto" of the split-precision scorers
+def test_gmm_precision_auto_picks_the_cheaper_path_and_keeps_the_argmax(ssp):
+    """ssp_gmm_score precision 4: the proven-band guarantee must never cost more than the path it replaces.  Well-separated speaker
+    models (0.3 std): few close calls -> the pilot keeps the split path; models on top of the UBM (0.01 std): every utterance is a
+    close call -> fp32.  Arg-max equal to the fp32 path's on every utterance either way; small batches and score_samples requests
+    run as precision 0."""
+    import torch
+    pkg, api = ssp
+    ctx = api.default_context(torch_stream=True)
+    rng = np.random.default_rng(4)
+    K, D, S, U, T = 32, 39, 20, 4000, 60
+    w = rng.dirichlet(5 * np.ones(K))
+    mu = rng.standard_normal((K, D))
+    cov = rng.uniform(0.5, 2.0, (K, D))
+    X = torch.from_numpy(rng.standard_normal((U * T, D)).astype(np.float32)).cuda()
+    seg = api.Segments.from_lengths(ctx, [T] * U)
+    for off, want in ((0.3, 1), (0.01, 0)):
+        mus = np.stack([mu] + [mu + off * np.sqrt(cov) * rng.standard_normal((K, D)) for _ in range(S)])
+        sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
+        assert sc.last_auto["precision_used"] == -1
+        r0 = sc.score(X, seg, precision=0)
+        ra = sc.score(X, seg, precision="auto")
+        info = sc.last_auto
+        assert info["precision_used"] == want, (off, info)
+        assert info["pilot_utterances"] == 256 and 0 <= info["pilot_listed"] <= 256
+        assert (ra["argmax"] == r0["argmax"]).all(), off
+        if want == 0:
+            assert torch.equal(ra["scores"], r0["scores"]) and sc.last_rescored == 0
+        else:
+            assert float((ra["scores"] - r0["scores"]).abs().max()) <= 1e-4 * float(r0["scores"].abs().max())
+        # a small batch: fp32 without a pilot; score_samples: the parity path
+        small = api.Segments.from_lengths(ctx, [T] * 100)
+        rs = sc.score(X[:100 * T], small, precision=4)
+        assert sc.last_auto["precision_used"] == 0 and sc.last_auto["pilot_utterances"] == 0
+        assert torch.equal(rs["scores"], sc.score(X[:100 * T], small, precision=0)["scores"])
+        rl = sc.score(X[:100 * T], small, precision=4, loglik=True)
+        assert rl["loglik"].shape == (S + 1, 100 * T)
+    with pytest.raises(ValueError):
+        sc.score(X, seg, precision=5)
+
+
+def test_cosine_precision_auto(ssp):
+    """ssp_cosine_identify2 precision 3: well-separated embeddings -> the cascade; embeddings drowned in noise -> the bf16x3 sweep alone
+    (the bf16 sweep in front would hand most rows on); duplicated centroids (every row an exact tie) -> fp32.  The fp32 path's arg-min
+    on every row in each case."""
+    import torch
+    pkg, api = ssp
+    ctx = api.default_context(torch_stream=True)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    N, S, d = 60000, 400, 256
+    Cn = torch.randn((S, d), generator=g, device="cuda")
+    lab = torch.randint(0, S, (N,), generator=g, device="cuda")
+    Z = torch.randn((N, d), generator=g, device="cuda")
+    for noise, want in ((0.5, (2,)), (40.0, (1, 0))):
+        X = Cn[lab] + noise * Z
+        r0 = api.cosine_identify(ctx, X, Cn)
+        ra = api.cosine_identify(ctx, X, Cn, precision="auto")
+        assert ra["auto"]["precision_used"] in want, (noise, ra["auto"])
+        assert ra["auto"]["pilot_rows"] == 2048
+        assert torch.equal(ra["argmin"], r0["argmin"]), noise
+    Cd = torch.cat([Cn[:200], Cn[:200]])                       # every centroid twice: exact ties on every row
+    X = Cn[lab % 200] + 0.5 * Z
+    r0 = api.cosine_identify(ctx, X, Cd)
+    ra = api.cosine_identify(ctx, X, Cd, precision=3)
+    assert ra["auto"]["precision_used"] == 0 and ra["auto"]["pilot_to_fp32"] == 2048, ra["auto"]
+    assert torch.equal(ra["argmin"], r0["argmin"]) and torch.equal(ra["min"], r0["min"])
+    # small calls, wide embeddings and distance-matrix requests run as precision 0 without a pilot
+    rs = api.cosine_identify(ctx, X[:100], Cd, precision=3, dist=True)
+    assert rs["auto"]["precision_used"] == 0 and rs["auto"]["pilot_rows"] == 0 and rs["dist"].shape == (100, 400)
+    Xn = X[:9000].cpu().numpy()
+    rh = api.cosine_identify(api.default_context(), Xn, Cd.cpu().numpy(), precision=3)     # host pointers
+    assert (rh["argmin"] == r0["argmin"][:9000].cpu().numpy()).all()

@@ -64,12 +64,12 @@ for case in range(n_cases):
     a0, s0 = r0["argmax"], r0["scores"]
     nz = torch.as_tensor(lens > 0, device=dev)
     listed = {}
-    for prec in (1, 3):
+    for prec in (1, 3, 4):   # (4 = auto: a pilot picks 1 or 0)
         a1 = sc.score(X, seg, precision=prec)["argmax"]
         bad = torch.nonzero((a0 != a1) & nz).flatten()
         assert bad.numel() == 0, (case, "gmm split-precision arg-max differs from fp32's", prec, K, D, S, off_scale, "utterances",
                                   bad[:8].tolist(), "lens", [int(lens[b]) for b in bad[:8].tolist()])
-        listed[prec] = getattr(sc, "last_rescored", None)
+        listed[prec] = getattr(sc, "last_rescored", None) if prec != 4 else "auto->%d" % sc.last_auto["precision_used"]
     pick = [int(u) for u in rng.choice(np.nonzero(lens > 0)[0], 24, replace=False)]
     ref = gmm_scores_f64(w_t, mu_t, cv_t, X, offs, pick)
     got = s0[torch.as_tensor(pick, device=dev)].cpu().numpy().astype(np.float64)
@@ -89,7 +89,7 @@ for case in range(n_cases):
     lab = torch.randint(0, Sc, (N,), device=dev, generator=tg)
     Xc = Cn[lab] + float(10.0 ** rng.uniform(-2, 1)) * torch.randn(N, dd, device=dev, generator=tg)
     c0 = api.cosine_identify(ctx, Xc, Cn)
-    for prec in (1, 2):
+    for prec in (1, 2, 3):   # (3 = auto: a pilot picks 2, 1 or 0)
         c1 = api.cosine_identify(ctx, Xc, Cn, precision=prec)
         bad = torch.nonzero(c0["argmin"] != c1["argmin"]).flatten()
         assert bad.numel() == 0, (case, "cosine split-precision arg-min differs from fp32's", prec, N, Sc, dd, eps, bad[:8].tolist())
