@@ -314,11 +314,13 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
  * (these wait for the ctx stream when the counts of a device-pointer call have not been read yet) */
 int ssp_cosine_last_rescored(const ssp_ctx* ctx, int32_t* n_out);
 int ssp_cosine_last_split_rows(const ssp_ctx* ctx, int32_t* n_out);
-/* precision = 3 (auto; d_vector.py:315-319's arg-min with the fp32 path's result on every row, at the cost of the cheapest path): a pilot
- * runs the bf16 and the bf16x3 sweep over the first ~2 % of the rows (>= 2048) and reads how many each would hand on; from those shares
- * the call takes the cascade (2), the bf16x3 sweep (1) or — when nearly every row is a close call, or N < 8192, or d > 256, or dist_out
- * is asked for — the fp32 sweep (0).  One host wait per call (the counts), also with device pointers.  ssp_cosine_last_auto: what the
- * last such call chose and saw (precision_used -1: no auto call yet). */
+/* precision = 3 (auto; d_vector.py:315-319's arg-min with the fp32 path's result on every row, at the cost of the cheapest path): the
+ * pilot is the first round of the cascade's bf16 sweep (one machine-filling set of waves, at most N / 8 rows): it lists its close calls
+ * as the full sweep would and counts the rows closer than the bf16x3 band beside them; from those two shares the call goes on as the
+ * cascade (2: the sweep continues behind the pilot's rows, nothing is computed twice), or starts over as the bf16x3 sweep (1) or — when
+ * nearly every row is a close call — the fp32 sweep (0).  N < 8192, d > 256 and dist_out requests run as precision 0 without a pilot.
+ * One host wait per call (the counts), also with device pointers.  ssp_cosine_last_auto: what the last such call chose and saw
+ * (precision_used -1: no auto call yet). */
 int ssp_cosine_last_auto(const ssp_ctx* ctx, int32_t* precision_used, int32_t* pilot_rows, int32_t* pilot_to_bf16x3, int32_t* pilot_to_fp32);
 
 #ifdef __cplusplus

@@ -143,6 +143,7 @@ struct ssp_ctx {
     // cosine scorer's scratch, kept between calls (the reference calls it in a loop): packed centroid images, the lists of close calls, counts
     ssp::DevBuf cos_img16, cos_img, cos_list1, cos_list2, cos_count, cos_inc;
     mutable ssp::StagePool stage;  // staging buffers of SSP_HOST calls
+    int32_t* pinned_words = nullptr;  // 64 bytes of pinned host memory for small read-backs (precision-auto pilots)
     ssp::HostPipe* pipe = nullptr;  // slots / streams of the sliced host-fed MFCC path (staging.hpp; made on first use)
 };
 

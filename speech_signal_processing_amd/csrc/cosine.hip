@@ -500,6 +500,11 @@ struct Cos16Args {
     // later stages of a cascade: the embeddings are X[rows[i]], i < *n_dev (device-side count of the previous stage's list)
     const int32_t* rows;
     const int32_t* n_dev;
+    // a sweep over rows [base, base + N) of a larger array (X / argmin / minval point at row `base`): the ids it lists are base + row
+    int32_t list_base;
+    // pilot of precision 3 (auto): also count the rows whose two best cosines are closer than band2b (nullable)
+    int32_t* count2;
+    float band2b;
 };
 
 // SPLIT = 3: hi + lo operands, three products per k-step (error 1.3e-4 at d = 256); SPLIT = 1: the hi parts alone, one product per k-step
@@ -685,13 +690,19 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
     const int64_t go = (a.rows && gc < Nn) ? (int64_t)a.rows[gc] : gc;  // the row this lane's embedding is
     // close calls (and anything that is not a number: a zero-norm embedding, a NaN centroid) are scored again by the next stage; with a
     // single centroid there is nothing to confuse
-    const bool again = mine && (bad || a.cflag[0] != 0 || !(ix > 0.f && ix < INFINITY) || (a.S > 1 && !(b1 - b2 >= a.band2)));
+    const bool must = bad || a.cflag[0] != 0 || !(ix > 0.f && ix < INFINITY);
+    const bool again = mine && (must || (a.S > 1 && !(b1 - b2 >= a.band2)));
     const unsigned long long m = __builtin_amdgcn_ballot_w64(again);
     if (m != 0) {
         int base = 0;
         if (lane == 0) base = atomicAdd(a.count, __popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (again) a.list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)go;
+        if (again) a.list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)go + a.list_base;
+    }
+    if (a.count2) {   // (wave-uniform: a kernel argument)
+        const bool close2 = mine && (must || (a.S > 1 && !(b1 - b2 >= a.band2b)));
+        const unsigned long long m2 = __builtin_amdgcn_ballot_w64(close2);
+        if (m2 != 0 && lane == 0) atomicAdd(a.count2, __popcll(m2));
     }
     if (mine && !again) {
         if (a.argmin) a.argmin[go] = i1;
@@ -971,34 +982,38 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
         hipLaunchKernelGGL(cos_pack16_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nk, img16.as<__bf16>(), cnt + 2);
         hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>(), 1);
         SSP_HIP(hipGetLastError());
+        int64_t done1 = 0;   // rows of the bf16 sweep (stage 1 of the cascade) already swept by the pilot
         if (want_auto) {
-            // ---- precision 3 (auto): the pilot.  Both sweeps over the first ~2 % of the rows, each listing its close calls: the share the
-            // bf16 sweep would hand to the bf16 x 3 sweep (f1) and the share that one would hand to fp32 (f2).  Predicted cost in units of
-            // the fp32 sweep (bench `cosine_close_calls`: bf16 sweep 0.165, bf16 x 3 sweep 0.30; a listed row costs more than its share
-            // of a dense sweep — rows are gathered through the list, 64 to a wave — by ~1.6 x at the densities measured):
-            //   cascade = 0.165 + 1.6 (0.30 f1 + f2) | bf16 x 3 = 0.30 + 1.6 f2 | fp32 = 1.  The smallest wins.  One host wait.
-            int64_t n_p = std::max<int64_t>(2048, N / 50);
+            // ---- precision 3 (auto).  The pilot IS the first round of the cascade's first stage: the bf16 sweep over the first rows (one
+            // machine-filling round of waves, so it costs its share of the full sweep and nothing more), listing its close calls as the
+            // full sweep would and counting beside them the rows closer than the bf16 x 3 band (an estimate of what that sweep would hand
+            // to fp32: a call that close at bf16 accuracy is, with few exceptions, that close at any).  One host wait, then — in units of
+            // the fp32 sweep (bench `cosine_close_calls`: bf16 sweep 0.165, bf16 x 3 sweep 0.30; a listed row costs ~1.8 x its share of
+            // a dense sweep: rows are gathered through the list) —
+            //   cascade = 0.165 + 1.8 (0.30 f1 + f2) | bf16 x 3 = 0.30 + 1.8 f2 | fp32 = 1:  the smallest wins (ties and near-ties to the cascade).
+            // The cascade (the usual winner) continues with the remaining rows of its first stage: nothing the pilot did is thrown away.
+            int64_t n_p = std::min<int64_t>((int64_t)ctx->num_cu * 12 * 32, std::max<int64_t>(2048, N / 8));
             if (const char* e = getenv("SSP_COS_AUTO_PILOT")) n_p = std::max<int64_t>(1, atoll(e));
             n_p = std::min(n_p, N);
-            Cos16Args p3{dX, img16.as<__bf16>(), dA, dM, list2.as<int32_t>(), cnt + 1, cnt + 2, n_p, d, S, n_tiles, 2.0f * cos_band(d), nullptr, nullptr};
-            Cos16Args p1 = p3;
-            p1.list = list1.as<int32_t>();
-            p1.count = cnt;
-            p1.band2 = 2.0f * cos_band1(d);
+            Cos16Args p1{dX, img16.as<__bf16>(), dA, dM, list1.as<int32_t>(), cnt, cnt + 2, n_p, d, S, n_tiles, 2.0f * cos_band1(d), nullptr, nullptr};
+            p1.count2 = cnt + 3;
+            p1.band2b = 2.0f * cos_band(d);
             SSP_TRY(launch_cos16_nk<1>(nk, p1, s));
-            SSP_TRY(launch_cos16_nk<3>(nk, p3, s));
-            int32_t h[4] = {0, 0, 0, 0};
+            if (!ctx->pinned_words) SSP_HIP(hipHostMalloc((void**)&ctx->pinned_words, 64, hipHostMallocDefault));   // (pinned: the 16-byte read-back is a plain DMA)
+            int32_t* h = ctx->pinned_words;
             SSP_HIP(hipMemcpyAsync(h, count.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             SSP_HIP(hipStreamSynchronize(s));
-            const float f1 = (float)h[0] / (float)n_p, f2 = (float)h[1] / (float)n_p;
-            const float casc = 0.165f + 1.6f * (0.30f * f1 + f2), x3 = 0.30f + 1.6f * f2;
-            precision = (casc <= x3 && casc < 0.95f) ? 2 : (x3 < 0.95f ? 1 : 0);
-            // (a non-finite centroid makes the sweeps list every row: f1 = f2 = 1 and the fp32 sweep is chosen)
+            const float f1 = (float)h[0] / (float)n_p, f2 = (float)h[3] / (float)n_p;
+            const float casc = 0.165f + 1.8f * (0.30f * f1 + f2), x3 = 0.30f + 1.8f * f2;
+            // (the cascade keeps the pilot's rows, the other two start over: it is taken unless the prediction says it loses clearly)
+            precision = (casc <= 1.25f * x3 && casc < 0.95f) ? 2 : (x3 < 0.95f ? 1 : 0);
+            // (a non-finite centroid makes the sweep list every row: f1 = f2 = 1 and the fp32 sweep is chosen)
             ctx->cos_auto_choice = precision;
             ctx->cos_auto_pilot_rows = (int32_t)n_p;
             ctx->cos_auto_to_x3 = h[0];
-            ctx->cos_auto_to_f32 = h[1];
-            SSP_HIP(hipMemsetAsync(count.p, 0, 2 * sizeof(int32_t), s));   // (the centroid flag at [2] stays)
+            ctx->cos_auto_to_f32 = h[3];
+            if (precision == 2) done1 = n_p;                                   // the list and its count stand: the sweep goes on behind them
+            else SSP_HIP(hipMemsetAsync(count.p, 0, 2 * sizeof(int32_t), s));   // (the centroid flag at [2] stays)
         }
         if (precision >= 1) {
             Cos16Args c3{dX, img16.as<__bf16>(), dA, dM, list2.as<int32_t>(), cnt + 1, cnt + 2, N, d, S, n_tiles, 2.0f * cos_band(d), nullptr, nullptr};
@@ -1010,7 +1025,14 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
                 c1.list = list1.as<int32_t>();
                 c1.count = cnt;
                 c1.band2 = 2.0f * cos_band1(d);
-                SSP_TRY(launch_cos16_nk<1>(nk, c1, s));
+                if (done1 > 0) {   // (precision 3: rows [0, done1) were the pilot)
+                    c1.X = dX + (size_t)done1 * d;
+                    c1.argmin = dA ? dA + done1 : nullptr;
+                    c1.minval = dM ? dM + done1 : nullptr;
+                    c1.N = N - done1;
+                    c1.list_base = (int32_t)done1;
+                }
+                if (c1.N > 0) SSP_TRY(launch_cos16_nk<1>(nk, c1, s));
                 c3.rows = list1.as<int32_t>();
                 c3.n_dev = cnt;
             }

@@ -198,6 +198,7 @@ int ssp_ctx_destroy(ssp_ctx* ctx) {
         delete ctx->pipe;
         ctx->pipe = nullptr;
     }
+    if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
     for (hipEvent_t& ev : ctx->order_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);

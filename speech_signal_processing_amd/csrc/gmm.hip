@@ -1138,9 +1138,11 @@ static int gmm_auto_choice(ssp_gmm* gmm, const float* d_feats, const ssp_segment
     hipLaunchKernelGGL(gmm_flag_kernel, dim3(1), dim3(256), 0, s, gmm->margin.as<float>(), gmm->band.as<float>(), (int)n_p,
                        gmm->flag_list.as<int32_t>(), gmm->flag_count.as<int32_t>());
     SSP_HIP(hipGetLastError());
-    int32_t n_flag = 0;
-    SSP_HIP(hipMemcpyAsync(&n_flag, gmm->flag_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ssp_ctx* ctx = gmm->ctx;
+    if (!ctx->pinned_words) SSP_HIP(hipHostMalloc((void**)&ctx->pinned_words, 64, hipHostMallocDefault));
+    SSP_HIP(hipMemcpyAsync(ctx->pinned_words, gmm->flag_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SSP_HIP(hipStreamSynchronize(s));
+    const int32_t n_flag = ctx->pinned_words[0];
     double work = 0.0, work_all = 0.0;
     if (n_flag > 0) {
         SSP_TRY(gmm->cand.reserve((size_t)n_flag * GMM_CAND * sizeof(int32_t)));

@@ -2279,7 +2279,7 @@ def test_sliced_host_pipeline_equals_the_device_path(ssp, dialect, monkeypatch):
 # ----------------------------------------------------------------------------------------- precision "auto" of the split-precision scorers
 def test_gmm_precision_auto_picks_the_cheaper_path_and_keeps_the_argmax(ssp):
     """ssp_gmm_score precision 4: the proven-band guarantee must never cost more than the path it replaces.  Well-separated speaker
-    models (0.3 std): few close calls -> the pilot keeps the split path; models on top of the UBM (0.01 std): every utterance is a
+    models (0.3 std): few close calls -> the pilot keeps the split path; models on top of the UBM (1e-4 std): every utterance is a
     close call -> fp32.  Arg-max equal to the fp32 path's on every utterance either way; small batches and score_samples requests
     run as precision 0."""
     import torch
@@ -2292,7 +2292,7 @@ def test_gmm_precision_auto_picks_the_cheaper_path_and_keeps_the_argmax(ssp):
     cov = rng.uniform(0.5, 2.0, (K, D))
     X = torch.from_numpy(rng.standard_normal((U * T, D)).astype(np.float32)).cuda()
     seg = api.Segments.from_lengths(ctx, [T] * U)
-    for off, want in ((0.3, 1), (0.01, 0)):
+    for off, want in ((0.3, 1), (1e-4, 0)):
         mus = np.stack([mu] + [mu + off * np.sqrt(cov) * rng.standard_normal((K, D)) for _ in range(S)])
         sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
         assert sc.last_auto["precision_used"] == -1
@@ -2318,7 +2318,7 @@ def test_gmm_precision_auto_picks_the_cheaper_path_and_keeps_the_argmax(ssp):
 
 
 def test_cosine_precision_auto(ssp):
-    """ssp_cosine_identify2 precision 3: well-separated embeddings -> the cascade; embeddings drowned in noise -> the bf16x3 sweep alone
+    """ssp_cosine_identify2 precision 3: well-separated embeddings -> the cascade; near-duplicate centroid pairs -> the bf16x3 sweep alone
     (the bf16 sweep in front would hand most rows on); duplicated centroids (every row an exact tie) -> fp32.  The fp32 path's arg-min
     on every row in each case."""
     import torch
@@ -2330,18 +2330,22 @@ def test_cosine_precision_auto(ssp):
     Cn = torch.randn((S, d), generator=g, device="cuda")
     lab = torch.randint(0, S, (N,), generator=g, device="cuda")
     Z = torch.randn((N, d), generator=g, device="cuda")
-    for noise, want in ((0.5, (2,)), (40.0, (1, 0))):
-        X = Cn[lab] + noise * Z
-        r0 = api.cosine_identify(ctx, X, Cn)
-        ra = api.cosine_identify(ctx, X, Cn, precision="auto")
+    # near-duplicate centroid pairs (2e-3 apart): the two best cosines of every row are a pair — inside the bf16 sweep's band (8e-3),
+    # mostly outside the bf16x3 sweep's (2.7e-4): the first sweep would hand on nearly every row, so the bf16x3 sweep runs alone
+    Cpairs = torch.cat([Cn[:200], Cn[:200] + 2e-3 * torch.randn((200, d), generator=g, device="cuda")])
+    for Cx, labx, want in ((Cn, lab, (2,)), (Cpairs, lab % 200, (1, 0))):
+        X = Cx[labx] + 0.5 * Z
+        r0 = api.cosine_identify(ctx, X, Cx)
+        ra = api.cosine_identify(ctx, X, Cx, precision="auto")
+        noise = want
         assert ra["auto"]["precision_used"] in want, (noise, ra["auto"])
-        assert ra["auto"]["pilot_rows"] == 2048
+        assert ra["auto"]["pilot_rows"] == N // 8      # (the pilot is the first rows of the cascade's first sweep)
         assert torch.equal(ra["argmin"], r0["argmin"]), noise
     Cd = torch.cat([Cn[:200], Cn[:200]])                       # every centroid twice: exact ties on every row
     X = Cn[lab % 200] + 0.5 * Z
     r0 = api.cosine_identify(ctx, X, Cd)
     ra = api.cosine_identify(ctx, X, Cd, precision=3)
-    assert ra["auto"]["precision_used"] == 0 and ra["auto"]["pilot_to_fp32"] == 2048, ra["auto"]
+    assert ra["auto"]["precision_used"] == 0 and ra["auto"]["pilot_to_fp32"] == ra["auto"]["pilot_rows"] == N // 8, ra["auto"]
     assert torch.equal(ra["argmin"], r0["argmin"]) and torch.equal(ra["min"], r0["min"])
     # small calls, wide embeddings and distance-matrix requests run as precision 0 without a pilot
     rs = api.cosine_identify(ctx, X[:100], Cd, precision=3, dist=True)
