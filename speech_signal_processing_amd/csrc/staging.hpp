@@ -7,10 +7,13 @@ namespace ssp {
 // hipMalloc + hipFree pair per staged operand costs up to 0.7 ms each once the allocator has no small block at hand (GMM_UBM.delta
 // took 1.4 ms a call in such a state, 0.06 ms with the buffers kept).  A slot is taken for the life of one Staged; all work of a
 // ctx is ordered on its one stream, so the next call may overwrite a slot without a host wait.  Buffers above KEEP_MAX are not kept.
-struct StagePool {
+// (a template over the buffer type so that tests/native/stagepool_threads.cpp can drive the slot logic from several threads under
+//  ThreadSanitizer with a malloc-backed buffer, without a HIP runtime)
+template <class Buf>
+struct StagePoolT {
     static constexpr int SLOTS = 8;
     static constexpr size_t KEEP_MAX = (size_t)64 << 20;
-    DevBuf slot[SLOTS];
+    Buf slot[SLOTS];
     bool busy[SLOTS] = {};
     std::mutex mu;  // (a ctx is not thread-safe, but before the pool two host-pointer calls on one ctx never shared a staging buffer: keep it so)
     void give_back(int i) {
@@ -40,6 +43,8 @@ struct StagePool {
         return fit;
     }
 };
+#ifndef SSP_STAGING_NO_HIP
+using StagePool = StagePoolT<DevBuf>;
 // Pipeline of large SSP_HOST MFCC batches (mfcc_plan.hip, mfcc_run_host_sliced): the batch goes through RING slots of slice size — slice
 // i + 1 is copied in (own stream) while slice i computes (the ctx stream) and slice i - 1's features are copied back (third stream).
 // The slots, streams and events live on the ctx, are made on first use and kept (grow-only); ssp_ctx_destroy frees them.
@@ -69,6 +74,7 @@ struct HostPipe {
         if (d2h) (void)hipStreamDestroy(d2h);
     }
 };
+#endif  // SSP_STAGING_NO_HIP
 }  // namespace ssp
 #elif SSP_STAGING_PART == 2
 namespace ssp {

@@ -35,7 +35,8 @@ def test_bench_two_ranks_hip_scorer():
     assert r["gmm"]["gathered_rows"] == 2 * utts          # every rank sees every utterance's decision after the gather
     assert r["value"] > 0 and r["gmm"]["value"] > 0
     # weak scaling bookkeeping: the whole-job frame count is both ranks' frames
-    assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 2 * r["config"]["frames_per_gpu"]) <= 1e-6 * 2 * r["config"]["frames_per_gpu"]
+    # (the compact line carries six significant digits)
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 2 * r["config"]["frames_per_gpu"]) <= 1e-5 * 2 * r["config"]["frames_per_gpu"]
 
 
 def test_bench_four_ranks_rehearsal_ragged_gather():

@@ -2353,3 +2353,64 @@ def test_cosine_precision_auto(ssp):
     Xn = X[:9000].cpu().numpy()
     rh = api.cosine_identify(api.default_context(), Xn, Cd.cpu().numpy(), precision=3)     # host pointers
     assert (rh["argmin"] == r0["argmin"][:9000].cpu().numpy()).all()
+
+
+def test_two_contexts_on_two_threads_through_the_host_paths(ssp, monkeypatch):
+    """A ctx is not thread-safe, distinct contexts are (include/ssp.h): two threads, each with its own context / plan / scorer, run
+    host-pointer calls at the same time — per-utterance MFCC (the staging pool), a sliced host-fed batch (the copy / compute / copy-back
+    ring with its own streams), delta, GMM scoring with close-call re-scoring, and the error paths (ssp_last_error is per thread) —
+    and every result equals the one the same call gives alone."""
+    import threading
+    pkg, api = ssp
+    monkeypatch.setenv("SSP_HOST_SLICE_MB", "1")
+    rng = np.random.default_rng(21)
+    lens = [int(v) for v in rng.integers(2000, 60000, 120)]
+    flat = np.concatenate([(0.2 * rng.standard_normal(n)).astype(np.float32) for n in lens])
+    K, D, S = 16, 39, 12
+    w, mu, cov = rng.dirichlet(5 * np.ones(K)), rng.standard_normal((K, D)), rng.uniform(0.5, 2.0, (K, D))
+    mus = np.stack([mu] + [mu + 0.05 * rng.standard_normal((K, D)) for _ in range(S)])
+
+    def job(tag, out):
+        try:
+            ctx = api.Context(0)                                   # its own stream
+            plan = api.MfccPlan(ctx, pkg.preset_sidekit(delta_order=2)).set_reproducible()
+            seg = api.Segments.from_lengths(ctx, lens)
+            fseg = plan.frame_segments(seg)
+            sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
+            res = []
+            for rep in range(3):
+                feats = plan.run(flat, seg, fseg)                                          # sliced pipeline (1-MiB slices)
+                one = plan.run(flat[:lens[0]], api.Segments.from_lengths(ctx, lens[:1]))  # staging pool
+                dl = api.delta_features(ctx, np.ascontiguousarray(feats[:500, :13]), api.Segments.from_lengths(ctx, [500]), 2)
+                r = sc.score(feats, fseg, precision=1)
+                try:
+                    plan.run(flat[:10], seg, fseg)                                          # error path: samples shorter than the table
+                    res.append("no error")
+                except ValueError as e:
+                    res.append(str(e))
+                try:
+                    api.MfccPlan(ctx, pkg.preset_sidekit(delta_order=2)).run(flat, seg, fseg, variant=7)
+                except ValueError as e:
+                    res.append("variant" in str(e))
+                res += [feats.copy(), one.copy(), np.asarray(dl).copy(), np.asarray(r["argmax"]).copy(), np.asarray(r["scores"]).copy()]
+            out[tag] = res
+        except Exception as e:  # pragma: no cover
+            out[tag] = e
+
+    alone = {}
+    job("alone", alone)
+    assert not isinstance(alone["alone"], Exception), alone["alone"]
+    both = {}
+    ts = [threading.Thread(target=job, args=(t, both)) for t in ("a", "b")]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for t in ("a", "b"):
+        assert not isinstance(both[t], Exception), both[t]
+        assert len(both[t]) == len(alone["alone"])
+        for x, y in zip(both[t], alone["alone"]):
+            if isinstance(x, np.ndarray):
+                assert np.array_equal(x, y, equal_nan=True)
+            else:
+                assert x == y
