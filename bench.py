@@ -224,6 +224,26 @@ def kernel_source_sha256(names=("mfcc_stream_kernel.hpp", "mfcc_stream.hip", "cp
     return h.hexdigest()
 
 
+GMM_SOURCES = ("gmm.hip", "common.hpp")         # kernel source the MFMA-pipe counters of profiles/gmm_mfma_util.json are tied to
+COSINE_SOURCES = ("cosine.hip", "common.hpp")    # ... profiles/cosine_mfma_util.json
+
+
+def mfma_busy_from_profile(fname, kernel, sources):
+    """profiles/<fname> (tools/pmc_mfma.sh + store_mfma_pmc.py): the MFMA-pipe busy fraction of `kernel`, quoted only when the counters
+    were taken on the source this build was made from (sha256 of `sources`); -> (value or None, provenance dict)"""
+    src = {"file": "profiles/" + fname, "matches_this_build": False}
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        src["taken_on"] = j.get("kernel_source_sha256")
+        src["matches_this_build"] = j.get("kernel_source_sha256") == kernel_source_sha256(sources)
+        src["workload"] = j.get("workload")
+        if src["matches_this_build"]:
+            return (j["kernels"][kernel]["derived"] or {}).get("mfma_busy_fraction"), src
+    except Exception as e:
+        src["error"] = repr(e)
+    return None, src
+
+
 # ---------------------------------------------------------------------------------------------- the line the driver parses
 LINE_LIMIT = 4096            # the LAST stdout line stays under this; everything else goes to the detail file (round 5's 22.8 KB line did not parse)
 LIMITER_MFCC = "valu-issue at the power-capped clock (VALU busy 78 %, traffic = 1.01 x algorithmic: profiles/mfcc_valu_lds_pmc.json); frac stays priced on HBM"
@@ -847,6 +867,8 @@ def main():
                                    "never reaches HBM) + piece_reduce", "kernel_ms": g_ms,
                          "algorithmic_flop_per_launch": flop},
         }
+        mb, msrc = mfma_busy_from_profile("gmm_mfma_util.json", "gmm_loglik_kernel", GMM_SOURCES)
+        result["gmm"]["roofline"]["mfma_busy"], result["gmm"]["roofline"]["mfma_busy_source"] = mb, msrc
         # bf16 hi/lo split path: 3 bf16 MFMAs per k-step, same tolerance class; priced against the dense bf16 peak with
         # the ALGORITHMIC flops (the kernel executes 3x as many).  precision = 1 scores every utterance whose top-2 margin lies
         # inside the split-precision error band again on the fp32 path (timed with it), so its arg-max is the fp32 path's
@@ -1045,6 +1067,8 @@ def main():
                          "frac": flop / (c_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "cosine_reg_kernel<32, false> (d <= 256: embeddings register-resident, centroid tiles by LDS-DMA)",
                          "kernel_ms": c_ms, "algorithmic_flop_per_launch": flop},
         }
+        mb, msrc = mfma_busy_from_profile("cosine_mfma_util.json", "cosine_reg_kernel", COSINE_SOURCES)
+        result["cosine"]["roofline"]["mfma_busy"], result["cosine"]["roofline"]["mfma_busy_source"] = mb, msrc
         # split precision (ssp_cosine_identify2 precision = 1): bf16 x 3 MFMA sweep keeping the two best cosines + fp32 re-scoring of the
         # rows inside the proven error band (device-side list, no host round trip); the fp32 path's arg-min on every row
         am0 = rc["argmin"].clone()

@@ -39,6 +39,13 @@ constexpr int LM_OFF = 1792;       // log-mel row of frame g sits at LM_OFF - 64
 constexpr int RING_FRAMES = 24;    // cepstrum ring: the 16 newest frames + 8 of history (delta-delta reaches back 4 + 4)
 constexpr int RING_ROW = 64;       // bytes per ring row: 16 cepstral slots (13 used)
 constexpr int STREAM_WAVES = 4;
+// P row (257 power / magnitude bins) of frame g starts PSH bytes into its image for odd g: the images are 512 dwords apart, so the four
+// frames' P rows would sit on the same banks and the 16-lane groups of two frames that share a ds_write_b32 half-wave conflict 2-way on
+// every P write (bank = dword mod 32); 16 dwords apart they take the two halves of the bank row.  (SSP_S_PSHIFT=0: the layout of rounds 2-5)
+#ifndef SSP_S_PSHIFT
+#define SSP_S_PSHIFT 64
+#endif
+constexpr int PSH = SSP_S_PSHIFT;
 #define SSP_STR_(x) #x
 #define SSP_STR(x) SSP_STR_(x)
 
@@ -280,7 +287,11 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 // (volatile: one ds_read_b64 + one ds_read_b32 per row, 2 + 2 LDS cycles.  Left to itself the compiler merges the pair
                 //  with its pre-emphasis partner into a ds_read2_b64 — 8 LDS cycles — and spends an address VGPR + add per row on it)
                 pf[n1] = *(lds_cv2f_t)(uintptr_t)(sp + 128 * n1);
+#ifdef SSP_S_PM64   // (experiment: the partner through a ds_read_b64 of (x[e - 2], x[e - 1]) — bank modulus 64, conflict free — instead of the 2-way conflicting b32)
+                if (PRE) pm[n1] = (*(lds_cv2f_t)(uintptr_t)(sp + 128 * n1 - 8)).y;
+#else
                 if (PRE) pm[n1] = *(lds_cvf_t)(uintptr_t)(sp + 128 * n1 - 4);
+#endif
             }
         };
         auto stage_read_b = [&](pfarr_t& pf, pmarr_t& pm) {
@@ -288,7 +299,11 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
 #pragma unroll
             for (int n1 = NH; n1 < NZ; ++n1) {
                 pf[n1] = *(lds_cv2f_t)(uintptr_t)(sp + 128 * n1);
+#ifdef SSP_S_PM64
+                if (PRE) pm[n1] = (*(lds_cv2f_t)(uintptr_t)(sp + 128 * n1 - 8)).y;
+#else
                 if (PRE) pm[n1] = *(lds_cvf_t)(uintptr_t)(sp + 128 * n1 - 4);
+#endif
             }
         };
         // A row that runs past the window's last tap carries zero weights there, and whatever the samples behind the frame hold — a NaN of a
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             fft16(z);
             // ---- split step of the real FFT (partners from lane 16 - j), power / magnitude -> P row
             {
-                float* P = reinterpret_cast<float*>(zf);
+                float* P = reinterpret_cast<float*>(zf + (PSH ? (g & 1) * PSH : 0));
                 float* Pm = P + 144 - j;
 #pragma unroll
                 for (int kp = 0; kp < 4; ++kp) {
@@ -424,7 +439,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
             float sfr[4];
 #pragma unroll
             for (int fr = 0; fr < 4; ++fr) {
-                const char* pr = zbuf + fr * ZFRAME;
+                const char* pr = zbuf + fr * ZFRAME + (fr & 1) * PSH;
                 v4f acc = *reinterpret_cast<const v4f*>(pr + mofs[0]) * mw[0];
 #pragma unroll
                 for (int i = 1; i < MV; ++i) acc = __builtin_elementwise_fma(*reinterpret_cast<const v4f*>(pr + mofs[i]), mw[i], acc);
@@ -729,7 +744,7 @@ __global__ __launch_bounds__(64 * STREAM_WAVES, OCC) void mfcc_stream512_kernel(
                 float r[4][6];
 #pragma unroll
                 for (int fr = 0; fr < 4; ++fr) {
-                    const char* pr = zbuf + fr * ZFRAME;
+                    const char* pr = zbuf + fr * ZFRAME + (fr & 1) * PSH;
                     const v4f p0 = *reinterpret_cast<const v4f*>(pr + 64 * c), p1 = *reinterpret_cast<const v4f*>(pr + 64 * c + 16);
                     const v4f p2 = *reinterpret_cast<const v4f*>(pr + 64 * c + 32), p3 = *reinterpret_cast<const v4f*>(pr + 64 * c + 48);
                     const float p256 = *reinterpret_cast<const float*>(pr + 1024);

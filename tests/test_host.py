@@ -356,12 +356,14 @@ def test_staging_pool_under_thread_sanitizer(tmp_path):
     """SURVEY section 5 (race detection): the SSP_HOST staging pool's slot logic (csrc/staging.hpp, the code round 5 put a mutex into)
     driven by eight threads on one pool and by two pools side by side, compiled with -fsanitize=thread (host code only; the buffer type
     is malloc-backed, no HIP runtime): no report from ThreadSanitizer, no slot ever held by two threads."""
+    import subprocess
     exe = str(tmp_path / "stagepool_tsan")
     src = os.path.join(ROOT, "tests", "native", "stagepool_threads.cpp")
     b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", src, "-o", exe], capture_output=True, text=True)
     assert b.returncode == 0, b.stderr[-2000:]
     r = subprocess.run([exe, "8", "20000"], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0"))
+                       env={**{k: v for k, v in os.environ.items() if k != "LD_PRELOAD"},   # (tools/asan_host.sh preloads the ASan runtime)
+                            "TSAN_OPTIONS": "halt_on_error=0:report_signal_unsafe=0"})
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
     assert "ownership errors 0" in r.stdout
