@@ -46,6 +46,9 @@ constexpr int STREAM_WAVES = 4;
 #define SSP_S_PSHIFT 64
 #endif
 constexpr int PSH = SSP_S_PSHIFT;
+// (a piece read starts at a filter's first bin rounded down to 4 and spans at most 4 MELV <= 20 taps: it ends below dword 256 + 24 of the P
+//  row — with the shift still far below the lowest log-mel row, LM_OFF - 192, which a read must never reach: last quad's ln 0 = -inf there)
+static_assert(4 * (256 + 24) + PSH <= LM_OFF - 192, "shifted P row: piece reads must stay below the log-mel rows");
 #define SSP_STR_(x) #x
 #define SSP_STR(x) SSP_STR_(x)
 

@@ -362,7 +362,7 @@ def test_staging_pool_under_thread_sanitizer(tmp_path):
     b = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", src, "-o", exe], capture_output=True, text=True)
     assert b.returncode == 0, b.stderr[-2000:]
     r = subprocess.run([exe, "8", "20000"], capture_output=True, text=True, timeout=300,
-                       env={**{k: v for k, v in os.environ.items() if k != "LD_PRELOAD"},   # (tools/asan_host.sh preloads the ASan runtime)
+                       env={**{k: v for k, v in os.environ.items() if k != "LD_PRELOAD"},   # (a sanitizer run of the CPU suite preloads another runtime)
                             "TSAN_OPTIONS": "halt_on_error=0:report_signal_unsafe=0"})
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
