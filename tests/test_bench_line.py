@@ -52,7 +52,7 @@ def test_compact_line_of_a_full_result():
     assert line["detail"] == "gpurun_out/bench_detail.json" and "build" in line
     # one small summary per other stage
     for k in ("gmm", "cosine", "mfcc_ref26_cmvn", "mfcc_librosa", "plp", "gmm_em", "dvector_dnn", "dtw"):
-        assert set(line[k]) <= {"value", "unit", "kernel_ms", "frac", "bound", "mfma_busy", "gathered_rows", "record_bytes", "ms_per_step"}, (k, line[k])
+        assert set(line[k]) <= {"value", "kernel_ms", "frac", "mfma_busy", "gathered_rows", "record_bytes", "ms_per_step"}, (k, line[k])
         assert line[k]["value"] > 0
     assert line["gmm"]["gathered_rows"] == res["gmm"]["gathered_rows"] and line["gmm"]["record_bytes"] == 12
     assert "env" not in line or set(line["env"]) == {"sclk_mhz", "power_w"}     # the per-window statistics stay in the detail file

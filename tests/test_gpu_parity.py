@@ -451,7 +451,15 @@ def test_partially_silent_utterances_in_a_machine_filling_batch(ssp, order, cmvn
         np.testing.assert_allclose(got[u], got[u % 7 + 7], rtol=0, atol=2e-4 * max(1.0, float(np.abs(got[u % 7 + 7]).max())))
 
 
-@pytest.mark.parametrize("dialect", ["librosa", "inrepo2048", "sidekit", "sidekit_short", "plp"])
+def _with_floor2(tables_oracle):
+    """a sidekit dialect with a max(eps, .) floor (floor_mode 2, numpy.maximum: a NaN mel sum stays NaN) -> (MfccTables, oracle tuple)"""
+    import dataclasses
+    tables, (cfg, w, fb, dct) = tables_oracle
+    return (dataclasses.replace(tables, cfg=dataclasses.replace(tables.cfg, floor_mode=2, eps=1e-10)),
+            (dict(cfg, floor_mode=2, eps=1e-10), w, fb, dct))
+
+
+@pytest.mark.parametrize("dialect", ["librosa", "inrepo2048", "sidekit", "sidekit_short", "plp", "sidekit_floor2", "plp_short"])
 def test_nan_sample_stays_in_its_frames(ssp, dialect):
     """A NaN sample (a corrupt recording) in a ragged batch of short and long utterances (multi-chunk work tables): in the reference's
     arithmetic every frame that holds it is NaN — plus the deltas' reach; with librosa's power_to_db the whole utterance, because
@@ -466,7 +474,12 @@ def test_nan_sample_stays_in_its_frames(ssp, dialect):
         "sidekit": lambda: (pkg.preset_sidekit(delta_order=2), O.sidekit_tables(delta_order=2), 16000),
         # an 18 ms window: 288 taps, FOUR of the 512-point kernels' thirteen 32-sample rows are padding (round 4 excepted such windows)
         "sidekit_short": lambda: (pkg.preset_sidekit(nwin=0.018, delta_order=2), O.sidekit_tables(nwin=0.018, delta_order=2), 16000),
-        "plp": lambda: (pkg.preset_sidekit_plp(), O.sidekit_plp_tables(), 16000)}[dialect]()
+        "plp": lambda: (pkg.preset_sidekit_plp(), O.sidekit_plp_tables(), 16000),
+        # round 5's advisor findings: a max(eps, .) floor on a 512-point plan (the fused kernels' fmaxf would turn a NaN mel sum into
+        # log(eps): such plans take the generic kernel now), and the PLP front end with an 18 ms window (several padded rows: the dense-band
+        # instance, which silences the last row only, no longer takes it)
+        "sidekit_floor2": lambda: _with_floor2((pkg.preset_sidekit(delta_order=2), O.sidekit_tables(delta_order=2))) + (16000,),
+        "plp_short": lambda: (pkg.preset_sidekit_plp(nwin=0.018), O.sidekit_plp_tables(nwin=0.018), 16000)}[dialect]()
     rng = np.random.default_rng(3)
     lens = [1025, 1025, 200000, 1025, 3000, 1025, 1025, 200000, 1025, 5000]
     # (2, 1999) / (2, 1600): the LAST and the FIRST tap of frame 10 of the sidekit dialects — numpy.hanning is exactly zero there, and
@@ -480,7 +493,7 @@ def test_nan_sample_stays_in_its_frames(ssp, dialect):
         with np.errstate(all="ignore"):
             for x in sigs:
                 refs.append(O.mfcc_pipeline(x, cfg, w, fb, dct))
-        for variant in ((0, 1, 2, 3) if dialect.startswith("sidekit") else (0, 1)):
+        for variant in ((0, 1, 2, 3) if dialect in ("sidekit", "sidekit_short") else (0, 1)):
             got, _ = _run_plan(api, tables, sigs, variant=variant)
             for u in range(len(sigs)):
                 fin = np.isfinite(refs[u])
@@ -490,6 +503,10 @@ def test_nan_sample_stays_in_its_frames(ssp, dialect):
         if where is not None:
             # (the sample may sit behind the last frame of a dialect that does not pad: then nothing is NaN at all)
             assert all(np.isfinite(refs[u]).all() for u in range(len(sigs)) if u != where[0])
+    if dialect == "sidekit_floor2":   # the fused kernels refuse the plan instead of flooring a NaN away
+        for variant in (2, 3):
+            with pytest.raises(NotImplementedError):
+                _run_plan(api, tables, sigs[:1], variant=variant)
 
 
 def test_sidekit_shape_fact(ssp):

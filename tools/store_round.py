@@ -53,6 +53,10 @@ for st, (kern, key) in DOM.items():
         out.append("| " + " | ".join("%.3f" % x for x in d) + " |")
         out.append("")
         out.append("mean of all %.3f ms, min %.3f, max %.3f; mean of the last %d: %.3f ms" % (sum(d) / len(d), min(d), max(d), min(5, len(d)), sum(d[-5:]) / min(5, len(d))))
+        big = [x for x in d if x >= 0.5 * max(d)]   # (re-scoring passes and precision-auto pilots launch the same kernels on a few rows)
+        if len(big) != len(d):
+            out.append("full-size launches only (>= half of the longest; the short ones are re-scoring passes / pilots on listed rows): %d launches, mean %.3f ms, mean of the last %d: %.3f ms" % (
+                len(big), sum(big) / len(big), min(5, len(big)), sum(big[-5:]) / min(5, len(big))))
         out.append("")
     node = line if key == "roofline" else line.get(key, {})
     def rooflines(n, pre=""):
