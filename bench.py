@@ -760,6 +760,32 @@ def main():
             "value_i16": hfseg.total / w16, "wall_ms_i16": w16 * 1e3, "pcie_bound_ms_i16": bound16 * 1e3, "frac_of_pcie_bound_i16": bound16 / w16,
             "bits_equal_device_path_i16": same16, "i16_over_f32": w32 / w16,
             "bound": "PCIe: max(input bytes / measured pinned H2D rate, feature bytes / measured D2H rate) of this box, this run"}
+        # ---- the reference-shaped call itself: GMM_UBM.extract_feature(x, y) (GMM_UBM.py:72-118) on a list of int16 utterances as
+        # utils.tools.read returns them (pageable memory, the shim's own context): list -> flat int16 -> ssp_mfcc_run_i16 -> 26-d scaled
+        # features -> float64 rows per utterance.  Wall clock of the Python call (what a user of the reference's script waits for).
+        try:
+            from speech_signal_processing_amd import GMM_UBM as shim
+            n_s = min(n_h, 2000)
+            xs = [np.array(pin16[i * n_samp:(i + 1) * n_samp].numpy()) for i in range(n_s)]   # (pageable copies, one array per utterance)
+            shim.extract_feature(xs[:50], [0] * 50)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                feat, _ = shim.extract_feature(xs, [0] * n_s)
+                ts.append(time.perf_counter() - t0)
+            ws = float(np.median(ts))
+            fr = int(sum(f.shape[0] for f in feat))
+            xs32 = [x.astype(np.float32) for x in xs]
+            t0 = time.perf_counter()
+            shim.extract_feature(xs32, [0] * n_s)
+            ws32 = time.perf_counter() - t0
+            result["mfcc_host_fed"]["extract_feature_shim"] = {
+                "what": "GMM_UBM.extract_feature(list of %d int16 utterances of 3 s, pageable) -> list of (298, 26) float64, wall clock of the Python call" % n_s,
+                "wall_ms": ws * 1e3, "frames_per_s": fr / ws, "utterances": n_s, "wall_ms_float32_input": ws32 * 1e3,
+                "bytes_in": n_s * n_samp * 2, "bytes_out_float64": fr * 26 * 8}
+            del xs, xs32, feat
+        except Exception as e:  # (never lose the bench line to an extra)
+            result["mfcc_host_fed"]["extract_feature_shim"] = {"error": repr(e)}
         del pin_in, pin_out, dev_tmp, dev_out, pin16, a16, in_np, out_np
 
     # ------------------------------------------------------------------ the reference-pinned dialect: in-repo MFCC (utils/processing.py:19-144)
