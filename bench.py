@@ -760,6 +760,26 @@ def main():
             "value_i16": hfseg.total / w16, "wall_ms_i16": w16 * 1e3, "pcie_bound_ms_i16": bound16 * 1e3, "frac_of_pcie_bound_i16": bound16 / w16,
             "bits_equal_device_path_i16": same16, "i16_over_f32": w32 / w16,
             "bound": "PCIe: max(input bytes / measured pinned H2D rate, feature bytes / measured D2H rate) of this box, this run"}
+        # ---- the same call from PAGEABLE memory (what numpy hands over unless the caller allocates with api.pinned_empty): a fifth of the batch
+        try:
+            n_pg = max(1, n_h // 5)
+            pg_seg = api.Segments.from_lengths(ctx, np.full(n_pg, n_samp, dtype=np.int64))
+            pg_fseg = plan.frame_segments(pg_seg)
+            pg_in = np.array(in_np[:n_pg * n_samp])                 # (a pageable copy)
+            pg_out = np.empty((pg_fseg.total, plan.d_out), dtype=np.float32)
+            plan.run(pg_in, pg_seg, pg_fseg, out=pg_out, variant=args.variant)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                plan.run(pg_in, pg_seg, pg_fseg, out=pg_out, variant=args.variant)
+                ts.append(time.perf_counter() - t0)
+            wpg = float(np.median(ts))
+            result["mfcc_host_fed"]["pageable"] = {"utterances": n_pg, "wall_ms": wpg * 1e3, "frames_per_s": pg_fseg.total / wpg,
+                                                   "effective_gbs_in": n_pg * n_samp * 4 / wpg / 1e9,
+                                                   "frac_of_pcie_bound": (bound32 * n_pg / n_h) / wpg}
+            del pg_in, pg_out
+        except Exception as e:
+            result["mfcc_host_fed"]["pageable"] = {"error": repr(e)}
         # ---- the reference-shaped call itself: GMM_UBM.extract_feature(x, y) (GMM_UBM.py:72-118) on a list of int16 utterances as
         # utils.tools.read returns them (pageable memory, the shim's own context): list -> flat int16 -> ssp_mfcc_run_i16 -> 26-d scaled
         # features -> float64 rows per utterance.  Wall clock of the Python call (what a user of the reference's script waits for).

@@ -77,9 +77,9 @@ struct FastArgs {
     float log_add, log_max, log_k;
     // persistent workgroups
     float* ceps_scratch;      // [grid][ceps_stride] cepstra of the chunk each workgroup has in flight
-    int32_t* work_counter;    // [0] next chunk to claim | [1] != 0: a chunk was flagged (64 bytes, zeroed before every launch)
-    int32_t* redo_flags;      // = work_counter + 16: [n_chunks], written by the first kernel — the chunk's time steps met a non-finite cepstrum:
-                              // the second kernel (WALK) walks it again
+    int32_t* work_counter;    // [0] next chunk to claim (zeroed before every launch)
+    int32_t* redo_flags;      // (unused by the workgroup kernel — it forms non-finite steps inline —; kept so that the argument block's
+                              //  layout, which the stream kernels share, stays what their instances were tuned with)
     int32_t ceps_stride;      // floats per workgroup slot (multiple of 4)
     int32_t n_chunks;  // log(max(v + log_add, log_max)) * log_k  (floor_mode / log_mode, branch free)
 };
@@ -88,8 +88,8 @@ struct FastArgs {
 struct StreamArgs {
     const float* dctA;        // [KS][64] DCT matrix as the MFMA A operand: lane (ceps = l & 15, kq = l >> 4), k-step s <-> filter KS kq + s
     int32_t* work_counter;    // [0] next chunk to claim | [1] != 0: a chunk was flagged (64 bytes, zeroed before every launch)
-    int32_t* redo_flags;      // = work_counter + 16: [n_chunks], written by the first kernel — the chunk's time steps met a non-finite cepstrum:
-                              // the second kernel (WALK) walks it again
+    int32_t* redo_flags;      // = work_counter + 16: [n_chunks], zeroed by the launch, set by mfcc_stream_scan_kernel (the SECOND kernel) for every
+                              // chunk whose stored rows show a non-finite cepstrum in a time step's window; the THIRD kernel (WALK = 1) walks those again
     int32_t n_chunks;
     int32_t wave_bytes;       // LDS per wave: 4 frame images + sample stage + cepstrum ring
     int32_t stage_bytes;      // sample stage (whole 1-KiB DMA pieces + a trailing 512-B half piece)

@@ -722,7 +722,18 @@ static int mfcc_run_any(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, con
     const bool two_pass = plan->cache_split_topdb && (v == 1 || v == 4);   // (needs the whole batch's rows in one scratch)
     const bool big = (size_t)n_samp_total * sizeof(float) >= 2 * slice && frame_seg->n >= 2 && sample_seg->host.front() == 0 && frame_seg->host.front() == 0;
     if (!two_pass && ((where == SSP_HOST && big) || (stype == 1 && where == SSP_DEVICE && sample_seg->host.front() == 0 && frame_seg->host.front() == 0)))
-        return run_sliced(plan, sample_seg, frame_seg, samples, stype, feats_out, where == SSP_HOST, slice, kernel_ms);
+    {
+        const int src = run_sliced(plan, sample_seg, frame_seg, samples, stype, feats_out, where == SSP_HOST, slice, kernel_ms);
+        if (src != SSP_OK && plan->ctx->pipe) {
+            // a call that failed half way must not leave copies in flight that read / write the CALLER's arrays after it has returned:
+            // the three streams are drained before the error goes up (the message of the first failure stays)
+            HostPipe& hp = *plan->ctx->pipe;
+            (void)hipStreamSynchronize(s);
+            if (hp.h2d) (void)hipStreamSynchronize(hp.h2d);
+            if (hp.d2h) (void)hipStreamSynchronize(hp.d2h);
+        }
+        return src;
+    }
 
     // one piece: the operands as they are (device pointers), or staged whole through the ctx's pool (host pointers)
     Staged sin, sout, sraw;
