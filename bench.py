@@ -336,8 +336,8 @@ def compact_line(res, detail_path=None):
     if isinstance(res.get("build"), dict):
         line["build"] = _pick(res["build"], "build_mode", "lib_bytes")
     # ---- the other stages: a summary each (never part of `value`)
-    for k in ("mfcc_ref26_cmvn", "mfcc_librosa", "mfcc_host_fed", "gmm", "gmm_bf16x3", "gmm_bf16x3_proven_band", "gmm_auto", "cosine", "cosine_bf16x3",
-              "cosine_bf16_cascade", "cosine_auto", "gmm_em", "dvector_dnn", "dvector_pipeline", "dtw", "plp"):
+    for k in ("mfcc_ref26_cmvn", "mfcc_librosa", "mfcc_host_fed", "gmm", "gmm_bf16x3", "gmm_bf16x3_proven_band", "gmm_auto", "gmm_host_fed", "cosine",
+              "cosine_bf16x3", "cosine_bf16_cascade", "cosine_auto", "cosine_host_fed", "gmm_em", "dvector_dnn", "dvector_pipeline", "dtw", "plp"):
         if k in res:
             line[k] = _stage_summary(res[k])
     if "gmm" in res:   # the one collective of the path: what the N-rank runs are checked on
@@ -347,6 +347,9 @@ def compact_line(res, detail_path=None):
     for k in ("gmm_auto", "cosine_auto"):
         if k in res:
             line[k].update(_pick(res[k], "worst_ratio_to_best_fixed", "mismatches_vs_fp32"))
+    for k in ("gmm_host_fed", "cosine_host_fed"):
+        if k in res:
+            line[k] = _pick(res[k], "value", "wall_ms", "sum_ms", "overlap", "error")
     if "mfcc_inrepo" in res:
         line["mfcc_inrepo"] = {t: _stage_summary(v) for t, v in res["mfcc_inrepo"].items() if t in ("16k", "8k")}
     c3 = res.get("gmm_cfg3_shape")
@@ -915,6 +918,43 @@ def main():
         }
         mb, msrc = mfma_busy_from_profile("gmm_mfma_util.json", "gmm_loglik_kernel", GMM_SOURCES)
         result["gmm"]["roofline"]["mfma_busy"], result["gmm"]["roofline"]["mfma_busy_source"] = mb, msrc
+        if "hostfed" in stages and rank == 0:
+            # the same scoring HOST-FED (GMM_UBM.py:181-197 hands host arrays): a quarter of the batch's features in pinned memory through
+            # ssp_gmm_score(SSP_HOST) — rows copied in ahead of the kernels that score them; wall clock against copy + kernels
+            try:
+                u_q = max(2, n_utt // 4)
+                f_q = int(fseg.offsets[u_q])
+                pin_f = torch.empty((f_q, D), dtype=torch.float32, pin_memory=True)
+                pin_f.copy_(feats[:f_q])
+                seg_q = api.Segments.from_lengths(ctx, np.diff(fseg.offsets[:u_q + 1]))
+                torch.cuda.synchronize()
+                dev_q = scorer.score(feats[:f_q], seg_q, precision=0, timing=True)
+                tcp = []
+                tmp = torch.empty_like(feats[:f_q])
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    tmp.copy_(pin_f, non_blocking=True)
+                    torch.cuda.synchronize()
+                    tcp.append(time.perf_counter() - t0)
+                copy_ms = float(np.median(tcp)) * 1e3
+                fnp = pin_f.numpy()
+                scorer.score(fnp, seg_q, precision=0)
+                tw = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    hq = scorer.score(fnp, seg_q, precision=0)
+                    tw.append(time.perf_counter() - t0)
+                wall_ms = float(np.median(tw)) * 1e3
+                result["gmm_host_fed"] = {
+                    "metric": "GMM frame-scores/s, host-fed: %d utterances' features in pinned host memory through ssp_gmm_score(SSP_HOST), fp32 path; wall clock of the call" % u_q,
+                    "value": f_q * (S + 1) / (wall_ms * 1e-3), "unit": "frame-scores/s", "wall_ms": wall_ms, "copy_in_ms": copy_ms,
+                    "kernel_ms_device_path": dev_q["kernel_ms"], "sum_ms": copy_ms + dev_q["kernel_ms"],
+                    "overlap": max(copy_ms, dev_q["kernel_ms"]) / wall_ms,
+                    "scores_equal_device_path": bool(torch.equal(torch.from_numpy(hq["scores"]).to(device), dev_q["scores"]))}
+                del pin_f, tmp, fnp, hq, dev_q
+            except Exception as e:  # (never lose the bench line to an extra)
+                result["gmm_host_fed"] = {"error": repr(e)}
         # bf16 hi/lo split path: 3 bf16 MFMAs per k-step, same tolerance class; priced against the dense bf16 peak with
         # the ALGORITHMIC flops (the kernel executes 3x as many).  precision = 1 scores every utterance whose top-2 margin lies
         # inside the split-precision error band again on the fp32 path (timed with it), so its arg-max is the fp32 path's
@@ -1021,7 +1061,7 @@ def main():
         del mus
         seg4 = api.Segments.from_lengths(ctx, np.diff(fseg.offsets[:u4 + 1]))
         out4 = {}
-        for prec, tag in ((0, "f32"), (3, "bf16x3"), (1, "bf16x3_proven_band")):  # (3: calibrated band; 1: proven bound, more re-scoring)
+        for prec, tag in ((0, "f32"), (3, "bf16x3"), (1, "bf16x3_proven_band"), (4, "auto")):  # (3: calibrated band; 1: proven bound, more re-scoring; 4: pilot, then 1 or 0)
             scorer4.score(feats[:f4], seg4, precision=prec)
             barrier()
             torch.cuda.synchronize()
@@ -1039,6 +1079,8 @@ def main():
             else:
                 out4[tag]["utterances_rescored_in_fp32"] = int(scorer4.last_rescored)
                 out4[tag]["argmax_mismatches_vs_fp32_path"] = int((am4 != r4["argmax"]).sum().item())
+                if prec == 4:
+                    out4[tag].update(scorer4.last_auto)
         result["gmm_cfg3_shape"] = {
             "metric": "GMM frame-scores/s at the configs[3] shape (K=512, 1251 speakers + UBM, D=%d), sample of %d utterances per GPU" % (D, u4),
             "frames_per_gpu": f4, "full_config_utterances_per_gpu": 150000, "fraction_of_full_config": u4 / 150000.0,
@@ -1115,6 +1157,36 @@ def main():
         }
         mb, msrc = mfma_busy_from_profile("cosine_mfma_util.json", "cosine_reg_kernel", COSINE_SOURCES)
         result["cosine"]["roofline"]["mfma_busy"], result["cosine"]["roofline"]["mfma_busy_source"] = mb, msrc
+        if "hostfed" in stages and rank == 0:
+            # host-fed (d_vector.py:315-319 hands host arrays): the embeddings in pinned memory through ssp_cosine_identify(SSP_HOST), arg-min + minimum
+            try:
+                pin_x = torch.empty((N, d), dtype=torch.float32, pin_memory=True)
+                pin_x.copy_(X)
+                tmpx = torch.empty_like(X)
+                tcp = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    tmpx.copy_(pin_x, non_blocking=True)
+                    torch.cuda.synchronize()
+                    tcp.append(time.perf_counter() - t0)
+                copy_ms = float(np.median(tcp)) * 1e3
+                xnp, cnp = pin_x.numpy(), Cn.cpu().numpy()
+                api.cosine_identify(ctx, xnp, cnp)
+                tw = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    hc = api.cosine_identify(ctx, xnp, cnp)
+                    tw.append(time.perf_counter() - t0)
+                wall_ms = float(np.median(tw)) * 1e3
+                result["cosine_host_fed"] = {
+                    "metric": "cosine pair-scores/s, host-fed: 1e6 x 256 embeddings in pinned host memory through ssp_cosine_identify(SSP_HOST), fp32 path, arg-min + minimum; wall clock of the call",
+                    "value": N * S / (wall_ms * 1e-3), "unit": "pair-scores/s", "wall_ms": wall_ms, "copy_in_ms": copy_ms, "kernel_ms_device_path": c_ms,
+                    "sum_ms": copy_ms + c_ms, "overlap": max(copy_ms, c_ms) / wall_ms,
+                    "argmin_equals_device_path": bool((torch.from_numpy(hc["argmin"]).to(device) == rc["argmin"]).all().item())}
+                del pin_x, tmpx, xnp, hc
+            except Exception as e:
+                result["cosine_host_fed"] = {"error": repr(e)}
         # split precision (ssp_cosine_identify2 precision = 1): bf16 x 3 MFMA sweep keeping the two best cosines + fp32 re-scoring of the
         # rows inside the proven error band (device-side list, no host round trip); the fp32 path's arg-min on every row
         am0 = rc["argmin"].clone()

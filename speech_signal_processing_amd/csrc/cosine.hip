@@ -947,6 +947,46 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
     hipStream_t s = ctx->stream;
     Staged sx, sc, sd, sa, sm;
     int rc;
+    // Host-fed arg-min / minimum on the parity path above two slices of embeddings (d_vector.py:315-319 hands host arrays): the rows go
+    // through the ctx's ring, copied in ahead of the sweep that scores them (feed_rows, staging.hpp): a call costs its PCIe time
+    // instead of PCIe + sweep.  Rows are independent: bits equal to the one-piece path.
+    if (where == SSP_HOST && precision == 0 && !dist_out && d <= 256 && N >= 2 && (size_t)N * d * sizeof(float) >= 2 * host_slice_bytes()) {
+        const float* dC = (const float*)sc.in(ctx, C, (size_t)S * d * sizeof(float), where, &rc);
+        SSP_TRY(rc);
+        int32_t* dA = (int32_t*)sa.out(ctx, argmin_out, (size_t)N * sizeof(int32_t), where, &rc);
+        SSP_TRY(rc);
+        float* dM = (float*)sm.out(ctx, min_out, (size_t)N * sizeof(float), where, &rc);
+        SSP_TRY(rc);
+        const int nq = d <= 64 ? 8 : (d <= 128 ? 16 : (d <= 192 ? 24 : 32));
+        const int n_tiles = (S + 31) / 32;
+        DevBuf& img = ctx->cos_img;
+        SSP_TRY(img.reserve((size_t)n_tiles * nq * 256 * sizeof(float)));
+        ctx->cos_last_rescored = ctx->cos_last_split = 0;
+        ctx->cos_counts_pending = false;
+        const int64_t per = std::max<int64_t>(1, (int64_t)(host_slice_bytes() / ((size_t)d * sizeof(float))));
+        std::vector<int64_t> cuts;
+        for (int64_t r = 0; r < N; r += per) cuts.push_back(r);
+        cuts.push_back(N);
+        Timer tms;
+        SSP_TRY(tms.start(kernel_ms != nullptr, s));
+        hipLaunchKernelGGL(cos_pack_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, s, dC, S, d, nq, img.as<float>(), 1);
+        SSP_HIP(hipGetLastError());
+        SSP_TRY(feed_rows(ctx, X, (size_t)d * sizeof(float), cuts, [&](int i, void* dev) -> int {
+            const int64_t r0 = cuts[(size_t)i], r1 = cuts[(size_t)i + 1];
+            CosRegArgs ra{static_cast<const float*>(dev), img.as<float>(), nullptr, 0, nullptr, dA ? dA + r0 : nullptr, dM ? dM + r0 : nullptr, r1 - r0, d, S, n_tiles};
+            switch (nq) {
+                case 8: return launch_cos_reg<8>(ra, s);
+                case 16: return launch_cos_reg<16>(ra, s);
+                case 24: return launch_cos_reg<24>(ra, s);
+                default: return launch_cos_reg<32>(ra, s);
+            }
+        }));
+        SSP_TRY(tms.stop(s, kernel_ms));
+        SSP_TRY(sa.back(ctx, argmin_out, (size_t)N * sizeof(int32_t), where));
+        SSP_TRY(sm.back(ctx, min_out, (size_t)N * sizeof(float), where));
+        SSP_HIP(hipStreamSynchronize(s));
+        return SSP_OK;
+    }
     const float* dX = (const float*)sx.in(ctx, X, (size_t)N * d * sizeof(float), where, &rc);
     SSP_TRY(rc);
     const float* dC = (const float*)sc.in(ctx, C, (size_t)S * d * sizeof(float), where, &rc);

@@ -1202,6 +1202,44 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
     const int M = gmm->n_models;
     Staged sin, sll, ssc, sam;
     int rc;
+    // Host-fed batches without re-scoring (precision 0 / 2) above two slices of features (GMM_UBM.py:181-197 hands host arrays): the
+    // feature rows go through the ctx's ring in runs of whole utterances, copied in ahead of the kernels that score them (feed_rows,
+    // staging.hpp) — the 81 ms a configs[2] batch spends on PCIe hide under its 120 ms of scoring.  Same kernels, same piece sums:
+    // bits equal to the one-piece path.
+    if (where == SSP_HOST && !loglik_out && (scores_out || argmax_out) && (precision == 0 || precision == 2) && !want_auto && n_utt >= 2 &&
+        frame_seg->host.front() == 0 && (size_t)F * gmm->D * sizeof(float) >= 2 * host_slice_bytes()) {
+        const std::vector<int64_t>& ho = frame_seg->host;
+        const int64_t per = (int64_t)(host_slice_bytes() / ((size_t)gmm->D * sizeof(float)));
+        std::vector<int64_t> ucut{0}, fcut{0};
+        for (int64_t u = 0; u < n_utt;) {
+            int64_t e = u + 1;
+            while (e < n_utt && ho[(size_t)e + 1] - ho[(size_t)u] <= per) ++e;
+            ucut.push_back(e);
+            fcut.push_back(ho[(size_t)e]);
+            u = e;
+        }
+        float* d_sc = (float*)ssc.out(ctx, scores_out, (size_t)n_utt * M * sizeof(float), where, &rc);
+        SSP_TRY(rc);
+        int32_t* d_am = (int32_t*)sam.out(ctx, argmax_out, (size_t)n_utt * sizeof(int32_t), where, &rc);
+        SSP_TRY(rc);
+        gmm->last_rescored = 0;
+        Timer tms;
+        SSP_TRY(tms.start(kernel_ms != nullptr, s));
+        const int64_t* d_off = frame_seg->dev.as<int64_t>();
+        SSP_TRY(feed_rows(ctx, feats, (size_t)gmm->D * sizeof(float), fcut, [&](int i, void* dev) -> int {
+            const int64_t u0 = ucut[(size_t)i], u1 = ucut[(size_t)i + 1];
+            if (ho[(size_t)u1] == ho[(size_t)u0] && !d_sc && !d_am) return SSP_OK;
+            // (the slot holds frames [ho[u0], ho[u1]); score_fused addresses with the batch's absolute offsets: the pointer is biased)
+            const float* biased = static_cast<const float*>(dev) - (size_t)ho[(size_t)u0] * gmm->D;
+            return score_fused(gmm, biased, ho.data() + u0, d_off + u0, u1 - u0, 0, precision != 0, false, d_sc ? d_sc + (size_t)u0 * M : nullptr,
+                               d_am ? d_am + u0 : nullptr, nullptr, s);
+        }));
+        SSP_TRY(tms.stop(s, kernel_ms));
+        SSP_TRY(ssc.back(ctx, scores_out, (size_t)n_utt * M * sizeof(float), where));
+        SSP_TRY(sam.back(ctx, argmax_out, (size_t)n_utt * sizeof(int32_t), where));
+        SSP_HIP(hipStreamSynchronize(s));
+        return SSP_OK;
+    }
     const float* d_feats = (const float*)sin.in(ctx, feats, (size_t)F * gmm->D * sizeof(float), where, &rc);
     SSP_TRY(rc);
     Timer tm;

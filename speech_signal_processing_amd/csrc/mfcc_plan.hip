@@ -696,11 +696,6 @@ static int run_sliced(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const
     return SSP_OK;
 }
 
-static size_t host_slice_bytes() {
-    size_t mb = 64;  // ~1.2 ms of PCIe per slice: long against a launch's host cost, short against the batch (fill + drain = two slices)
-    if (const char* e = getenv("SSP_HOST_SLICE_MB")) mb = (size_t)std::max(1, atoi(e));
-    return mb << 20;
-}
 
 static int mfcc_run_any(ssp_mfcc_plan* plan, const ssp_segments* sample_seg, const ssp_segments* frame_seg, const void* samples, int stype,
                         float* feats_out, int where, int variant, float* kernel_ms) {

@@ -77,6 +77,8 @@ struct HostPipe {
 #endif  // SSP_STAGING_NO_HIP
 }  // namespace ssp
 #elif SSP_STAGING_PART == 2
+#include <algorithm>
+#include <cstdlib>
 namespace ssp {
 // Staging helper for SSP_HOST calls: device copy of a host input / device scratch for an output.
 struct Staged {
@@ -128,5 +130,64 @@ struct Staged {
         return SSP_OK;
     }
 };
+
+// feed_rows — a HOST matrix through the ctx's ring of device slots, copied in ahead of its consumer (the scorers' host-fed batches: the
+// rows of slice i + 1 and i + 2 cross PCIe on the copy stream while `consume` has slice i's kernels on the ctx stream).  `cuts`: row
+// indices 0 = c0 < c1 < ... < cn of the slices; consume(i, dev) launches slice i's work on ctx->stream, dev = device copy of rows
+// [cuts[i], cuts[i + 1]).  The host waits for slice i's kernels before it issues the copy that reuses a slot (and consumers may
+// therefore reuse host-side tables they upload per slice); on an error everything in flight is drained before it goes up.
+template <class F>
+static int feed_rows(ssp_ctx* ctx, const void* host, size_t row_bytes, const std::vector<int64_t>& cuts, F&& consume) {
+    const int n = (int)cuts.size() - 1;
+    if (n <= 0) return SSP_OK;
+    if (!ctx->pipe) {
+        ctx->pipe = new (std::nothrow) HostPipe;
+        if (!ctx->pipe) SSP_FAIL(SSP_ERR_NOMEM, "host alloc (pipeline)");
+    }
+    HostPipe& hp = *ctx->pipe;
+    SSP_TRY(hp.init());
+    hipStream_t cs = ctx->stream;
+    size_t max_bytes = 0;
+    for (int i = 0; i < n; ++i) max_bytes = std::max(max_bytes, (size_t)(cuts[(size_t)i + 1] - cuts[(size_t)i]) * row_bytes);
+    bool grow = false;
+    for (int k = 0; k < HostPipe::RING; ++k) grow = grow || hp.in[k].bytes < max_bytes + 256;
+    if (grow) {  // (a slot that has to grow may still be read by work of an earlier call: everything is drained first)
+        SSP_HIP(hipStreamSynchronize(cs));
+        SSP_HIP(hipStreamSynchronize(hp.h2d));
+        SSP_HIP(hipStreamSynchronize(hp.d2h));
+        for (int k = 0; k < HostPipe::RING; ++k) SSP_TRY(hp.in[k].reserve(max_bytes + 256));
+    }
+    auto body = [&]() -> int {
+        auto issue = [&](int i) -> int {
+            const int k = i % HostPipe::RING;
+            SSP_HIP(hipMemcpyAsync(hp.in[k].p, static_cast<const char*>(host) + (size_t)cuts[(size_t)i] * row_bytes,
+                                   (size_t)(cuts[(size_t)i + 1] - cuts[(size_t)i]) * row_bytes, hipMemcpyHostToDevice, hp.h2d));
+            SSP_HIP(hipEventRecord(hp.in_ready[k], hp.h2d));
+            return SSP_OK;
+        };
+        SSP_HIP(hipEventRecord(hp.computed[0], cs));   // the copy stream starts behind what the ctx stream holds (the slots' last readers)
+        SSP_HIP(hipStreamWaitEvent(hp.h2d, hp.computed[0], 0));
+        for (int i = 0; i < n && i < HostPipe::RING - 1; ++i) SSP_TRY(issue(i));
+        for (int i = 0; i < n; ++i) {
+            if (i + HostPipe::RING - 1 < n) SSP_TRY(issue(i + HostPipe::RING - 1));   // its slot's last reader was slice i - 1: waited for below
+            SSP_HIP(hipStreamWaitEvent(cs, hp.in_ready[i % HostPipe::RING], 0));
+            SSP_TRY(consume(i, hp.in[i % HostPipe::RING].p));
+            SSP_HIP(hipStreamSynchronize(cs));
+        }
+        return SSP_OK;
+    };
+    const int rc = body();
+    if (rc != SSP_OK) {
+        (void)hipStreamSynchronize(cs);
+        (void)hipStreamSynchronize(hp.h2d);
+    }
+    return rc;
+}
+
+static inline size_t host_slice_bytes() {
+    size_t mb = 64;  // ~1.2 ms of PCIe per slice: long against a launch's host cost, short against the batch (fill + drain = two slices)
+    if (const char* e = getenv("SSP_HOST_SLICE_MB")) mb = (size_t)std::max(1, atoi(e));
+    return mb << 20;
+}
 }  // namespace ssp
 #endif

@@ -2431,3 +2431,52 @@ def test_two_contexts_on_two_threads_through_the_host_paths(ssp, monkeypatch):
                 assert np.array_equal(x, y, equal_nan=True)
             else:
                 assert x == y
+
+
+def test_host_fed_scorers_slice_and_equal_the_device_path(ssp, monkeypatch):
+    """Host-fed GMM scoring (precision 0 / 2) and cosine arg-min batches above two slices go through the ctx's ring — rows copied in ahead
+    of the kernels that score them (feed_rows) — in runs of whole utterances / rows: with 1-MiB slices a 50-MB batch is ~50 slices.  Bits
+    must equal the one-piece device-pointer path; empty utterances, an utterance longer than a slice, arg-max-only calls."""
+    import torch
+    pkg, api = ssp
+    monkeypatch.setenv("SSP_HOST_SLICE_MB", "1")
+    rng = np.random.default_rng(31)
+    K, D, S = 32, 39, 10
+    w, mu, cov = rng.dirichlet(5 * np.ones(K)), rng.standard_normal((K, D)), rng.uniform(0.5, 2.0, (K, D))
+    mus = np.stack([mu] + [mu + 0.2 * rng.standard_normal((K, D)) for _ in range(S)])
+    lens = [int(v) for v in rng.integers(0, 300, 3000)]
+    lens[5], lens[6], lens[100] = 0, 0, 20000                       # empty utterances; 20000 x 39 x 4 B = 3 MB > the slice
+    X = rng.standard_normal((sum(lens), D)).astype(np.float32)
+    assert X.nbytes > 2 * (1 << 20)
+    hctx, tctx = api.default_context(), api.default_context(torch_stream=True)
+    hsc = api.GmmScorer(hctx, np.stack([w] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
+    tsc = api.GmmScorer(tctx, np.stack([w] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
+    hseg, tseg = api.Segments.from_lengths(hctx, lens), api.Segments.from_lengths(tctx, lens)
+    Xd = torch.from_numpy(X).cuda()
+    nz = np.asarray(lens) > 0
+    for prec in (0, 2):
+        want = tsc.score(Xd, tseg, precision=prec)
+        got = hsc.score(X, hseg, precision=prec)
+        assert np.array_equal(got["scores"][nz], want["scores"].cpu().numpy()[nz], equal_nan=True), prec
+        assert np.array_equal(got["argmax"][nz], want["argmax"].cpu().numpy()[nz]), prec
+        only = hsc.score(X, hseg, precision=prec, scores=False)
+        assert "scores" not in only and np.array_equal(only["argmax"][nz], want["argmax"].cpu().numpy()[nz])
+        again = hsc.score(X, hseg, precision=prec)                   # (the ring's slots and events, reused)
+        assert np.array_equal(again["scores"][nz], got["scores"][nz], equal_nan=True)
+    # the re-scoring precisions and score_samples requests stage the batch whole, as before
+    r1 = hsc.score(X, hseg, precision=1)
+    assert np.array_equal(r1["argmax"][nz], tsc.score(Xd, tseg, precision=0)["argmax"].cpu().numpy()[nz])
+    # ---- cosine
+    for d, S2 in ((256, 300), (64, 1251), (200, 7)):
+        N = (6 << 20) // (4 * d) + 37
+        Cn = rng.standard_normal((S2, d)).astype(np.float32)
+        Xe = (Cn[rng.integers(0, S2, N)] + 0.8 * rng.standard_normal((N, d))).astype(np.float32)
+        Xe[11] = 0.0                                                  # a zero-norm row: NaN distance rules
+        want = api.cosine_identify(tctx, torch.from_numpy(Xe).cuda(), torch.from_numpy(Cn).cuda())
+        got = api.cosine_identify(hctx, Xe, Cn)
+        assert np.array_equal(got["argmin"], want["argmin"].cpu().numpy()), d
+        assert np.array_equal(got["min"], want["min"].cpu().numpy(), equal_nan=True), d
+        got2 = api.cosine_identify(hctx, Xe, Cn, minval=False)
+        assert "min" not in got2 and np.array_equal(got2["argmin"], got["argmin"])
+        full = api.cosine_identify(hctx, Xe[:2000], Cn, dist=True)     # the distance matrix: one piece
+        assert np.array_equal(full["argmin"], got["argmin"][:2000])

@@ -367,3 +367,21 @@ def test_staging_pool_under_thread_sanitizer(tmp_path):
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
     assert "ownership errors 0" in r.stdout
+
+
+def test_flatten_signals_keeps_int16_pcm():
+    """api.flatten_signals (what every reference-shaped extractor feeds the device from): a list whose utterances are ALL int16 PCM stays
+    int16 (ssp_mfcc_run_i16 widens on the device: half the PCIe bytes, no host pass); anything else becomes float32 as before."""
+    from speech_signal_processing_amd import api
+    rng = np.random.default_rng(0)
+    a, b = (rng.integers(-3000, 3000, 1000)).astype(np.int16), (rng.integers(-3000, 3000, 777)).astype(np.int16)
+    flat, lens = api.flatten_signals([a, b.reshape(-1, 1)])
+    assert flat.dtype == np.int16 and lens == [1000, 777] and np.array_equal(flat, np.concatenate([a, b]))
+    one, lens1 = api.flatten_signals([a])
+    assert one.dtype == np.int16 and lens1 == [1000] and np.shares_memory(one, a)            # a single utterance: no copy at all
+    flat, lens = api.flatten_signals([a, b.astype(np.float64)])                                  # mixed: float32, the integer VALUES (no 1/32768)
+    assert flat.dtype == np.float32 and lens == [1000, 777] and np.array_equal(flat[:1000], a.astype(np.float32))
+    flat, lens = api.flatten_signals([])
+    assert flat.dtype == np.float32 and flat.shape == (0,) and lens == []
+    flat, lens = api.flatten_signals([np.zeros(0, np.int16), a])
+    assert flat.dtype == np.int16 and lens == [0, 1000]

@@ -3,7 +3,9 @@ the sliced copy-in / compute / copy-back pipeline of ssp_mfcc_run(SSP_HOST) with
 call), float32 and int16 input (ssp_mfcc_run_i16: device-side widening), pinned and pageable memory, every dialect and every kernel
 variant the plan has.  The sliced path launches the batch's work table in utterance ranges with data pointers biased by each slice's
 first offsets: any kernel that addressed samples or rows other than through the batch's absolute offsets would differ here.  Bits must
-be EQUAL (the work table is the same on both sides).  Run on the GPU box:
+be EQUAL (the work table is the same on both sides).  Every case also feeds the GMM scorer (precision 0 / 2) and the cosine scorer from
+host arrays (feed_rows: rows through the same ring, ahead of the kernels) and compares with the device-pointer path, bit for bit.
+Run on the GPU box:
     python tools/fuzz_hostfed.py [seed] [cases]"""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
@@ -72,6 +74,31 @@ for case in range(n_cases):
         # int16 through device pointers (widened slice by slice on the device)
         got = tplan.run(torch.from_numpy(x16).cuda(), tseg, tfseg, variant=variant).cpu().numpy()
         assert np.array_equal(got, want, equal_nan=True), (case, dialect, variant, "i16 device")
-    print("case %d: %s, %d utterances / %.1f MB, slice %d MiB (%s), variants %s" % (case, dialect, n_utt, total * 4 / 1e6, slice_mb,
-                                                                                  "sliced" if sliced else "whole", variants), flush=True)
+    # ---- the scorers fed from the host (feed_rows: rows copied in ahead of the kernels that score them) against the device-pointer path
+    K, D, S = int(rng.choice([8, 32, 64])), int(rng.choice([13, 26, 39])), int(rng.integers(2, 20))
+    w, mu, cov = rng.dirichlet(5 * np.ones(K)), rng.standard_normal((K, D)), rng.uniform(0.5, 2.0, (K, D))
+    mus = np.stack([mu] + [mu + 0.3 * rng.standard_normal((K, D)) for _ in range(S)])
+    n_g = int(rng.integers(500, 6000))
+    glens = [int(v) for v in np.where(rng.random(n_g) < 0.03, 0, rng.integers(1, 400, n_g))]   # (3 % empty utterances)
+    if rng.random() < 0.3 and glens:
+        glens[int(rng.integers(0, len(glens)))] = int(rng.integers(20000, 60000))      # an utterance longer than a slice
+    F = int(np.sum(glens))
+    Xg = rng.standard_normal((F, D)).astype(np.float32)
+    hsc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
+    tsc = api.GmmScorer(tctx, np.stack([w] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
+    hs, ts = api.Segments.from_lengths(ctx, glens), api.Segments.from_lengths(tctx, glens)
+    nz = np.asarray(glens) > 0
+    Xgd = torch.from_numpy(Xg).cuda()
+    for prec in (0, 2):
+        want, got = tsc.score(Xgd, ts, precision=prec), hsc.score(Xg, hs, precision=prec)
+        assert np.array_equal(got["scores"][nz], want["scores"].cpu().numpy()[nz], equal_nan=True), (case, "gmm host-fed scores", prec, K, D, S, len(glens))
+        assert np.array_equal(got["argmax"][nz], want["argmax"].cpu().numpy()[nz]), (case, "gmm host-fed arg-max", prec)
+    dd, Sc = int(rng.choice([64, 128, 200, 256])), int(rng.integers(2, 1500))
+    Nc = int(rng.integers(20000, 120000))
+    Cn = rng.standard_normal((Sc, dd)).astype(np.float32)
+    Xc = (Cn[rng.integers(0, Sc, Nc)] + float(10.0 ** rng.uniform(-1, 1)) * rng.standard_normal((Nc, dd))).astype(np.float32)
+    want, got = api.cosine_identify(tctx, torch.from_numpy(Xc).cuda(), torch.from_numpy(Cn).cuda()), api.cosine_identify(ctx, Xc, Cn)
+    assert np.array_equal(got["argmin"], want["argmin"].cpu().numpy()) and np.array_equal(got["min"], want["min"].cpu().numpy(), equal_nan=True), (case, "cosine host-fed", Nc, Sc, dd)
+    print("case %d: %s, %d utterances / %.1f MB, slice %d MiB (%s), variants %s; gmm %d utt / %.1f MB K %d D %d S %d; cosine %d x %d x %d (%.1f MB)" % (
+        case, dialect, n_utt, total * 4 / 1e6, slice_mb, "sliced" if sliced else "whole", variants, len(glens), Xg.nbytes / 1e6, K, D, S, Nc, Sc, dd, Xc.nbytes / 1e6), flush=True)
 print("fuzz_hostfed OK: %d cases (%d through the sliced pipeline), %.1f s" % (n_cases, n_sliced, time.time() - t_start))
