@@ -11,7 +11,10 @@
  *     thread-local message for the last failure on the calling thread.  Nothing aborts.
  *   - `where` = SSP_HOST (0): bulk arrays are host pointers, the library stages them through
  *     device scratch the ctx keeps between calls (up to 8 buffers of at most 64 MiB; larger
- *     operands get a buffer of their own for the call);  SSP_DEVICE (1): bulk arrays are
+ *     operands get a buffer of their own for the call — except the batches of ssp_mfcc_run(_i16),
+ *     ssp_gmm_score (precision 0 / 2) and ssp_cosine_identify(2) (precision 0, arg-min / minimum)
+ *     above two slices (SSP_HOST_SLICE_MB, 64 MiB): those go through a ring of three slice-sized
+ *     slots, copied in ahead of the kernels that consume them);  SSP_DEVICE (1): bulk arrays are
  *     device pointers on the ctx's device.
  *   - segment offsets (per-utterance sample / frame offsets) are small host-side metadata:
  *     they are always HOST int64 arrays and are uploaded once into an ssp_segments handle.

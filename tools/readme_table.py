@@ -63,6 +63,12 @@ if "gmm_auto" in d:
                  "%.1f ms" % v["kernel_ms"] + ("; " + " / ".join("%.1f" % p["auto"]["kernel_ms"] for p in pts if "auto" in p) + " ms" if pts else ""),
                  "ratio %.2f" % v["ratio_to_best_fixed"] + ("; " + " / ".join("%.2f" % p["auto"]["ratio_to_best_fixed"] for p in pts if "auto" in p) if pts else "")
                  + "; arg-max mismatches against fp32: %d" % v.get("mismatches_vs_fp32", v["argmax_mismatches_vs_fp32_path"])))
+if "gmm_host_fed" in d and "wall_ms" in d["gmm_host_fed"]:
+    v = d["gmm_host_fed"]
+    rows.append(("GMM-UBM scoring HOST-FED (`GMM_UBM.py:181-197` hands host arrays): a quarter of the batch's features in pinned host memory through `ssp_gmm_score(SSP_HOST)`, fp32 path — rows copied in ahead of the kernels that score them",
+                 "%.3g frame-scores/s (%.1f ms wall)" % (v["value"], v["wall_ms"]),
+                 "copy-in %.1f ms + kernels %.1f ms = %.1f ms if staged whole; the longer of the two is %.2f of the wall time; scores bit-equal to the device path: %s" % (
+                     v["copy_in_ms"], v["kernel_ms_device_path"], v["sum_ms"], v["overlap"], v["scores_equal_device_path"])))
 c3 = d["gmm_cfg3_shape"]
 fs = c3.get("bf16x3_full_share")
 rows.append(("configs[3] model shape (K = 512, 1251 speakers + UBM): 12 000 utterances per GPU fp32 / bf16×3" + ("; the FULL per-GPU share (150 000 utterances) on bf16×3, measured" if fs else ""),
@@ -95,6 +101,12 @@ if "cosine_auto" in d:
                  "%.2f ms" % v["kernel_ms"] + ("; " + " / ".join("%.2f" % p["auto"]["kernel_ms"] for p in pts if "auto" in p) + " ms" if pts else ""),
                  "ratio %.2f" % v["ratio_to_best_fixed"] + ("; " + " / ".join("%.2f" % p["auto"]["ratio_to_best_fixed"] for p in pts if "auto" in p) if pts else "")
                  + "; arg-min mismatches against fp32: %d" % v.get("mismatches_vs_fp32", 0)))
+if "cosine_host_fed" in d and "wall_ms" in d["cosine_host_fed"]:
+    v = d["cosine_host_fed"]
+    rows.append(("cosine scoring HOST-FED (`d_vector.py:315-319` hands host arrays): 1e6 × 256 embeddings in pinned host memory through `ssp_cosine_identify(SSP_HOST)`, fp32 path, arg-min + minimum",
+                 "%.2g pair-scores/s (%.1f ms wall)" % (v["value"], v["wall_ms"]),
+                 "copy-in %.1f ms + sweep %.1f ms = %.1f ms if staged whole; the copy is %.2f of the wall time; arg-min equal to the device path: %s" % (
+                     v["copy_in_ms"], v["kernel_ms_device_path"], v["sum_ms"], v["overlap"], v["argmin_equals_device_path"])))
 v = d["dvector_dnn"]
 rows.append(("d-vector network forward 1274→256×4 (one packed object, hidden layers chained in registers), 5e5 embeddings", "%.2g embeddings/s (%.1f ms)" % (v["value"], v["kernel_ms"]), "%.2f of the fp32 MFMA peak" % v["roofline"]["frac"]))
 v = d["dvector_pipeline"]
