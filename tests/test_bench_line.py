@@ -60,6 +60,24 @@ def test_compact_line_of_a_full_result():
         assert k not in line
 
 
+def test_compact_line_of_the_round6_detail():
+    """the full result of the round-6 driver command (profiles/r06_bench_detail.json: every stage incl. the host-fed and precision-auto
+    rows) -> the committed line (profiles/r06_bench_line.json) again, under the limit, every stage summarised"""
+    import bench
+    res = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_detail.json")))
+    text = bench.compact_line(res, "gpurun_out/r06/bench_detail.json")
+    assert len(text.encode()) < bench.LINE_TARGET < bench.LINE_LIMIT
+    line = _strict(text)
+    for k in CONTRACT + ("roofline", "cpu_baseline", "cpu_baseline_parallel", "value_normalised", "build", "detail", "mfcc_host_fed", "gmm_auto", "cosine_auto",
+                         "gmm_host_fed", "cosine_host_fed", "gmm_cfg3_shape", "mfcc_inrepo", "plp", "dtw"):
+        assert k in line, k
+    assert line["roofline"]["traffic"] and 0.95 < line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"] < 1.1
+    assert line["gmm"]["mfma_busy"] > 0.5 and line["cosine"]["mfma_busy"] > 0.5          # quoted: the counters were taken on this source
+    assert line["cpu_baseline_parallel"]["usable_cores"] <= line["cpu_baseline_parallel"]["host_cores"]
+    committed = _strict(open(os.path.join(ROOT, "profiles", "r06_bench_line.json")).read())
+    assert committed["value"] == line["value"] and set(committed) == set(line)
+
+
 def test_compact_line_eight_ranks_and_non_finite_values():
     import bench
     res = _canned()
