@@ -285,8 +285,10 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
         const float* wcur = wbuf + (r & 1) * TILE_FLOATS;
         // tile r+1 streams into the other buffer while this one feeds the MFMAs (the barrier at the end of the
         // iteration drains the LDS-DMA: __syncthreads() waits vmcnt(0))
+#ifndef SSP_GMM_ABL_NODMA  // (ablation, wrong results: every tile computes on the first one's bytes — what issuing the tile stream costs)
         if (r + 1 < n_it)
             stage_tile<NQ>(a.wimg + (size_t)tile_at(r + 1) * TILE_FLOATS, wbuf + ((r + 1) & 1) * TILE_FLOATS, wave, lane);
+#endif
         f32x16 acc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -319,7 +321,11 @@ __global__ __launch_bounds__(256) void gmm_loglik_kernel(GmmArgs a) {
             rt = 0;
             ++model;
         }
+#ifdef SSP_GMM_ABL_NOBARRIER  // ablation (racy, wrong results): what the workgroup barrier per row tile costs (the wave waits for its own DMA only)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         __syncthreads();
+#endif
     }
 }
 
