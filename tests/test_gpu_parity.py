@@ -2480,3 +2480,30 @@ def test_host_fed_scorers_slice_and_equal_the_device_path(ssp, monkeypatch):
         assert "min" not in got2 and np.array_equal(got2["argmin"], got["argmin"])
         full = api.cosine_identify(hctx, Xe[:2000], Cn, dist=True)     # the distance matrix: one piece
         assert np.array_equal(full["argmin"], got["argmin"][:2000])
+
+
+def test_wav_files_to_features_without_a_host_widening_pass(ssp, tmp_path):
+    """The reference's own data flow (GMM_UBM.py:24-50 load_data -> :72-118 extract_feature): int16 wav files read by utils.tools.read
+    (utils/tools.py:45-47) go to the extractors as the int16 arrays they are — the shims hand them to ssp_mfcc_run_i16 (device-side
+    widening) — and the features equal the oracle's recipe on the integer values (sidekit's mfcc does not scale by 1/32768)."""
+    import scipy.io.wavfile as wavfile
+    from speech_signal_processing_amd import GMM_UBM, api
+    from speech_signal_processing_amd.utils import tools
+    from oracle import ref_cpu as O
+    xs = []
+    for u in range(4):
+        pcm = (synth_audio(u, 20000 + 1777 * u, 16000) * 20000).astype(np.int16)
+        wavfile.write(str(tmp_path / ("u%d.wav" % u)), 16000, pcm)
+        fs, x = tools.read(str(tmp_path / ("u%d.wav" % u)))
+        assert fs == 16000 and x.dtype == np.int16 and np.array_equal(x, pcm)
+        xs.append(x)
+    flat, lens = api.flatten_signals(xs)
+    assert flat.dtype == np.int16 and lens == [len(x) for x in xs]               # what the shim passes on: no float copy on the host
+    feats, _ = GMM_UBM.extract_feature(xs, [0, 1, 0, 1])
+    for u in range(4):
+        ref = O.extract_feature_one(xs[u].astype(np.float64))
+        assert feats[u].dtype == np.float64 and feats[u].shape == ref.shape
+        assert_feat_close(feats[u], ref, what="wav %d" % u)
+    one = GMM_UBM.mfcc(xs[0])[0]                                                  # the per-utterance call of GMM_UBM.py:89
+    cfg, w, fb, dct = O.sidekit_tables()
+    assert_feat_close(one, O.mfcc_pipeline(xs[0].astype(np.float64), cfg, w, fb, dct), what="mfcc(int16)")
