@@ -58,3 +58,34 @@ def test_librosa_mfcc_vs_transformers(seed, n):
     assert ours.shape == theirs.shape
     scale = float(np.abs(theirs).max())
     assert np.abs(ours - theirs).max() <= 1e-4 * scale, (np.abs(ours - theirs).max(), scale)
+
+
+@pytest.mark.parametrize("seed,n,nwin", [(4, 16000, 0.025), (5, 48000, 0.025), (6, 7777, 0.025), (7, 16000, 0.018)])
+def test_sidekit_front_end_vs_transformers(seed, n, nwin):
+    """The sidekit dialect's front end as the oracle restates it (GMM_UBM.py:89, d_vector.py:91: frames without padding, floor((N - L) /
+    hop) + 1 of them; per-FRAME pre-emphasis y[0] = x[0] - a x[0], y[n] = x[n] - a x[n - 1]; numpy.hanning; 512-point power spectrum)
+    against `transformers.audio_utils.spectrogram(center=False, preemphasis=0.97, power=2)` — an independent implementation of the same
+    Kaldi-style frame processing — and, with the oracle's own filterbank handed to it, the ln + DCT-II(ortho)[1:14] back end against
+    scipy's DCT.  Corroborates the restatement's frame rule, pre-emphasis, window and transform; the filterbank's integer-bin triangles
+    (sidekit's trfbank) have no independent counterpart here, and none of this pins row a7 to the reference."""
+    from scipy.fft import dct
+    fs = 16000
+    x = _signal(seed, n, fs).astype(np.float64) * 3000.0           # (int16-scale amplitudes: what utils.tools.read hands over)
+    cfg, w, fb, dctm = O.sidekit_tables(fs=fs, nwin=nwin)
+    L, hop, n_fft = cfg["win_len"], cfg["hop"], cfg["n_fft"]
+    # the oracle's power spectrum, step by step as mfcc_pipeline forms it
+    frames = O.frame_matrix(x, cfg)
+    prev = np.concatenate([frames[:, :1], frames[:, :-1]], axis=1)
+    spec = np.fft.rfft((frames - cfg["preemph"] * prev) * w[None, :], n=n_fft, axis=1)
+    P = spec.real ** 2 + spec.imag ** 2
+    theirs = au.spectrogram(x, np.hanning(L), frame_length=L, hop_length=hop, fft_length=n_fft, power=2.0, center=False, preemphasis=0.97,
+                            dtype=np.float64).T
+    assert P.shape == theirs.shape == (O.num_frames(n, cfg), n_fft // 2 + 1)
+    assert np.abs(P - theirs).max() <= 2e-6 * np.abs(theirs).max()      # (their transform runs in complex64: measured 6e-8)
+    # back end: ln(P . fbank^T) -> DCT-II ortho, c0 dropped
+    logmel = au.spectrogram(x, np.hanning(L), frame_length=L, hop_length=hop, fft_length=n_fft, power=2.0, center=False, preemphasis=0.97,
+                            mel_filters=np.asarray(fb, dtype=np.float64).T, mel_floor=1e-300, log_mel="log", dtype=np.float64)
+    ceps_theirs = dct(logmel.T, type=2, norm="ortho", axis=1)[:, 1:14]
+    ours = O.mfcc_pipeline(x, cfg, w, fb, dctm)
+    assert ours.shape == ceps_theirs.shape
+    assert np.abs(ours - ceps_theirs).max() <= 1e-4 * max(1.0, np.abs(ceps_theirs).max())      # (the bar of the librosa check above)
