@@ -89,3 +89,47 @@ def test_sidekit_front_end_vs_transformers(seed, n, nwin):
     ours = O.mfcc_pipeline(x, cfg, w, fb, dctm)
     assert ours.shape == ceps_theirs.shape
     assert np.abs(ours - ceps_theirs).max() <= 1e-4 * max(1.0, np.abs(ceps_theirs).max())      # (the bar of the librosa check above)
+
+
+def test_dense_network_vs_torch():
+    """Row f2 (d_vector.py:171-189: Dense(256, relu) x 3 + Dense(256) on the 1274-d input, `spkModel.predict`): the oracle's restatement of
+    a Keras Dense stack (kernel (d_in, units), y = act(x @ kernel + bias)) against torch.nn.functional.linear in float64 — an independent
+    implementation of the same layer (torch keeps the weight as (units, d_in): the kernel's transpose).  Keras itself is absent."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(12)
+    dims = [1274, 256, 256, 256, 256]
+    layers = [(rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i]), 0.1 * rng.standard_normal(dims[i + 1]), "relu" if i < 3 else None) for i in range(4)]
+    X = rng.standard_normal((64, dims[0]))
+    ours = O.dense_net_forward(X, layers)
+    h = torch.from_numpy(X)
+    for W, b, act in layers:
+        h = torch.nn.functional.linear(h, torch.from_numpy(W).T.contiguous(), torch.from_numpy(b))
+        if act == "relu":
+            h = torch.relu(h)
+    assert np.abs(ours - h.numpy()).max() <= 1e-12 * max(1.0, float(h.abs().max()))
+
+
+def test_dtw_recurrence_vs_plain_recursion():
+    """Row f4 (MFCC_DTW.py:57-108: accelerated_dtw(x, y, 'euclidean') on flattened sequences): the oracle's anti-diagonal numpy sweep of
+    the dtw package's recurrence D[i, j] = |x_i - y_j| + min(D[i-1, j-1], D[i-1, j], D[i, j-1]) against a memoised top-down recursion
+    written from the textbook definition (a different evaluation order, no shared code); the package itself is absent."""
+    import functools
+    rng = np.random.default_rng(13)
+    for n, m in ((1, 1), (1, 7), (9, 1), (13, 29), (40, 40)):
+        x, y = rng.standard_normal(n), rng.standard_normal(m)
+
+        @functools.lru_cache(maxsize=None)
+        def D(i, j):
+            c = abs(x[i] - y[j])
+            if i == 0 and j == 0:
+                return c
+            best = float("inf")
+            if i > 0 and j > 0:
+                best = min(best, D(i - 1, j - 1))
+            if i > 0:
+                best = min(best, D(i - 1, j))
+            if j > 0:
+                best = min(best, D(i, j - 1))
+            return c + best
+        ref = D(n - 1, m - 1)
+        assert abs(O.dtw_distance(x, y) - ref) <= 1e-12 * max(1.0, ref), (n, m)
