@@ -706,110 +706,116 @@ def main():
     # wav files into host arrays, :86-93 feeds them to the extractor).  A configs[1]-shaped batch in PINNED host memory through
     # ssp_mfcc_run(SSP_HOST): sliced copy-in / compute / copy-back pipeline inside the library; wall clock, next to what PCIe gives this box.
     if "hostfed" in stages and rank == 0:
-        n_h = min(n_utt, args.hostfed_utts)
-        hseg = api.Segments.from_lengths(ctx, np.full(n_h, n_samp, dtype=np.int64))
-        hfseg = plan.frame_segments(hseg)
-        pin_in = torch.empty(n_h * n_samp, dtype=torch.float32, pin_memory=True)
-        pin_in.copy_(flat[:n_h * n_samp])
-        pin_out = torch.empty((hfseg.total, plan.d_out), dtype=torch.float32, pin_memory=True)
-        dev_tmp = torch.empty(n_h * n_samp, dtype=torch.float32, device=device)
-        dev_out = torch.empty((hfseg.total, plan.d_out), dtype=torch.float32, device=device)
-        torch.cuda.synchronize()
+        def stage_hostfed():   # (a function: an extra stage that fails — e.g. no page-locked memory to be had on a box — must not take the line with it)
+            n_h = min(n_utt, args.hostfed_utts)
+            hseg = api.Segments.from_lengths(ctx, np.full(n_h, n_samp, dtype=np.int64))
+            hfseg = plan.frame_segments(hseg)
+            pin_in = torch.empty(n_h * n_samp, dtype=torch.float32, pin_memory=True)
+            pin_in.copy_(flat[:n_h * n_samp])
+            pin_out = torch.empty((hfseg.total, plan.d_out), dtype=torch.float32, pin_memory=True)
+            dev_tmp = torch.empty(n_h * n_samp, dtype=torch.float32, device=device)
+            dev_out = torch.empty((hfseg.total, plan.d_out), dtype=torch.float32, device=device)
+            torch.cuda.synchronize()
 
-        def gbs(dst, src, reps=3):
-            ts = []
-            for _ in range(reps):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                dst.copy_(src, non_blocking=True)
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-            return src.numel() * src.element_size() / float(np.median(ts)) / 1e9
-        h2d = gbs(dev_tmp, pin_in)
-        plan.run(dev_tmp, hseg, hfseg, out=dev_out, variant=args.variant)        # the device-pointer result of the same batch
-        d2h = gbs(pin_out, dev_out)
-        torch.cuda.synchronize()
-        in_np, out_np = pin_in.numpy(), pin_out.numpy()
+            def gbs(dst, src, reps=3):
+                ts = []
+                for _ in range(reps):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    dst.copy_(src, non_blocking=True)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                return src.numel() * src.element_size() / float(np.median(ts)) / 1e9
+            h2d = gbs(dev_tmp, pin_in)
+            plan.run(dev_tmp, hseg, hfseg, out=dev_out, variant=args.variant)        # the device-pointer result of the same batch
+            d2h = gbs(pin_out, dev_out)
+            torch.cuda.synchronize()
+            in_np, out_np = pin_in.numpy(), pin_out.numpy()
 
-        def wall(src):
-            ts = []
-            plan.run(src, hseg, hfseg, out=out_np, variant=args.variant)
-            for _ in range(3):
-                t0 = time.perf_counter()
-                plan.run(src, hseg, hfseg, out=out_np, variant=args.variant)     # (a host-pointer call returns when the features are in `out`)
-                ts.append(time.perf_counter() - t0)
-            return float(np.median(ts))
-        out_np[:] = 0
-        w32 = wall(in_np)
-        same32 = bool(torch.equal(torch.from_numpy(out_np).to(device), dev_out))
-        in_b, out_b = n_h * n_samp * 4, int(hfseg.total) * plan.d_out * 4
-        bound32 = max(in_b / (h2d * 1e9), out_b / (d2h * 1e9))                   # PCIe is full duplex: the longer direction bounds the pipeline
-        # int16 PCM (utils/tools.py:45-47): half the bytes in; the device widens
-        a16 = (audio[:n_h] * 20000.0).to(torch.int16).view(-1)
-        pin16 = torch.empty(n_h * n_samp, dtype=torch.int16, pin_memory=True)
-        pin16.copy_(a16)
-        plan.run(a16.float(), hseg, hfseg, out=dev_out, variant=args.variant)
-        torch.cuda.synchronize()
-        out_np[:] = 0
-        w16 = wall(pin16.numpy())
-        same16 = bool(torch.equal(torch.from_numpy(out_np).to(device), dev_out))
-        bound16 = max(in_b / 2 / (h2d * 1e9), out_b / (d2h * 1e9))
-        result["mfcc_host_fed"] = {
-            "metric": "MFCC frames/s, host-fed: a configs[1]-shaped batch in pinned host memory through ssp_mfcc_run(SSP_HOST) — sliced pipeline "
-                      "(copy-in | compute | copy-back on three streams), wall clock of the call; never part of `value`",
-            "value": hfseg.total / w32, "unit": "frames/s", "utterances": n_h, "wall_ms": w32 * 1e3, "dtype": "f32",
-            "h2d_gbs": h2d, "d2h_gbs": d2h, "pcie_bound_ms": bound32 * 1e3, "frac_of_pcie_bound": bound32 / w32,
-            "bits_equal_device_path": same32, "slice_mb": int(os.environ.get("SSP_HOST_SLICE_MB", "64")),
-            "value_i16": hfseg.total / w16, "wall_ms_i16": w16 * 1e3, "pcie_bound_ms_i16": bound16 * 1e3, "frac_of_pcie_bound_i16": bound16 / w16,
-            "bits_equal_device_path_i16": same16, "i16_over_f32": w32 / w16,
-            "bound": "PCIe: max(input bytes / measured pinned H2D rate, feature bytes / measured D2H rate) of this box, this run"}
-        # ---- the same call from PAGEABLE memory (what numpy hands over unless the caller allocates with api.pinned_empty): a fifth of the batch
-        try:
-            n_pg = max(1, n_h // 5)
-            pg_seg = api.Segments.from_lengths(ctx, np.full(n_pg, n_samp, dtype=np.int64))
-            pg_fseg = plan.frame_segments(pg_seg)
-            pg_in = np.array(in_np[:n_pg * n_samp])                 # (a pageable copy)
-            pg_out = np.empty((pg_fseg.total, plan.d_out), dtype=np.float32)
-            plan.run(pg_in, pg_seg, pg_fseg, out=pg_out, variant=args.variant)
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
+            def wall(src):
+                ts = []
+                plan.run(src, hseg, hfseg, out=out_np, variant=args.variant)
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    plan.run(src, hseg, hfseg, out=out_np, variant=args.variant)     # (a host-pointer call returns when the features are in `out`)
+                    ts.append(time.perf_counter() - t0)
+                return float(np.median(ts))
+            out_np[:] = 0
+            w32 = wall(in_np)
+            same32 = bool(torch.equal(torch.from_numpy(out_np).to(device), dev_out))
+            in_b, out_b = n_h * n_samp * 4, int(hfseg.total) * plan.d_out * 4
+            bound32 = max(in_b / (h2d * 1e9), out_b / (d2h * 1e9))                   # PCIe is full duplex: the longer direction bounds the pipeline
+            # int16 PCM (utils/tools.py:45-47): half the bytes in; the device widens
+            a16 = (audio[:n_h] * 20000.0).to(torch.int16).view(-1)
+            pin16 = torch.empty(n_h * n_samp, dtype=torch.int16, pin_memory=True)
+            pin16.copy_(a16)
+            plan.run(a16.float(), hseg, hfseg, out=dev_out, variant=args.variant)
+            torch.cuda.synchronize()
+            out_np[:] = 0
+            w16 = wall(pin16.numpy())
+            same16 = bool(torch.equal(torch.from_numpy(out_np).to(device), dev_out))
+            bound16 = max(in_b / 2 / (h2d * 1e9), out_b / (d2h * 1e9))
+            result["mfcc_host_fed"] = {
+                "metric": "MFCC frames/s, host-fed: a configs[1]-shaped batch in pinned host memory through ssp_mfcc_run(SSP_HOST) — sliced pipeline "
+                          "(copy-in | compute | copy-back on three streams), wall clock of the call; never part of `value`",
+                "value": hfseg.total / w32, "unit": "frames/s", "utterances": n_h, "wall_ms": w32 * 1e3, "dtype": "f32",
+                "h2d_gbs": h2d, "d2h_gbs": d2h, "pcie_bound_ms": bound32 * 1e3, "frac_of_pcie_bound": bound32 / w32,
+                "bits_equal_device_path": same32, "slice_mb": int(os.environ.get("SSP_HOST_SLICE_MB", "64")),
+                "value_i16": hfseg.total / w16, "wall_ms_i16": w16 * 1e3, "pcie_bound_ms_i16": bound16 * 1e3, "frac_of_pcie_bound_i16": bound16 / w16,
+                "bits_equal_device_path_i16": same16, "i16_over_f32": w32 / w16,
+                "bound": "PCIe: max(input bytes / measured pinned H2D rate, feature bytes / measured D2H rate) of this box, this run"}
+            # ---- the same call from PAGEABLE memory (what numpy hands over unless the caller allocates with api.pinned_empty): a fifth of the batch
+            try:
+                n_pg = max(1, n_h // 5)
+                pg_seg = api.Segments.from_lengths(ctx, np.full(n_pg, n_samp, dtype=np.int64))
+                pg_fseg = plan.frame_segments(pg_seg)
+                pg_in = np.array(in_np[:n_pg * n_samp])                 # (a pageable copy)
+                pg_out = np.empty((pg_fseg.total, plan.d_out), dtype=np.float32)
                 plan.run(pg_in, pg_seg, pg_fseg, out=pg_out, variant=args.variant)
-                ts.append(time.perf_counter() - t0)
-            wpg = float(np.median(ts))
-            result["mfcc_host_fed"]["pageable"] = {"utterances": n_pg, "wall_ms": wpg * 1e3, "frames_per_s": pg_fseg.total / wpg,
-                                                   "effective_gbs_in": n_pg * n_samp * 4 / wpg / 1e9,
-                                                   "frac_of_pcie_bound": (bound32 * n_pg / n_h) / wpg}
-            del pg_in, pg_out
-        except Exception as e:
-            result["mfcc_host_fed"]["pageable"] = {"error": repr(e)}
-        # ---- the reference-shaped call itself: GMM_UBM.extract_feature(x, y) (GMM_UBM.py:72-118) on a list of int16 utterances as
-        # utils.tools.read returns them (pageable memory, the shim's own context): list -> flat int16 -> ssp_mfcc_run_i16 -> 26-d scaled
-        # features -> float64 rows per utterance.  Wall clock of the Python call (what a user of the reference's script waits for).
-        try:
-            from speech_signal_processing_amd import GMM_UBM as shim
-            n_s = min(n_h, 2000)
-            xs = [np.array(pin16[i * n_samp:(i + 1) * n_samp].numpy()) for i in range(n_s)]   # (pageable copies, one array per utterance)
-            shim.extract_feature(xs[:50], [0] * 50)
-            ts = []
-            for _ in range(3):
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    plan.run(pg_in, pg_seg, pg_fseg, out=pg_out, variant=args.variant)
+                    ts.append(time.perf_counter() - t0)
+                wpg = float(np.median(ts))
+                result["mfcc_host_fed"]["pageable"] = {"utterances": n_pg, "wall_ms": wpg * 1e3, "frames_per_s": pg_fseg.total / wpg,
+                                                       "effective_gbs_in": n_pg * n_samp * 4 / wpg / 1e9,
+                                                       "frac_of_pcie_bound": (bound32 * n_pg / n_h) / wpg}
+                del pg_in, pg_out
+            except Exception as e:
+                result["mfcc_host_fed"]["pageable"] = {"error": repr(e)}
+            # ---- the reference-shaped call itself: GMM_UBM.extract_feature(x, y) (GMM_UBM.py:72-118) on a list of int16 utterances as
+            # utils.tools.read returns them (pageable memory, the shim's own context): list -> flat int16 -> ssp_mfcc_run_i16 -> 26-d scaled
+            # features -> float64 rows per utterance.  Wall clock of the Python call (what a user of the reference's script waits for).
+            try:
+                from speech_signal_processing_amd import GMM_UBM as shim
+                n_s = min(n_h, 2000)
+                xs = [np.array(pin16[i * n_samp:(i + 1) * n_samp].numpy()) for i in range(n_s)]   # (pageable copies, one array per utterance)
+                shim.extract_feature(xs[:50], [0] * 50)
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    feat, _ = shim.extract_feature(xs, [0] * n_s)
+                    ts.append(time.perf_counter() - t0)
+                ws = float(np.median(ts))
+                fr = int(sum(f.shape[0] for f in feat))
+                xs32 = [x.astype(np.float32) for x in xs]
                 t0 = time.perf_counter()
-                feat, _ = shim.extract_feature(xs, [0] * n_s)
-                ts.append(time.perf_counter() - t0)
-            ws = float(np.median(ts))
-            fr = int(sum(f.shape[0] for f in feat))
-            xs32 = [x.astype(np.float32) for x in xs]
-            t0 = time.perf_counter()
-            shim.extract_feature(xs32, [0] * n_s)
-            ws32 = time.perf_counter() - t0
-            result["mfcc_host_fed"]["extract_feature_shim"] = {
-                "what": "GMM_UBM.extract_feature(list of %d int16 utterances of 3 s, pageable) -> list of (298, 26) float64, wall clock of the Python call" % n_s,
-                "wall_ms": ws * 1e3, "frames_per_s": fr / ws, "utterances": n_s, "wall_ms_float32_input": ws32 * 1e3,
-                "bytes_in": n_s * n_samp * 2, "bytes_out_float64": fr * 26 * 8}
-            del xs, xs32, feat
-        except Exception as e:  # (never lose the bench line to an extra)
-            result["mfcc_host_fed"]["extract_feature_shim"] = {"error": repr(e)}
-        del pin_in, pin_out, dev_tmp, dev_out, pin16, a16, in_np, out_np
+                shim.extract_feature(xs32, [0] * n_s)
+                ws32 = time.perf_counter() - t0
+                result["mfcc_host_fed"]["extract_feature_shim"] = {
+                    "what": "GMM_UBM.extract_feature(list of %d int16 utterances of 3 s, pageable) -> list of (298, 26) float64, wall clock of the Python call" % n_s,
+                    "wall_ms": ws * 1e3, "frames_per_s": fr / ws, "utterances": n_s, "wall_ms_float32_input": ws32 * 1e3,
+                    "bytes_in": n_s * n_samp * 2, "bytes_out_float64": fr * 26 * 8}
+                del xs, xs32, feat
+            except Exception as e:  # (never lose the bench line to an extra)
+                result["mfcc_host_fed"]["extract_feature_shim"] = {"error": repr(e)}
+            del pin_in, pin_out, dev_tmp, dev_out, pin16, a16, in_np, out_np
+
+        try:
+            stage_hostfed()
+        except Exception as e:
+            result.setdefault("mfcc_host_fed", {})["error"] = repr(e)
 
     # ------------------------------------------------------------------ the reference-pinned dialect: in-repo MFCC (utils/processing.py:19-144)
     if "inrepo" in stages:
