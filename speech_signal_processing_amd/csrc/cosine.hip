@@ -491,8 +491,12 @@ struct Cos16Args {
     const __bf16* img;
     int32_t* argmin;
     float* minval;
-    int32_t* list;         // rows the NEXT stage scores again
-    int32_t* count;        // [0] how many
+    uint32_t* mask;        // [ceil(N / 32)] one word per wave: bit r = row 32 w + r of this sweep's input goes to the NEXT stage.  Plain
+                           // stores — until round 6 every wave appended its rows to the list behind one atomic counter, and the
+                           // same-address atomics serialised (23 ns each: a sweep of 12 500 waves took 292 us instead of 40 once a few
+                           // per cent of the rows were close calls); cos_compact_kernel turns the words into the list
+    int32_t* list;         // (cos_compact_kernel's output: rows the next stage scores again)
+    int32_t* count;        // (... [0] how many)
     const int32_t* cflag;  // [0] != 0: a centroid's norm is not a finite positive number (cos_pack16_kernel): every row goes on the list
     int64_t N;
     int32_t d, S, n_tiles;
@@ -500,8 +504,6 @@ struct Cos16Args {
     // later stages of a cascade: the embeddings are X[rows[i]], i < *n_dev (device-side count of the previous stage's list)
     const int32_t* rows;
     const int32_t* n_dev;
-    // a sweep over rows [base, base + N) of a larger array (X / argmin / minval point at row `base`): the ids it lists are base + row
-    int32_t list_base;
     // pilot of precision 3 (auto): also count the rows whose two best cosines are closer than band2b (nullable)
     int32_t* count2;
     float band2b;
@@ -692,13 +694,8 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
     // single centroid there is nothing to confuse
     const bool must = bad || a.cflag[0] != 0 || !(ix > 0.f && ix < INFINITY);
     const bool again = mine && (must || (a.S > 1 && !(b1 - b2 >= a.band2)));
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(again);
-    if (m != 0) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(a.count, __popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (again) a.list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)go + a.list_base;
-    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(again);   // (`mine` holds on lanes 0..31 only: the word's 32 bits)
+    if (lane == 0) a.mask[col0 >> 5] = (uint32_t)m;
     if (a.count2) {   // (wave-uniform: a kernel argument)
         const bool close2 = mine && (must || (a.S > 1 && !(b1 - b2 >= a.band2b)));
         const unsigned long long m2 = __builtin_amdgcn_ballot_w64(close2);
@@ -708,6 +705,55 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
         if (a.argmin) a.argmin[go] = i1;
         if (a.minval) a.minval[go] = fminf(fmaxf(1.0f - b1, 0.0f), 2.0f);
     }
+}
+
+// cos_compact_kernel — the mask words of a sweep (Cos16Args::mask) become the next stage's row list.  One thread per word (32 rows), a
+// workgroup's rows go behind ONE atomic on the counter: N / 8192 atomics per sweep instead of the N / 32 of the waves themselves.  The
+// list is not in row order (workgroups land as they come); its consumers write results by row id, so the order has no effect.
+// in_rows (nullable): the sweep was itself list driven — position p of its input was row in_rows[p]; n_dev (nullable): device-side
+// length of that input.  row_base: the sweep covered rows [row_base, row_base + n_rows) of a larger array.
+__global__ __launch_bounds__(256) void cos_compact_kernel(const uint32_t* __restrict__ mask, int64_t n_rows, const int32_t* n_dev,
+                                                           const int32_t* __restrict__ in_rows, int32_t row_base, int32_t* __restrict__ list,
+                                                           int32_t* count) {
+    __shared__ int wsum[4];
+    __shared__ int wg_base;
+    const int64_t Nn = n_dev ? (int64_t)*n_dev : n_rows;
+    if ((int64_t)blockIdx.x * 256 * 32 >= Nn) return;  // (whole workgroup, before any barrier)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t w = (int64_t)blockIdx.x * 256 + tid;
+    const uint32_t mw = w * 32 < Nn ? mask[w] : 0u;
+    const int c = __builtin_popcount(mw);
+    int incl = c;  // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        incl += lane >= o ? t : 0;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        wg_base = tot > 0 ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    int at = wg_base + incl - c;
+    for (int k = 0; k < wave; ++k) at += wsum[k];
+    uint32_t m = mw;
+    while (m) {
+        const int b = __builtin_ctz(m);
+        m &= m - 1;
+        const int64_t pos = w * 32 + b;
+        list[at++] = in_rows ? in_rows[pos] : (int32_t)pos + row_base;
+    }
+}
+
+static int launch_cos_compact(const uint32_t* mask, int64_t n_rows, const int32_t* n_dev, const int32_t* in_rows, int32_t row_base, int32_t* list,
+                              int32_t* count, hipStream_t s) {
+    const int64_t grid = ceil_div<int64_t>(ceil_div<int64_t>(n_rows, 32), 256);
+    if (grid <= 0) return SSP_OK;
+    hipLaunchKernelGGL(cos_compact_kernel, dim3((unsigned)grid), dim3(256), 0, s, mask, n_rows, n_dev, in_rows, row_base, list, count);
+    SSP_HIP(hipGetLastError());
+    return SSP_OK;
 }
 
 template <int NK, int SPLIT>
@@ -934,7 +980,8 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
     const bool want_auto = precision == 3;
     ctx->cos_auto_choice = -1;
     ctx->cos_auto_pilot_rows = ctx->cos_auto_to_x3 = ctx->cos_auto_to_f32 = 0;
-    if (want_auto && (dist_out || d > 256 || N < COS_AUTO_MIN_ROWS)) {   // the distance matrix / wide embeddings: fp32 only; small calls: launch bound, fp32
+    // the distance matrix / wide embeddings: fp32 only; small calls (an fp32 sweep under ~0.25 ms by the cost model below): launch bound, fp32
+    if (want_auto && (dist_out || d > 256 || N < COS_AUTO_MIN_ROWS || (double)N * d * (7.8e-13 + 1.62e-14 * S) < 0.25e-3)) {
         precision = 0;
         ctx->cos_auto_choice = 0;
     }
@@ -1012,8 +1059,12 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
         DevBuf &img16 = ctx->cos_img16, &list1 = ctx->cos_list1, &list2 = ctx->cos_list2, &count = ctx->cos_count;
         SSP_TRY(img16.reserve((size_t)n_tiles * nk * 2048));
         SSP_TRY(img.reserve((size_t)n_tiles * nq * 256 * sizeof(float)));
-        SSP_TRY(list2.reserve((size_t)N * sizeof(int32_t)));
-        if (precision >= 2) SSP_TRY(list1.reserve((size_t)N * sizeof(int32_t)));
+        // a list of up to N rows + the mask words of the sweep that fills it (one per 32 rows, whole 128-row workgroups) behind it
+        const size_t n_words = (size_t)ceil_div<int64_t>(N, 128) * 4, list_ints = (size_t)N + n_words + 64;
+        SSP_TRY(list2.reserve(list_ints * sizeof(int32_t)));
+        if (precision >= 2) SSP_TRY(list1.reserve(list_ints * sizeof(int32_t)));
+        uint32_t* mask2 = reinterpret_cast<uint32_t*>(list2.as<int32_t>() + N);
+        uint32_t* mask1 = precision >= 2 ? reinterpret_cast<uint32_t*>(list1.as<int32_t>() + N) : nullptr;
         SSP_TRY(count.reserve(4 * sizeof(int32_t)));  // [0] rows for the bf16 x 3 sweep (precision 2), [1] rows for fp32, [2] centroid flag
         int32_t* cnt = count.as<int32_t>();
         SSP_TRY(tm.start(kernel_ms != nullptr, s));
@@ -1027,56 +1078,64 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
             // ---- precision 3 (auto).  The pilot IS the first round of the cascade's first stage: the bf16 sweep over the first rows (one
             // machine-filling round of waves, so it costs its share of the full sweep and nothing more), listing its close calls as the
             // full sweep would and counting beside them the rows closer than the bf16 x 3 band (an estimate of what that sweep would hand
-            // to fp32: a call that close at bf16 accuracy is, with few exceptions, that close at any).  One host wait, then — in units of
-            // the fp32 sweep (bench `cosine_close_calls`: bf16 sweep 0.165, bf16 x 3 sweep 0.30; a listed row costs ~1.8 x its share of
-            // a dense sweep: rows are gathered through the list) —
-            //   cascade = 0.165 + 1.8 (0.30 f1 + f2) | bf16 x 3 = 0.30 + 1.8 f2 | fp32 = 1:  the smallest wins (ties and near-ties to the cascade).
-            // The cascade (the usual winner) continues with the remaining rows of its first stage: nothing the pilot did is thrown away.
+            // to fp32: a call that close at bf16 accuracy is, with few exceptions, that close at any).  One host wait, then the cost model
+            // below prices the three ways on; the smallest wins (near-ties to the cascade: it continues with the remaining rows of its
+            // first stage — nothing the pilot did is thrown away — while the other two start over).
             int64_t n_p = std::min<int64_t>((int64_t)ctx->num_cu * 12 * 32, std::max<int64_t>(2048, N / 8));
             if (const char* e = getenv("SSP_COS_AUTO_PILOT")) n_p = std::max<int64_t>(1, atoll(e));
-            n_p = std::min(n_p, N);
-            Cos16Args p1{dX, img16.as<__bf16>(), dA, dM, list1.as<int32_t>(), cnt, cnt + 2, n_p, d, S, n_tiles, 2.0f * cos_band1(d), nullptr, nullptr};
+            n_p = std::min(n_p, N) & ~(int64_t)127;   // (whole workgroups: the sweep behind the pilot starts on a mask-word boundary)
+            Cos16Args p1{dX, img16.as<__bf16>(), dA, dM, mask1, list1.as<int32_t>(), cnt, cnt + 2, n_p, d, S, n_tiles, 2.0f * cos_band1(d), nullptr, nullptr};
             p1.count2 = cnt + 3;
             p1.band2b = 2.0f * cos_band(d);
             SSP_TRY(launch_cos16_nk<1>(nk, p1, s));
+            SSP_TRY(launch_cos_compact(mask1, n_p, nullptr, nullptr, 0, list1.as<int32_t>(), cnt, s));   // (its count is what the host reads)
             if (!ctx->pinned_words) SSP_HIP(hipHostMalloc((void**)&ctx->pinned_words, 64, hipHostMallocDefault));   // (pinned: the 16-byte read-back is a plain DMA)
             int32_t* h = ctx->pinned_words;
             SSP_HIP(hipMemcpyAsync(h, count.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             SSP_HIP(hipStreamSynchronize(s));
             const float f1 = (float)h[0] / (float)n_p, f2 = (float)h[3] / (float)n_p;
-            const float casc = 0.165f + 1.8f * (0.30f * f1 + f2), x3 = 0.30f + 1.8f * f2;
+            // cost model (seconds; fitted to tools/auto_sweep.py's grid after the lists moved to mask words + compaction): a sweep over n
+            // rows costs n d (A + B S) — A: reading and normalising a row, B: the products per centroid (fp32 / bf16 x 3 / bf16 MFMA) —, a
+            // LIST-driven sweep pays the row term twice (rows gathered through the list, 32 to a wave, partly filled)
+            const double e = (double)N * d, A = 7.8e-13, B32 = 1.62e-14, BX3 = 4.55e-15, B16 = 1.74e-15;
+            const double again32 = f2 * e * (2 * A + B32 * S);
+            const double t32 = e * (A + B32 * S), tx3 = e * (A + BX3 * S) + again32, tcasc = e * (A + B16 * S) + f1 * e * (2 * A + BX3 * S) + again32;
             // (the cascade keeps the pilot's rows, the other two start over: it is taken unless the prediction says it loses clearly)
-            precision = (casc <= 1.25f * x3 && casc < 0.95f) ? 2 : (x3 < 0.95f ? 1 : 0);
+            precision = (tcasc <= 1.1 * std::min(tx3, t32)) ? 2 : (tx3 < 0.95 * t32 ? 1 : 0);
             // (a non-finite centroid makes the sweep list every row: f1 = f2 = 1 and the fp32 sweep is chosen)
             ctx->cos_auto_choice = precision;
             ctx->cos_auto_pilot_rows = (int32_t)n_p;
             ctx->cos_auto_to_x3 = h[0];
             ctx->cos_auto_to_f32 = h[3];
-            if (precision == 2) done1 = n_p;                                   // the list and its count stand: the sweep goes on behind them
-            else SSP_HIP(hipMemsetAsync(count.p, 0, 2 * sizeof(int32_t), s));   // (the centroid flag at [2] stays)
+            if (precision == 2) done1 = n_p;                                   // the pilot's mask words stand: the sweep goes on behind them
+            SSP_HIP(hipMemsetAsync(count.p, 0, 2 * sizeof(int32_t), s));        // (the lists are compacted afresh; the centroid flag at [2] stays)
         }
         if (precision >= 1) {
-            Cos16Args c3{dX, img16.as<__bf16>(), dA, dM, list2.as<int32_t>(), cnt + 1, cnt + 2, N, d, S, n_tiles, 2.0f * cos_band(d), nullptr, nullptr};
+            Cos16Args c3{dX, img16.as<__bf16>(), dA, dM, mask2, list2.as<int32_t>(), cnt + 1, cnt + 2, N, d, S, n_tiles, 2.0f * cos_band(d), nullptr, nullptr};
             CosRegArgs ra{dX, img.as<float>(), nullptr, 0, nullptr, dA, dM, N, d, S, n_tiles};
             ra.rows = list2.as<int32_t>();
             ra.n_dev = cnt + 1;
             if (precision == 2) {
                 Cos16Args c1 = c3;
+                c1.mask = mask1;
                 c1.list = list1.as<int32_t>();
                 c1.count = cnt;
                 c1.band2 = 2.0f * cos_band1(d);
-                if (done1 > 0) {   // (precision 3: rows [0, done1) were the pilot)
+                if (done1 > 0) {   // (precision 3: rows [0, done1) were the pilot; its mask words are words [0, done1 / 32))
                     c1.X = dX + (size_t)done1 * d;
                     c1.argmin = dA ? dA + done1 : nullptr;
                     c1.minval = dM ? dM + done1 : nullptr;
                     c1.N = N - done1;
-                    c1.list_base = (int32_t)done1;
+                    c1.mask = mask1 + done1 / 32;
                 }
                 if (c1.N > 0) SSP_TRY(launch_cos16_nk<1>(nk, c1, s));
+                SSP_TRY(launch_cos_compact(mask1, N, nullptr, nullptr, 0, list1.as<int32_t>(), cnt, s));
                 c3.rows = list1.as<int32_t>();
                 c3.n_dev = cnt;
             }
             SSP_TRY(launch_cos16_nk<3>(nk, c3, s));
+            // (list driven: position p of the sweep's input was row list1[p], *cnt of them)
+            SSP_TRY(launch_cos_compact(mask2, N, precision == 2 ? cnt : nullptr, precision == 2 ? list1.as<int32_t>() : nullptr, 0, list2.as<int32_t>(), cnt + 1, s));
             switch (nq) {
                 case 8: SSP_TRY(launch_cos_reg<8>(ra, s)); break;
                 case 16: SSP_TRY(launch_cos_reg<16>(ra, s)); break;

@@ -2343,7 +2343,7 @@ def test_cosine_precision_auto(ssp):
     ctx = api.default_context(torch_stream=True)
     g = torch.Generator(device="cuda")
     g.manual_seed(5)
-    N, S, d = 60000, 400, 256
+    N, S, d = 300000, 400, 256       # (an fp32 sweep of ~0.6 ms: calls the cost model prices under 0.25 ms run as fp32 without a pilot)
     Cn = torch.randn((S, d), generator=g, device="cuda")
     lab = torch.randint(0, S, (N,), generator=g, device="cuda")
     Z = torch.randn((N, d), generator=g, device="cuda")
@@ -2356,15 +2356,17 @@ def test_cosine_precision_auto(ssp):
         ra = api.cosine_identify(ctx, X, Cx, precision="auto")
         noise = want
         assert ra["auto"]["precision_used"] in want, (noise, ra["auto"])
-        assert ra["auto"]["pilot_rows"] == N // 8      # (the pilot is the first rows of the cascade's first sweep)
+        assert ra["auto"]["pilot_rows"] == (N // 8) & ~127      # (the pilot is the first rows — whole workgroups — of the cascade's first sweep)
         assert torch.equal(ra["argmin"], r0["argmin"]), noise
     Cd = torch.cat([Cn[:200], Cn[:200]])                       # every centroid twice: exact ties on every row
     X = Cn[lab % 200] + 0.5 * Z
     r0 = api.cosine_identify(ctx, X, Cd)
     ra = api.cosine_identify(ctx, X, Cd, precision=3)
-    assert ra["auto"]["precision_used"] == 0 and ra["auto"]["pilot_to_fp32"] == ra["auto"]["pilot_rows"] == N // 8, ra["auto"]
+    assert ra["auto"]["precision_used"] == 0 and ra["auto"]["pilot_to_fp32"] == ra["auto"]["pilot_rows"] == (N // 8) & ~127, ra["auto"]
     assert torch.equal(ra["argmin"], r0["argmin"]) and torch.equal(ra["min"], r0["min"])
     # small calls, wide embeddings and distance-matrix requests run as precision 0 without a pilot
+    r_small = api.cosine_identify(ctx, X[:20000], Cd, precision=3)              # (~0.04 ms of fp32 sweep by the cost model)
+    assert r_small["auto"]["precision_used"] == 0 and r_small["auto"]["pilot_rows"] == 0 and torch.equal(r_small["argmin"], r0["argmin"][:20000])
     rs = api.cosine_identify(ctx, X[:100], Cd, precision=3, dist=True)
     assert rs["auto"]["precision_used"] == 0 and rs["auto"]["pilot_rows"] == 0 and rs["dist"].shape == (100, 400)
     Xn = X[:9000].cpu().numpy()
