@@ -238,7 +238,10 @@ int ssp_gmm_last_rescored(const ssp_gmm* gmm, int32_t* n_out);
  * two ways to get it): precision 1's guarantee scores close calls twice, which costs more than precision 0 once most utterances are
  * close calls.  A pilot — split-precision pass, band and candidate lists on the first ~2 % of the utterances (>= 256) — prices the
  * re-scoring (listed frames x candidate models); the call then runs as precision 1 when that predicts less than the fp32 pass, else as
- * precision 0.  Batches under 1024 utterances and calls that ask for loglik_out run as precision 0.  One extra host wait.
+ * precision 0.  Batches of fewer than ~16 machine-filling rounds of frames (3.1 M at 256 CUs) skip the pilot — it would cost a round of
+ * its own — and decide LATE: the split pass runs on everything and, when re-scoring the close calls it lists would cost more than a
+ * whole fp32 pass, that pass runs instead (at worst 1.33 x the fp32 path).  Batches under 1024 utterances and calls that ask for
+ * loglik_out run as precision 0.  One extra host wait.
  * ssp_gmm_last_auto: what the last such call chose (precision_used; -1: none yet) and saw (predicted_cost: of precision 1, in units of
  * the fp32 pass). */
 int ssp_gmm_last_auto(const ssp_gmm* gmm, int32_t* precision_used, int32_t* pilot_utts, int32_t* pilot_listed, float* predicted_cost);

@@ -814,6 +814,7 @@ struct ssp_gmm {
     // precision = 4 (auto): what the pilot of the last such call saw and chose
     int32_t auto_choice = -1, auto_pilot_utts = 0, auto_pilot_listed = 0;
     float auto_predicted = 0.f;  // predicted cost of the proven-band split path, in units of the fp32 path's
+    bool auto_late = false;      // precision 4 on a batch too small for a pilot: the split pass runs, the re-scoring is priced from the FULL lists
 };
 
 using namespace ssp;
@@ -1119,10 +1120,20 @@ static int gmm_auto_choice(ssp_gmm* gmm, const float* d_feats, const ssp_segment
     const int M = gmm->n_models;
     gmm->auto_pilot_utts = gmm->auto_pilot_listed = 0;
     gmm->auto_predicted = 0.f;
+    gmm->auto_late = false;
     *choice = 0;
     if (gmm->nk16 == 0 || n_utt < AUTO_MIN_UTTS) return SSP_OK;       // no split kernels for this D / tiny batch
     if (gmm->has_ubm + 1 >= M) {                                         // one speaker model: nothing to confuse, the split path needs no re-scoring
         *choice = 1;
+        return SSP_OK;
+    }
+    // A pilot costs at least one machine-filling round of the split kernel however few utterances it holds; on a batch of a few rounds
+    // that is a large share of the pass (measured 17 % at 2 000 utterances, K = 512).  Such batches run the split pass on everything and
+    // decide LATE, from the full close-call lists the precision-1 flow reads back anyway: when re-scoring them would cost more than a
+    // whole fp32 pass, that pass runs instead (bounded at 1.33 x the fp32 path in the worst case, nothing extra in the usual one).
+    if (frame_seg->total() < (int64_t)16 * gmm->ctx->num_cu * 3 * 256) {
+        *choice = 1;
+        gmm->auto_late = true;
         return SSP_OK;
     }
     int64_t n_p = std::max<int64_t>(256, n_utt / 50);
@@ -1196,6 +1207,7 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
                                   "whichever a pilot on the first utterances predicts to be faster)");
     if (precision != 0 && precision != 4 && gmm->nk16 == 0) SSP_FAIL(SSP_ERR_UNSUPPORTED, "ssp_gmm_score: bf16x3 path covers D <= 64");
     const bool want_auto = precision == 4;
+    gmm->auto_late = false;
     if (want_auto) precision = 0;   // (until the pilot has spoken; score_samples requests — loglik_out — stay on the parity path)
     gmm->auto_choice = -1;
     if (kernel_ms) *kernel_ms = 0.f;
@@ -1330,6 +1342,29 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
                 SSP_HIP(hipMemcpyAsync(gmm->sub_list_host.data(), gmm->flag_list.p, (size_t)n_flag * sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 SSP_HIP(hipMemcpyAsync(gmm->cand_host.data(), gmm->cand.p, (size_t)n_flag * GMM_CAND * sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 SSP_HIP(hipStreamSynchronize(s));
+                if (gmm->auto_late) {   // precision 4, small batch: is re-scoring these lists dearer than the fp32 pass itself?
+                    double work = 0.0, work_all = 0.0;
+                    for (int32_t i = 0; i < n_flag; ++i) {
+                        const int32_t u = gmm->sub_list_host[(size_t)i];
+                        const double T = (double)(frame_seg->host[(size_t)u + 1] - frame_seg->host[(size_t)u]);
+                        const int32_t c0 = gmm->cand_host[(size_t)i * GMM_CAND];
+                        if (c0 < 0) work_all += T * M;
+                        else work += T * (double)c0;
+                    }
+                    const double total = (double)std::max<int64_t>(F, 1) * M;
+                    const float again = (float)((AUTO_RESCORE_LISTS * work + AUTO_RESCORE_ALL * work_all) / total);
+                    gmm->auto_pilot_utts = (int32_t)n_utt;
+                    gmm->auto_pilot_listed = n_flag;
+                    gmm->auto_predicted = AUTO_SPLIT + again;
+                    if (again >= 1.0f) {   // the whole batch on the fp32 path: every row and the arg-max are precision 0's
+                        gmm->auto_choice = 0;
+                        gmm->last_rescored = 0;
+                        SSP_TRY(score_fused(gmm, d_feats, frame_seg->host.data(), frame_seg->dev.as<int64_t>(), n_utt, frame_seg->serial, false, false,
+                                            d_sc, d_am, nullptr, s));
+                        n_flag = 0;
+                    }
+                }
+                if (n_flag > 0) {
                 gmm->sub_off_host.resize((size_t)n_flag + 1);
                 gmm->sub_off_host[0] = 0;
                 for (int32_t i = 0; i < n_flag; ++i) {
@@ -1388,6 +1423,7 @@ int ssp_gmm_score(ssp_gmm* gmm, const float* feats, const ssp_segments* frame_se
                 hipLaunchKernelGGL(gmm_scatter_cand_kernel, dim3((unsigned)n_flag), dim3(64), 0, s, gmm->flag_list.as<int32_t>(),
                                    gmm->cand.as<int32_t>(), M, gmm->has_ubm, sub_sc, gmm->sub_argmax.as<int32_t>(), d_sc, d_am, used_lists ? 0 : 1);
                 SSP_HIP(hipGetLastError());
+                }  // (n_flag > 0 after the late decision)
             }
         }
     } else {

@@ -2296,42 +2296,52 @@ def test_sliced_host_pipeline_equals_the_device_path(ssp, dialect, monkeypatch):
 # ----------------------------------------------------------------------------------------- precision "auto" of the split-precision scorers
 def test_gmm_precision_auto_picks_the_cheaper_path_and_keeps_the_argmax(ssp):
     """ssp_gmm_score precision 4: the proven-band guarantee must never cost more than the path it replaces.  Well-separated speaker
-    models (0.3 std): few close calls -> the pilot keeps the split path; models on top of the UBM (1e-4 std): every utterance is a
-    close call -> fp32.  Arg-max equal to the fp32 path's on every utterance either way; small batches and score_samples requests
-    run as precision 0."""
+    models (0.3 std): few close calls -> the split path; models on top of the UBM (1e-4 std): every utterance is a close call -> fp32.
+    Large batches decide from a PILOT on 2 % of the utterances, batches of a few machine rounds LATE, from the full close-call lists of
+    the split pass (a pilot would cost a round of its own).  Arg-max equal to the fp32 path's on every utterance either way; tiny
+    batches and score_samples requests run as precision 0."""
     import torch
     pkg, api = ssp
     ctx = api.default_context(torch_stream=True)
     rng = np.random.default_rng(4)
-    K, D, S, U, T = 32, 39, 20, 4000, 60
+    K, D, S, T = 32, 39, 20, 60
     w = rng.dirichlet(5 * np.ones(K))
     mu = rng.standard_normal((K, D))
     cov = rng.uniform(0.5, 2.0, (K, D))
-    X = torch.from_numpy(rng.standard_normal((U * T, D)).astype(np.float32)).cuda()
-    seg = api.Segments.from_lengths(ctx, [T] * U)
-    for off, want in ((0.3, 1), (1e-4, 0)):
-        mus = np.stack([mu] + [mu + off * np.sqrt(cov) * rng.standard_normal((K, D)) for _ in range(S)])
-        sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
-        assert sc.last_auto["precision_used"] == -1
-        r0 = sc.score(X, seg, precision=0)
-        ra = sc.score(X, seg, precision="auto")
-        info = sc.last_auto
-        assert info["precision_used"] == want, (off, info)
-        assert info["pilot_utterances"] == 256 and 0 <= info["pilot_listed"] <= 256
-        assert (ra["argmax"] == r0["argmax"]).all(), off
-        if want == 0:
-            assert torch.equal(ra["scores"], r0["scores"]) and sc.last_rescored == 0
-        else:
-            assert float((ra["scores"] - r0["scores"]).abs().max()) <= 1e-4 * float(r0["scores"].abs().max())
-        # a small batch: fp32 without a pilot; score_samples: the parity path
-        small = api.Segments.from_lengths(ctx, [T] * 100)
-        rs = sc.score(X[:100 * T], small, precision=4)
-        assert sc.last_auto["precision_used"] == 0 and sc.last_auto["pilot_utterances"] == 0
-        assert torch.equal(rs["scores"], sc.score(X[:100 * T], small, precision=0)["scores"])
-        rl = sc.score(X[:100 * T], small, precision=4, loglik=True)
-        assert rl["loglik"].shape == (S + 1, 100 * T)
+    U_big = 56000                                      # 3.36e6 frames: above 16 rounds of 768 workgroups x 256 frames -> pilot
+    g = torch.Generator(device="cuda").manual_seed(4)
+    Xbig = torch.randn((U_big * T, D), generator=g, device="cuda")
+    for U, mode in ((4000, "late"), (U_big, "pilot")):
+        X = Xbig[:U * T]
+        seg = api.Segments.from_lengths(ctx, [T] * U)
+        for off, want in ((0.3, 1), (1e-4, 0)):
+            mus = np.stack([mu] + [mu + off * np.sqrt(cov) * rng.standard_normal((K, D)) for _ in range(S)])
+            sc = api.GmmScorer(ctx, np.stack([w] * (S + 1)), mus, np.stack([cov] * (S + 1)), has_ubm=True)
+            assert sc.last_auto["precision_used"] == -1
+            r0 = sc.score(X, seg, precision=0)
+            ra = sc.score(X, seg, precision="auto")
+            info = sc.last_auto
+            assert info["precision_used"] == want, (mode, off, info)
+            if mode == "pilot":
+                assert info["pilot_utterances"] == U // 50 and 0 <= info["pilot_listed"] <= U // 50, info
+            else:   # (late: the split pass ran on everything; what it listed is known in full — unless nothing was listed at all)
+                assert info["pilot_utterances"] in (0, U) and 0 <= info["pilot_listed"] <= U, info
+            assert (ra["argmax"] == r0["argmax"]).all(), (mode, off)
+            if want == 0:
+                assert torch.equal(ra["scores"], r0["scores"]) and sc.last_rescored == 0
+            else:
+                assert float((ra["scores"] - r0["scores"]).abs().max()) <= 1e-4 * float(r0["scores"].abs().max())
+            onlyam = sc.score(X, seg, precision=4, scores=False)
+            assert "scores" not in onlyam and (onlyam["argmax"] == r0["argmax"]).all()
+    # a tiny batch: fp32 without a pilot; score_samples: the parity path
+    small = api.Segments.from_lengths(ctx, [T] * 100)
+    rs = sc.score(Xbig[:100 * T], small, precision=4)
+    assert sc.last_auto["precision_used"] == 0 and sc.last_auto["pilot_utterances"] == 0
+    assert torch.equal(rs["scores"], sc.score(Xbig[:100 * T], small, precision=0)["scores"])
+    rl = sc.score(Xbig[:100 * T], small, precision=4, loglik=True)
+    assert rl["loglik"].shape == (S + 1, 100 * T)
     with pytest.raises(ValueError):
-        sc.score(X, seg, precision=5)
+        sc.score(Xbig[:100 * T], small, precision=5)
 
 
 def test_cosine_precision_auto(ssp):
