@@ -504,8 +504,9 @@ struct Cos16Args {
     // later stages of a cascade: the embeddings are X[rows[i]], i < *n_dev (device-side count of the previous stage's list)
     const int32_t* rows;
     const int32_t* n_dev;
-    // pilot of precision 3 (auto): also count the rows whose two best cosines are closer than band2b (nullable)
-    int32_t* count2;
+    // pilot of precision 3 (auto): also mark the rows whose two best cosines are closer than band2b (nullable; mask words like `mask`,
+    // counted by cos_compact_kernel — an atomic per wave on one counter would serialise here as it did for the lists)
+    uint32_t* mask2b;
     float band2b;
 };
 
@@ -696,10 +697,10 @@ __global__ __launch_bounds__(256, 3) void cosine_bf16x3_kernel(Cos16Args a) {
     const bool again = mine && (must || (a.S > 1 && !(b1 - b2 >= a.band2)));
     const unsigned long long m = __builtin_amdgcn_ballot_w64(again);   // (`mine` holds on lanes 0..31 only: the word's 32 bits)
     if (lane == 0) a.mask[col0 >> 5] = (uint32_t)m;
-    if (a.count2) {   // (wave-uniform: a kernel argument)
+    if (a.mask2b) {   // (wave-uniform: a kernel argument)
         const bool close2 = mine && (must || (a.S > 1 && !(b1 - b2 >= a.band2b)));
         const unsigned long long m2 = __builtin_amdgcn_ballot_w64(close2);
-        if (m2 != 0 && lane == 0) atomicAdd(a.count2, __popcll(m2));
+        if (lane == 0) a.mask2b[col0 >> 5] = (uint32_t)m2;
     }
     if (mine && !again) {
         if (a.argmin) a.argmin[go] = i1;
@@ -1085,10 +1086,11 @@ int ssp_cosine_identify2(ssp_ctx* ctx, const float* X, int64_t N, int32_t d, con
             if (const char* e = getenv("SSP_COS_AUTO_PILOT")) n_p = std::max<int64_t>(1, atoll(e));
             n_p = std::min(n_p, N) & ~(int64_t)127;   // (whole workgroups: the sweep behind the pilot starts on a mask-word boundary)
             Cos16Args p1{dX, img16.as<__bf16>(), dA, dM, mask1, list1.as<int32_t>(), cnt, cnt + 2, n_p, d, S, n_tiles, 2.0f * cos_band1(d), nullptr, nullptr};
-            p1.count2 = cnt + 3;
+            p1.mask2b = mask2;   // (the second sweep's words and list are free until that sweep runs)
             p1.band2b = 2.0f * cos_band(d);
             SSP_TRY(launch_cos16_nk<1>(nk, p1, s));
-            SSP_TRY(launch_cos_compact(mask1, n_p, nullptr, nullptr, 0, list1.as<int32_t>(), cnt, s));   // (its count is what the host reads)
+            SSP_TRY(launch_cos_compact(mask1, n_p, nullptr, nullptr, 0, list1.as<int32_t>(), cnt, s));       // (the counts are what the host reads)
+            SSP_TRY(launch_cos_compact(mask2, n_p, nullptr, nullptr, 0, list2.as<int32_t>(), cnt + 3, s));
             if (!ctx->pinned_words) SSP_HIP(hipHostMalloc((void**)&ctx->pinned_words, 64, hipHostMallocDefault));   // (pinned: the 16-byte read-back is a plain DMA)
             int32_t* h = ctx->pinned_words;
             SSP_HIP(hipMemcpyAsync(h, count.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
