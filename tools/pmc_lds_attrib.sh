@@ -2,6 +2,8 @@
 # LDS bank-conflict attribution of the headline MFCC kernel by ablation builds (GPU box): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE /
 # SQ_INSTS_LDS of the first kernel per launch at configs[1], one rocprofv3 --pmc pass per library variant (tools/scratch/variants/<name>.so,
 # '-' = the in-tree library).   tools/pmc_lds_attrib.sh <variant> ...   -> gpurun_out/lds_attrib.txt
+# The round-6 attribution (profiles/r06_lds_attrib.txt) used, built here beforehand with tools/variant_flags.sh <name> mfcc_stream,mfcc_stream_walk <flags>:
+#   psh0 = -DSSP_S_PSHIFT=0 (the round-5 P-row layout) | nomel = -DSSP_S_NOMEL (no piece filterbank) | pm64 = -DSSP_S_PM64 (partner through a b64 read)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 O=$ROOT/gpurun_out/lds_attrib; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
