@@ -17,6 +17,7 @@ if has bench; then
 fi
 if has stats; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_all -o run -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-env --detail $O/prof_all_detail.json > $O/prof_all.log 2>&1
+  cp $(find $O/prof_all -name "*kernel_trace.csv" | head -1) $O/kernel_trace.csv   # (per launch: the host-fed stages launch the headline kernel per slice, which the per-kernel average mixes in)
   cp $(find $O/prof_all -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv && rm -rf $O/prof_all
   echo "stats: $(wc -l < $O/kernel_stats.csv) rows"
 fi

@@ -26,6 +26,27 @@ if have("kernel_stats.csv"):
                          "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-env   (MI355X, %s, tree %s)" % (R, git)],
                         capture_output=True, text=True).stdout
     md = "\n".join(l for l in md.splitlines() if "at::native" not in l) + "\n"
+    if have("kernel_trace.csv"):   # the same run, per launch: full-size launches of the kernels the rooflines are quoted on
+        by = collections.OrderedDict()
+        for r in csv.DictReader(open(os.path.join(S, "kernel_trace.csv"))):
+            n = r["Kernel_Name"]
+            if any(k in n for k in ("mfcc_stream512_kernel<13, 2, 1, 3, 6, 2, 3, 0, 0>", "gmm_loglik_kernel<10, 2, true>", "cosine_reg_kernel<32, false>")):
+                by.setdefault(n, []).append(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, int(r["Grid_Size_X"])))
+        md += "\nPer workload, from the kernel trace of the SAME run (the host-fed stages launch these kernels once per 64-MiB slice and the\n" \
+              "split-precision scorers once per re-scoring pass / pilot: the per-kernel averages above mix those in):\n\n| kernel | launches of one workload (grouped by duration) | avg ms | min ms | max ms |\n|---|---|---|---|---|\n"
+        for n, v in by.items():   # (the stream kernel's grid is persistent and the list-driven launches are sized for the worst case: duration
+            # tells.  One kernel instance serves several workloads — configs[2] and the configs[3] sample, the 100 000-utterance pass and the
+            # stages that reuse its plan — so launches are grouped by duration: a new group where the next one is under 0.7 x the group's longest)
+            ds = sorted((x[0] for x in v), reverse=True)
+            groups = []
+            for x in ds:
+                if groups and x >= 0.7 * groups[-1][0]:
+                    groups[-1].append(x)
+                else:
+                    groups.append([x])
+            for grp in groups:
+                if len(grp) >= 2 and sum(grp) / len(grp) >= 0.5:
+                    md += "| `%s` | %d of %d | %.3f | %.3f | %.3f |\n" % (n.split("(")[0], len(grp), len(v), sum(grp) / len(grp), min(grp), max(grp))
     md += "\n(torch's own elementwise / reduction kernels that build the synthetic inputs are left out of this table; they are in the csv.\n" \
           "This file mixes every stage's launches of a kernel in one row; the per-stage files %s_stage_*.md list the launches one by one.)\n" % R
     open(os.path.join(P, "%s_kernel_stats.md" % R), "w").write(md)
